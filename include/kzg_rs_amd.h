@@ -1,0 +1,147 @@
+/*
+ * kzg_rs_amd.h - C ABI of the MI355X-native KZG blob-proof verifier (libkzg_rs_amd.so).
+ *
+ * Drop-in boundary for the verification path of succinctlabs/kzg-rs v0.2.8.  The reference has
+ * no FFI today (its boundary is the Rust API re-exported at src/lib.rs:12-18); each entry point
+ * below replaces one Rust function and is what a `kzg-rs`-compatible shim crate binds
+ * (INTEGRATION.md shows the Rust `extern "C"` block and the shim).  Shapes follow
+ * c-kzg-4844's C API so C callers can switch too.
+ *
+ * Conventions
+ *   - plain pointers + sizes; all pointers are borrowed for the duration of the call.
+ *   - return value: KzgRet.  KZG_OK means "*ok is valid" (Ok(true)/Ok(false) in the reference);
+ *     every other value is the reference's Err(KzgError::...) (src/enums.rs:6-18):
+ *         KZG_BADARGS        <-> KzgError::BadArgs            (undecodable / non-canonical input,
+ *                                                              src/kzg_proof.rs:17-43)
+ *         KZG_INVALID_LENGTH <-> KzgError::InvalidBytesLength (src/dtypes.rs:20-25,
+ *                                                              src/kzg_proof.rs:491-501)
+ *         KZG_ERROR          <-> KzgError::InternalError      (HIP failure, no GPU, ...)
+ *         KZG_MALLOC         <-> (allocation failure; c-kzg-4844's C_KZG_MALLOC)
+ *         KZG_BAD_SETUP      <-> KzgError::InvalidTrustedSetup
+ *     kzg_last_error() returns a thread-local message for the last non-OK return.
+ *   - there is NO CPU fallback: without a usable gfx950 device every call returns KZG_ERROR.
+ *   - thread safety: entry points may be called concurrently with one shared settings handle
+ *     (calls on one handle are serialised internally); handles are immutable after creation.
+ */
+#ifndef KZG_RS_AMD_H
+#define KZG_RS_AMD_H
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KZG_BYTES_PER_FIELD_ELEMENT 32      /* src/consts.rs:3  */
+#define KZG_FIELD_ELEMENTS_PER_BLOB 4096    /* src/consts.rs:7  */
+#define KZG_BYTES_PER_BLOB 131072           /* src/consts.rs:8  */
+#define KZG_BYTES_PER_COMMITMENT 48         /* src/consts.rs:9  */
+#define KZG_BYTES_PER_PROOF 48              /* src/consts.rs:10 */
+#define KZG_BYTES_PER_G2 96                 /* src/consts.rs:2  */
+
+typedef enum {
+    KZG_OK = 0,
+    KZG_BADARGS = 1,
+    KZG_ERROR = 2,
+    KZG_MALLOC = 3,
+    KZG_INVALID_LENGTH = 4,
+    KZG_BAD_SETUP = 5
+} KzgRet;
+
+/* Opaque settings handle: replaces KzgSettings / EnvKzgSettings (src/trusted_setup.rs:44-98).
+ * Owns the per-device tables (roots of unity in bit-reversed order, prepared lines of [tau]G2
+ * and of the G2 generator, pairing programs) and the call workspace. */
+typedef struct KzgSettings KzgSettings;
+
+/* KzgSettings::load_trusted_setup_file (src/trusted_setup.rs:94-98) for a caller-supplied copy of
+ * the text format of src/trusted_setup.txt / build.rs:23-87:
+ *   "<n_g1>\n<n_g2>\n" + n_g1 lines of 96 hex chars (G1, Lagrange) + n_g2 lines of 192 hex chars (G2).
+ * Verification reads only roots_of_unity (recomputed from SCALE2_ROOT_OF_UNITY[12],
+ * build.rs:131-170) and g2_points[1] (src/kzg_proof.rs:211,386,438). */
+KzgRet kzg_settings_load_trusted_setup(KzgSettings **out, const char *txt, size_t len);
+/* EnvKzgSettings::Custom (src/trusted_setup.rs:52-57): settings from g2_points[1] = [tau]G2 alone
+ * (96-byte compressed).  Used by the synthetic known-tau workloads of the benchmark. */
+KzgRet kzg_settings_from_tau_g2(KzgSettings **out, const uint8_t tau_g2[96]);
+void kzg_settings_free(KzgSettings *s);
+/* roots_of_unity[i] as 32 big-endian bytes (i < 4096), for parity tests of the settings tables. */
+KzgRet kzg_settings_root_of_unity(const KzgSettings *s, size_t i, uint8_t out[32]);
+/* g2_points[1] re-compressed from the device-side decompressed point (round-trip check). */
+KzgRet kzg_settings_tau_g2(const KzgSettings *s, uint8_t out[96]);
+
+/* KzgProof::verify_kzg_proof (src/kzg_proof.rs:353-397). */
+KzgRet kzg_verify_kzg_proof(bool *ok, const uint8_t commitment[48], const uint8_t z[32], const uint8_t y[32],
+                            const uint8_t proof[48], const KzgSettings *s);
+/* KzgProof::verify_blob_kzg_proof (src/kzg_proof.rs:446-470). */
+KzgRet kzg_verify_blob_kzg_proof(bool *ok, const uint8_t *blob, const uint8_t commitment[48], const uint8_t proof[48],
+                                 const KzgSettings *s);
+/* KzgProof::verify_blob_kzg_proof_batch (src/kzg_proof.rs:472-525).  blobs: n * 131072 bytes,
+ * commitments / proofs: n * 48 bytes, HOST memory (a Rust Vec<Blob> is exactly this layout).
+ * n == 0 -> *ok = true (:478-480).  The Vec-length-mismatch errors (:491-501) are raised by the
+ * caller-side shim, which is the only place that knows three separate lengths. */
+KzgRet kzg_verify_blob_kzg_proof_batch(bool *ok, const uint8_t *blobs, const uint8_t *commitments,
+                                       const uint8_t *proofs, size_t n, const KzgSettings *s);
+/* Same, with all three arrays already resident in DEVICE memory (HBM) - the form the throughput
+ * benchmark times.  Pointers are device pointers on the settings' device. */
+KzgRet kzg_verify_blob_kzg_proof_batch_device(bool *ok, const void *d_blobs, const void *d_commitments,
+                                              const void *d_proofs, size_t n, const KzgSettings *s);
+
+/* ---- multi-GPU: one process per GPU, the batch sharded by blob in contiguous index ranges ----
+ * (the loop of src/kzg_proof.rs:261-273 is the data-parallel axis; the batch challenge r of :291-348
+ * needs every (C, z, y, pi), and the three MSMs of :419-430 are sums that split by index range).
+ *   1. kzg_shard_phase1 on every rank: decode + challenge + evaluate its n_local blobs (device pointers);
+ *      returns its slice of the batch transcript: n_local records of 160 bytes C || z(LE) || y(LE) || pi.
+ *   2. the caller all-gathers the records in rank order (RCCL / any transport).
+ *   3. kzg_shard_phase2 on every rank: r = H(transcript) from all n_total records, then the rank's partial
+ *      sums A_k = sum r^(offset+i) pi_i and B_k = sum r^(offset+i) (C_i + z_i pi_i) - (sum r^(offset+i) y_i) G
+ *      as 2 x 144 bytes (Jacobian X,Y,Z, 12 x u32 little-endian Montgomery limbs each).
+ *   4. the caller all-gathers the 288-byte partials (point addition is not an RCCL reduction op).
+ *   5. kzg_shard_finish on any rank: fold the partials and run the single pairing check. */
+KzgRet kzg_shard_phase1(uint8_t *records_out, const void *d_blobs, const void *d_commitments, const void *d_proofs,
+                        size_t n_local, const KzgSettings *s);
+KzgRet kzg_shard_phase2(uint8_t partial_out[288], const uint8_t *all_records, size_t n_total, size_t offset,
+                        size_t n_local, const KzgSettings *s);
+KzgRet kzg_shard_finish(bool *ok, const uint8_t *partials, size_t world, const KzgSettings *s);
+
+/* ---- pieces of the path, exposed for parity tests and the per-kernel benchmarks ---- */
+/* compute_challenge (src/kzg_proof.rs:46-72) for n blobs: z_out = n * 32 bytes, big-endian canonical.
+ * Host pointers.  commitments are used as bytes (to_compressed(from_compressed(b)) == b). */
+KzgRet kzg_compute_challenges(uint8_t *z_out, const uint8_t *blobs, const uint8_t *commitments, size_t n,
+                              const KzgSettings *s);
+/* evaluate_polynomial_in_evaluation_form (src/kzg_proof.rs:94-133) for n blobs at n points:
+ * zs = n * 32 bytes big-endian (reduced mod r like scalar_from_bytes_unchecked :74-81),
+ * ys_out = n * 32 bytes big-endian canonical.  KZG_BADARGS if any blob element is >= r
+ * (src/dtypes.rs:48-57).  Host pointers. */
+KzgRet kzg_evaluate_polynomials(uint8_t *ys_out, const uint8_t *blobs, const uint8_t *zs, size_t n,
+                                const KzgSettings *s);
+/* Device-resident form of the above (BASELINE config 3): d_z / d_y are n * 32-byte little-endian
+ * limb arrays (plain integers) in device memory. */
+KzgRet kzg_evaluate_polynomials_device(void *d_y, const void *d_blobs, const void *d_z, size_t n,
+                                       const KzgSettings *s);
+/* G1Affine::from_compressed (src/kzg_proof.rs:17-25) for n points: status_out[i] = 0 valid,
+ * 1 valid identity, 2 rejected; xy_out (optional, n * 96 bytes) = affine x || y big-endian. */
+KzgRet kzg_g1_decompress(uint8_t *status_out, uint8_t *xy_out, const uint8_t *points48, size_t n,
+                         const KzgSettings *s);
+/* G1Projective::msm_variable_base (call sites src/kzg_proof.rs:419,429,430): out = sum scalars[i] * points[i];
+ * points: n * 48 bytes compressed (subgroup unchecked), scalars: n * 32 bytes big-endian (reduced mod r),
+ * out: 48 bytes compressed.  Host pointers. */
+KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t *points48, const uint8_t *scalars, size_t n, const KzgSettings *s);
+/* out48[i] = compress(scalars[i] * G1::generator()); scalars n * 32 bytes big-endian (reduced mod r).
+ * Prover-side helper used to build synthetic (commitment, proof) pairs under a
+ * known-tau test setup (the `G1Affine::generator() * scalar` of src/kzg_proof.rs:388,423). */
+KzgRet kzg_g1_mul_generator(uint8_t *out48, const uint8_t *scalars, size_t n, const KzgSettings *s);
+/* pairings_verify (src/pairings.rs:5-9) specialised to the verifier's use (src/kzg_proof.rs:436-441):
+ * *ok = ( e(a, g2_points[1]) == e(b, G2::generator()) ); a, b: 48-byte compressed G1 (unchecked). */
+KzgRet kzg_pairing_check(bool *ok, const uint8_t a[48], const uint8_t b[48], const KzgSettings *s);
+
+/* Timing of the last batch call on this handle, in milliseconds, measured with HIP events on the
+ * library's own stream: [0] whole call (device work), [1] per-blob phase (challenge + evaluate +
+ * point decode), [2] MSM, [3] pairing, [4] evaluate kernel alone, [5] challenge kernel alone. */
+KzgRet kzg_last_timings(const KzgSettings *s, float out_ms[8]);
+
+const char *kzg_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,292 @@
+"""Host-side mirror of the reference's public API (succinctlabs/kzg-rs v0.2.8, src/lib.rs:12-18)
+over the C ABI of libkzg_rs_amd.so (include/kzg_rs_amd.h).
+
+Same names, argument meaning and error behaviour as the Rust crate so parity tests read like the
+reference's own tests (src/kzg_proof.rs:604-737):
+
+    Bytes32 / Bytes48 / Blob          src/dtypes.rs:7-57      (from_slice length check)
+    KzgError                          src/enums.rs:6-18
+    KzgSettings.load_trusted_setup_file()   src/trusted_setup.rs:94-98
+    KzgProof.verify_kzg_proof / verify_blob_kzg_proof / verify_blob_kzg_proof_batch
+                                      src/kzg_proof.rs:353-525
+
+This module is a ctypes binding only: there is no Python or CPU implementation behind it.  If the
+HIP library is missing, or no gfx950 device is usable, every call raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libkzg_rs_amd.so")
+TRUSTED_SETUP_PATH = os.path.join(HERE, "data", "trusted_setup.txt")
+
+BYTES_PER_FIELD_ELEMENT = 32
+FIELD_ELEMENTS_PER_BLOB = 4096
+BYTES_PER_BLOB = 131072
+BYTES_PER_COMMITMENT = 48
+BYTES_PER_PROOF = 48
+
+KZG_OK, KZG_BADARGS, KZG_ERROR, KZG_MALLOC, KZG_INVALID_LENGTH, KZG_BAD_SETUP = range(6)
+
+
+class KzgError(Exception):
+    """src/enums.rs:6-18.  `.kind` is the variant name."""
+
+    def __init__(self, kind, msg=""):
+        super().__init__("%s: %s" % (kind, msg))
+        self.kind = kind
+        self.msg = msg
+
+
+def BadArgs(msg):
+    return KzgError("BadArgs", msg)
+
+
+def InvalidBytesLength(msg):
+    return KzgError("InvalidBytesLength", msg)
+
+
+_KIND = {KZG_BADARGS: "BadArgs", KZG_ERROR: "InternalError", KZG_MALLOC: "InternalError",
+         KZG_INVALID_LENGTH: "InvalidBytesLength", KZG_BAD_SETUP: "InvalidTrustedSetup"}
+
+_lib = None
+
+
+def lib():
+    """Load libkzg_rs_amd.so.  No fallback: a missing library is a hard error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KzgError("InternalError", "libkzg_rs_amd.so is not built (python -m kzg_rs_amd.build); "
+                                            "there is no CPU fallback")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes cannot share a process.
+        # When torch is installed, let it load its runtime first so this library binds to the same one.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+        L = C.CDLL(LIB_PATH)
+        vp, pp, u8, sz, bp = C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t, C.POINTER(C.c_bool)
+        L.kzg_settings_load_trusted_setup.argtypes = [pp, u8, sz]
+        L.kzg_settings_from_tau_g2.argtypes = [pp, u8]
+        L.kzg_settings_free.argtypes = [vp]
+        L.kzg_settings_free.restype = None
+        L.kzg_settings_root_of_unity.argtypes = [vp, sz, u8]
+        L.kzg_settings_tau_g2.argtypes = [vp, u8]
+        L.kzg_verify_kzg_proof.argtypes = [bp, u8, u8, u8, u8, vp]
+        L.kzg_verify_blob_kzg_proof.argtypes = [bp, u8, u8, u8, vp]
+        L.kzg_verify_blob_kzg_proof_batch.argtypes = [bp, u8, u8, u8, sz, vp]
+        L.kzg_verify_blob_kzg_proof_batch_device.argtypes = [bp, vp, vp, vp, sz, vp]
+        L.kzg_compute_challenges.argtypes = [u8, u8, u8, sz, vp]
+        L.kzg_evaluate_polynomials.argtypes = [u8, u8, u8, sz, vp]
+        L.kzg_evaluate_polynomials_device.argtypes = [vp, vp, vp, sz, vp]
+        L.kzg_g1_decompress.argtypes = [u8, u8, u8, sz, vp]
+        L.kzg_g1_msm.argtypes = [u8, u8, u8, sz, vp]
+        L.kzg_pairing_check.argtypes = [bp, u8, u8, vp]
+        L.kzg_g1_mul_generator.argtypes = [u8, u8, sz, vp]
+        L.kzg_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
+        L.kzg_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != KZG_OK:
+        raise KzgError(_KIND.get(rc, "InternalError"), lib().kzg_last_error().decode(errors="replace"))
+
+
+class _BytesN:
+    SIZE = 0
+
+    def __init__(self, data):
+        self.data = bytes(data)
+
+    @classmethod
+    def from_slice(cls, data):
+        """src/dtypes.rs:20-29."""
+        if len(data) != cls.SIZE:
+            raise InvalidBytesLength("Invalid slice length")
+        return cls(data)
+
+    @classmethod
+    def from_hex(cls, s):
+        return cls.from_slice(bytes.fromhex(s[2:] if s.startswith("0x") else s))
+
+    def as_slice(self):
+        return self.data
+
+
+class Bytes32(_BytesN):
+    SIZE = 32
+
+
+class Bytes48(_BytesN):
+    SIZE = 48
+
+
+class Blob(_BytesN):
+    SIZE = BYTES_PER_BLOB
+
+
+class KzgSettings:
+    """Opaque device-side settings (replaces src/trusted_setup.rs:44-50)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def load_trusted_setup_file(cls, path=None):
+        """src/trusted_setup.rs:94-98 (the reference embeds the file at build time; here the same
+        public ceremony file ships as package data)."""
+        txt = open(path or TRUSTED_SETUP_PATH, "rb").read()
+        h = C.c_void_p()
+        _chk(lib().kzg_settings_load_trusted_setup(C.byref(h), txt, len(txt)))
+        return cls(h)
+
+    @classmethod
+    def from_tau_g2(cls, tau_g2):
+        """EnvKzgSettings::Custom (src/trusted_setup.rs:52-57) from g2_points[1] alone."""
+        h = C.c_void_p()
+        _chk(lib().kzg_settings_from_tau_g2(C.byref(h), bytes(tau_g2)))
+        return cls(h)
+
+    def root_of_unity(self, i):
+        out = C.create_string_buffer(32)
+        _chk(lib().kzg_settings_root_of_unity(self._h, i, out))
+        return out.raw
+
+    def tau_g2(self):
+        out = C.create_string_buffer(96)
+        _chk(lib().kzg_settings_tau_g2(self._h, out))
+        return out.raw
+
+    def last_timings(self):
+        t = (C.c_float * 8)()
+        _chk(lib().kzg_last_timings(self._h, t))
+        return list(t)
+
+    def close(self):
+        if self._h:
+            lib().kzg_settings_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_settings = None
+
+
+class EnvKzgSettings:
+    """src/trusted_setup.rs:52-92: Default (cached mainnet setup) or Custom(settings)."""
+
+    def __init__(self, custom=None):
+        self.custom = custom
+
+    def get(self):
+        global _default_settings
+        if self.custom is not None:
+            return self.custom
+        if _default_settings is None:
+            _default_settings = KzgSettings.load_trusted_setup_file()
+        return _default_settings
+
+
+class KzgProof:
+    @staticmethod
+    def verify_kzg_proof(commitment_bytes, z_bytes, y_bytes, proof_bytes, kzg_settings):
+        """src/kzg_proof.rs:353-397."""
+        ok = C.c_bool(False)
+        _chk(lib().kzg_verify_kzg_proof(C.byref(ok), commitment_bytes.data, z_bytes.data, y_bytes.data, proof_bytes.data,
+                                        kzg_settings._h))
+        return bool(ok.value)
+
+    @staticmethod
+    def verify_blob_kzg_proof(blob, commitment_bytes, proof_bytes, kzg_settings):
+        """src/kzg_proof.rs:446-470."""
+        ok = C.c_bool(False)
+        _chk(lib().kzg_verify_blob_kzg_proof(C.byref(ok), blob.data, commitment_bytes.data, proof_bytes.data,
+                                             kzg_settings._h))
+        return bool(ok.value)
+
+    @staticmethod
+    def verify_blob_kzg_proof_batch(blobs, commitments_bytes, proofs_bytes, kzg_settings):
+        """src/kzg_proof.rs:472-525, including the order of its early returns (quirk Q2:
+        empty -> Ok(true) and the single-blob shortcut come before the length checks)."""
+        if len(blobs) == 0:
+            return True
+        if len(blobs) == 1:
+            if not commitments_bytes or not proofs_bytes:
+                raise IndexError("index out of bounds")  # the reference panics on [0] here
+            return KzgProof.verify_blob_kzg_proof(blobs[0], commitments_bytes[0], proofs_bytes[0], kzg_settings)
+        if len(blobs) != len(commitments_bytes):
+            raise InvalidBytesLength("Invalid commitments length")
+        if len(blobs) != len(proofs_bytes):
+            raise InvalidBytesLength("Invalid proofs length")
+        ok = C.c_bool(False)
+        _chk(lib().kzg_verify_blob_kzg_proof_batch(
+            C.byref(ok), b"".join(b.data for b in blobs), b"".join(c.data for c in commitments_bytes),
+            b"".join(p.data for p in proofs_bytes), len(blobs), kzg_settings._h))
+        return bool(ok.value)
+
+    @staticmethod
+    def verify_blob_kzg_proof_batch_device(d_blobs, d_commitments, d_proofs, n, kzg_settings):
+        """Device-resident form: arguments are device pointers (ints), e.g. torch tensor .data_ptr()."""
+        ok = C.c_bool(False)
+        _chk(lib().kzg_verify_blob_kzg_proof_batch_device(C.byref(ok), d_blobs, d_commitments, d_proofs, n,
+                                                          kzg_settings._h))
+        return bool(ok.value)
+
+
+# ---- pieces of the path (parity tests / per-kernel benchmarks) ----
+
+def compute_challenges(blobs, commitments, kzg_settings):
+    """compute_challenge (src/kzg_proof.rs:46-72) for a list of blobs; returns list of 32-byte BE scalars."""
+    n = len(blobs)
+    out = C.create_string_buffer(32 * max(n, 1))
+    _chk(lib().kzg_compute_challenges(out, b"".join(blobs), b"".join(commitments), n, kzg_settings._h))
+    return [out.raw[32 * i: 32 * i + 32] for i in range(n)]
+
+
+def evaluate_polynomials(blobs, zs, kzg_settings):
+    """evaluate_polynomial_in_evaluation_form (src/kzg_proof.rs:94-133) for lists of blobs / 32-byte BE points."""
+    n = len(blobs)
+    out = C.create_string_buffer(32 * max(n, 1))
+    _chk(lib().kzg_evaluate_polynomials(out, b"".join(blobs), b"".join(zs), n, kzg_settings._h))
+    return [out.raw[32 * i: 32 * i + 32] for i in range(n)]
+
+
+def evaluate_polynomials_device(d_y, d_blobs, d_z, n, kzg_settings):
+    _chk(lib().kzg_evaluate_polynomials_device(d_y, d_blobs, d_z, n, kzg_settings._h))
+
+
+def g1_decompress(points, kzg_settings, want_xy=True):
+    n = len(points)
+    st = C.create_string_buffer(max(n, 1))
+    xy = C.create_string_buffer(96 * max(n, 1)) if want_xy else None
+    _chk(lib().kzg_g1_decompress(st, xy, b"".join(points), n, kzg_settings._h))
+    return list(st.raw[:n]), ([xy.raw[96 * i: 96 * i + 96] for i in range(n)] if want_xy else None)
+
+
+def g1_msm(points, scalars, kzg_settings):
+    n = len(points)
+    out = C.create_string_buffer(48)
+    _chk(lib().kzg_g1_msm(out, b"".join(points), b"".join(scalars), n, kzg_settings._h))
+    return out.raw
+
+
+def pairing_check(a, b, kzg_settings):
+    ok = C.c_bool(False)
+    _chk(lib().kzg_pairing_check(C.byref(ok), a, b, kzg_settings._h))
+    return bool(ok.value)
+
+
+def g1_mul_generator(scalars, kzg_settings):
+    """[k]G1 for a list of 32-byte big-endian scalars; returns list of 48-byte compressed points."""
+    n = len(scalars)
+    out = C.create_string_buffer(48 * max(n, 1))
+    _chk(lib().kzg_g1_mul_generator(out, b"".join(scalars), n, kzg_settings._h))
+    return [out.raw[48 * i: 48 * i + 48] for i in range(n)]

@@ -1,0 +1,209 @@
+// fr_kernels.hpp - the per-blob Fr hot path on gfx950:
+//   k_roots_tables      roots of unity (reference build.rs:131-170) in two Montgomery scalings
+//   k_blob_challenge    Fiat-Shamir challenge z (reference src/kzg_proof.rs:46-91)
+//   k_blob_evaluate     y = p(z), p given in evaluation form (reference src/kzg_proof.rs:94-133
+//                       + batch_inversion :155-201 + Blob::as_polynomial src/dtypes.rs:48-57)
+//
+// Evaluation algorithm (inversion-free restatement of the barycentric formula).
+// The reference computes  y = (z^4096 - 1)/4096 * sum_i p_i w_i / (z - w_i)  with one batch
+// inversion.  Because prod_i (z - w_i) = z^4096 - 1 exactly, putting the 4096 fractions over
+// their common denominator cancels the (z^4096 - 1) factor and leaves
+//        y = (1/4096) * N,   N = sum_i p_i w_i prod_{j != i} (z - w_j),
+// an identity of polynomials in z - so it is also correct at z = w_i (the reference's early
+// return :109-111) and needs no inversion and no special case.  N is built by a binary tree over
+// the bit-reversed index order: a block of 2^L consecutive indices k*2^L.. is a coset whose
+// denominator is  D_{L,k} = z^(2^L) - roots[k]  (the first 2^(12-L) roots of the SAME table), so
+//        N_{L+1,k} = Z_L (N_{L,2k} + N_{L,2k+1}) + roots[2k] (N_{L,2k} - N_{L,2k+1}),  Z_L = z^(2^L)
+// (2 multiplications per merge), and the first level folds the leaf products:
+//        N_{1,k} = roots[2k] z (p_2k - p_2k+1) + roots[k] (p_2k + p_2k+1)       (3 per pair).
+// Total 3*2048 + 2*2047 + 12 = 10 250 Fr multiplications per blob instead of ~20 480 + an
+// inversion + a 256-step pow; the result is the same field element, bit for bit.
+//
+// Mapping: ONE WAVEFRONT PER BLOB.  Lane t owns the 64 consecutive elements 64t..64t+63
+// (2 KiB of the blob), folds them depth-first with a 6-entry LDS stack (levels 1..6), then the
+// last 6 levels run across lanes with ds_bpermute shuffles.  No barriers beyond the one that
+// publishes the powers of z.
+#pragma once
+#include "field.hpp"
+#include "sha256.hpp"
+
+namespace kzg {
+
+constexpr int FE_PER_BLOB = 4096;
+constexpr int BLOB_BYTES = 131072;
+
+__device__ __forceinline__ uint32_t bitrev12(uint32_t i) { return __brev(i) >> 20; }
+
+// M[j]  = roots[j] * R      (Montgomery form),  roots[j] = omega^bitrev12(j)
+// DM[j] = roots[j] * R^2    ("double Montgomery": mul(DM[j], plain x) = roots[j]*x in Montgomery form)
+__global__ void k_roots_tables(Fr* __restrict__ M, Fr* __restrict__ DM) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= FE_PER_BLOB) return;
+    uint32_t e = bitrev12(j);
+    Fr w, acc = FrF::one();
+#pragma unroll
+    for (int i = 0; i < 8; i++) w.l[i] = consts::FR_OMEGA_MONT[i];
+    for (int b = 11; b >= 0; b--) {
+        acc = FrF::sqr(acc);
+        if ((e >> b) & 1) acc = FrF::mul(acc, w);
+    }
+    M[j] = acc;
+    Fr r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r2.l[i] = consts::FR_R2[i];
+    DM[j] = FrF::mul(acc, r2);
+}
+
+// 32 big-endian bytes (two uint4 as loaded from memory) -> 8 little-endian limbs
+__device__ __forceinline__ Fr fr_from_be_words(const uint4& hi, const uint4& lo) {
+    Fr r;
+    r.l[7] = __builtin_bswap32(hi.x); r.l[6] = __builtin_bswap32(hi.y);
+    r.l[5] = __builtin_bswap32(hi.z); r.l[4] = __builtin_bswap32(hi.w);
+    r.l[3] = __builtin_bswap32(lo.x); r.l[2] = __builtin_bswap32(lo.y);
+    r.l[1] = __builtin_bswap32(lo.z); r.l[0] = __builtin_bswap32(lo.w);
+    return r;
+}
+__device__ __forceinline__ void fr_to_be_words(uint4& hi, uint4& lo, const Fr& a) {
+    hi = make_uint4(__builtin_bswap32(a.l[7]), __builtin_bswap32(a.l[6]), __builtin_bswap32(a.l[5]), __builtin_bswap32(a.l[4]));
+    lo = make_uint4(__builtin_bswap32(a.l[3]), __builtin_bswap32(a.l[2]), __builtin_bswap32(a.l[1]), __builtin_bswap32(a.l[0]));
+}
+
+// ---------------------------------------------------------------- challenge (one lane per blob)
+// transcript = "FSBLOBVERIFY_V1_" || u64_be(0) || u64_be(4096) || blob || commitment   (131 152 B)
+// z = int_be(sha256(transcript)) mod r        (src/kzg_proof.rs:46-91)
+// Output: z as canonical little-endian limbs (plain integer, NOT Montgomery).
+__global__ __launch_bounds__(64) void k_blob_challenge(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
+                                                       Fr* __restrict__ z_out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* blob = reinterpret_cast<const uint4*>(blobs + (size_t)i * BLOB_BYTES);
+    const uint4* cm = reinterpret_cast<const uint4*>(commitments + (size_t)i * 48);
+    Sha256State st;
+    sha256_init(st);
+    uint32_t w[16];
+    // block 0: 32-byte header + blob[0..32)
+    w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;  // "FSBLOBVERIFY_V1_"
+    w[4] = 0; w[5] = 0; w[6] = 0; w[7] = FE_PER_BLOB;
+    {
+        uint4 a = blob[0], b = blob[1];
+        w[8] = __builtin_bswap32(a.x); w[9] = __builtin_bswap32(a.y); w[10] = __builtin_bswap32(a.z); w[11] = __builtin_bswap32(a.w);
+        w[12] = __builtin_bswap32(b.x); w[13] = __builtin_bswap32(b.y); w[14] = __builtin_bswap32(b.z); w[15] = __builtin_bswap32(b.w);
+    }
+    sha256_compress(st, w);
+    // blocks 1..2047: blob[64b-32 .. 64b+32)
+    for (int b = 1; b < 2048; b++) {
+        const uint4* p = blob + (4 * b - 2);
+        uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+        w[0] = __builtin_bswap32(q0.x); w[1] = __builtin_bswap32(q0.y); w[2] = __builtin_bswap32(q0.z); w[3] = __builtin_bswap32(q0.w);
+        w[4] = __builtin_bswap32(q1.x); w[5] = __builtin_bswap32(q1.y); w[6] = __builtin_bswap32(q1.z); w[7] = __builtin_bswap32(q1.w);
+        w[8] = __builtin_bswap32(q2.x); w[9] = __builtin_bswap32(q2.y); w[10] = __builtin_bswap32(q2.z); w[11] = __builtin_bswap32(q2.w);
+        w[12] = __builtin_bswap32(q3.x); w[13] = __builtin_bswap32(q3.y); w[14] = __builtin_bswap32(q3.z); w[15] = __builtin_bswap32(q3.w);
+        sha256_compress(st, w);
+    }
+    // block 2048: blob[131040..131072) + commitment[0..32)
+    {
+        uint4 q0 = blob[8190], q1 = blob[8191], q2 = cm[0], q3 = cm[1];
+        w[0] = __builtin_bswap32(q0.x); w[1] = __builtin_bswap32(q0.y); w[2] = __builtin_bswap32(q0.z); w[3] = __builtin_bswap32(q0.w);
+        w[4] = __builtin_bswap32(q1.x); w[5] = __builtin_bswap32(q1.y); w[6] = __builtin_bswap32(q1.z); w[7] = __builtin_bswap32(q1.w);
+        w[8] = __builtin_bswap32(q2.x); w[9] = __builtin_bswap32(q2.y); w[10] = __builtin_bswap32(q2.z); w[11] = __builtin_bswap32(q2.w);
+        w[12] = __builtin_bswap32(q3.x); w[13] = __builtin_bswap32(q3.y); w[14] = __builtin_bswap32(q3.z); w[15] = __builtin_bswap32(q3.w);
+        sha256_compress(st, w);
+    }
+    // final block: commitment[32..48) + 0x80 pad + bit length (131152 * 8)
+    {
+        uint4 q = cm[2];
+        w[0] = __builtin_bswap32(q.x); w[1] = __builtin_bswap32(q.y); w[2] = __builtin_bswap32(q.z); w[3] = __builtin_bswap32(q.w);
+        w[4] = 0x80000000u;
+#pragma unroll
+        for (int k = 5; k < 15; k++) w[k] = 0;
+        w[15] = 131152u * 8u;
+        sha256_compress(st, w);
+    }
+    // digest as big-endian integer, reduced mod r: to_mont reduces (d*R2*R^-1 = dR mod r), from_mont strips R
+    Fr d;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d.l[k] = st.h[7 - k];
+    z_out[i] = FrF::from_mont(FrF::to_mont(d));
+}
+
+// ---------------------------------------------------------------- evaluation (one wavefront per blob)
+__device__ __forceinline__ Fr fr_shfl_xor(const Fr& a, int mask) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = __shfl_xor((int)a.l[i], mask, 64);
+    return r;
+}
+
+// z_in: plain little-endian limbs (any value < 2^256; reduced mod r here, like scalar_from_bytes_unchecked)
+// y_out: plain little-endian canonical limbs.  status[b] |= 1 when a blob element is >= r
+// (src/kzg_proof.rs:36-41 -> KzgError::BadArgs).
+__global__ __launch_bounds__(64) void k_blob_evaluate(const uint8_t* __restrict__ blobs, const Fr* __restrict__ z_in,
+                                                      const Fr* __restrict__ M, const Fr* __restrict__ DM,
+                                                      Fr* __restrict__ y_out, uint32_t* __restrict__ status) {
+    const int blob_idx = blockIdx.x;
+    const int lane = threadIdx.x;
+    __shared__ Fr Z[13];              // Z[L] = z^(2^L), Montgomery
+    __shared__ uint4 stack[6][2][64]; // levels 1..6, two 16-byte halves, lane-major: conflict-free b128
+    if (lane == 0) {
+        Fr z = FrF::to_mont(z_in[blob_idx]);
+        Z[0] = z;
+        for (int l = 1; l <= 12; l++) {
+            z = FrF::sqr(z);
+            Z[l] = z;
+        }
+    }
+    __syncthreads();
+    const uint4* src = reinterpret_cast<const uint4*>(blobs + (size_t)blob_idx * BLOB_BYTES) + (size_t)lane * 128;
+    const Fr z0 = Z[0];
+    bool bad = false;
+    Fr n;
+    for (int q = 0; q < 32; q++) {
+        uint4 a_hi = src[4 * q], a_lo = src[4 * q + 1], b_hi = src[4 * q + 2], b_lo = src[4 * q + 3];
+        Fr pa = fr_from_be_words(a_hi, a_lo), pb = fr_from_be_words(b_hi, b_lo);
+        bad |= FrF::geq_mod(pa) | FrF::geq_mod(pb);
+        Fr u = FrF::sub(pa, pb), s = FrF::add(pa, pb);
+        int k = 32 * lane + q;  // level-1 node index
+        Fr t = FrF::mul(z0, u);  // plain z*u
+        n = FrF::add(FrF::mul(DM[2 * k], t), FrF::mul(DM[k], s));
+        int level = 1;
+        for (int qq = q; qq & 1; qq >>= 1) {
+            Fr na;
+            uint4 h0 = stack[level - 1][0][lane], h1 = stack[level - 1][1][lane];
+            na.l[0] = h0.x; na.l[1] = h0.y; na.l[2] = h0.z; na.l[3] = h0.w;
+            na.l[4] = h1.x; na.l[5] = h1.y; na.l[6] = h1.z; na.l[7] = h1.w;
+            Fr sum = FrF::add(na, n), dif = FrF::sub(na, n);
+            n = FrF::add(FrF::mul(Z[level], sum), FrF::mul(M[k & ~1], dif));
+            k >>= 1;
+            level++;
+        }
+        if (level <= 6 && q != 31) {
+            stack[level - 1][0][lane] = make_uint4(n.l[0], n.l[1], n.l[2], n.l[3]);
+            stack[level - 1][1][lane] = make_uint4(n.l[4], n.l[5], n.l[6], n.l[7]);
+        }
+    }
+    // n = N_{6,lane}; fold across lanes
+    for (int L = 6; L < 12; L++) {
+        int sh = L - 6;
+        Fr other = fr_shfl_xor(n, 1 << sh);
+        int j = lane >> sh;  // node index at level L
+        bool left = (j & 1) == 0;
+        Fr na, nb;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            na.l[i] = left ? n.l[i] : other.l[i];
+            nb.l[i] = left ? other.l[i] : n.l[i];
+        }
+        Fr sum = FrF::add(na, nb), dif = FrF::sub(na, nb);
+        n = FrF::add(FrF::mul(Z[L], sum), FrF::mul(M[j & ~1], dif));
+    }
+    unsigned long long any_bad = __ballot(bad);
+    if (lane == 0) {
+        Fr inv;
+#pragma unroll
+        for (int i = 0; i < 8; i++) inv.l[i] = consts::FR_INV4096_PLAIN[i];
+        y_out[blob_idx] = FrF::mul(n, inv);  // (N R)(1/4096) R^-1 = N/4096, plain
+        if (any_bad) atomicOr(&status[blob_idx], 1u);
+    }
+}
+
+}  // namespace kzg

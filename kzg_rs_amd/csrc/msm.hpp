@@ -1,0 +1,189 @@
+// msm.hpp - the random-linear-combination step of verify_kzg_proof_batch on gfx950
+// (reference src/kzg_proof.rs:399-444; compute_powers :279-289).
+//
+// The reference computes three size-n MSMs plus n full scalar multiplications G*y_i (:419-430).
+// The same group elements are obtained here from ONE pass:
+//     A = sum r^i pi_i
+//     B = sum r^i C_i + sum (r^i z_i) pi_i + (-(sum r^i y_i)) G
+// i.e. a multi-scalar multiplication over the term list
+//     t in [0,n)    : (pi_t,  a_t = r^t)        -> A
+//     t in [n,2n)   : (pi_t', b_t = r^t' z_t')  -> B
+//     t in [2n,3n)  : (C_t'', a_t'')            -> B
+//     t = 3n        : (G,     g = -sum r^i y_i) -> B
+//
+// Pippenger, window c = 8 bits (32 windows).  One workgroup per (window, output):
+//   1. counting sort of the output's terms by their 8-bit digit (LDS histogram + cursor),
+//      so that afterwards every lane walks its own bucket list and all lanes add at once;
+//   2. thread b accumulates bucket b with mixed Jacobian+affine additions;
+//   3. sum_b b*B_b by an LDS suffix scan followed by a tree sum (Jacobian points staged in LDS);
+// then k_msm_combine folds the 32 window sums (Horner, 8 doublings per window).
+#pragma once
+#include "g1.hpp"
+
+namespace kzg {
+
+constexpr int MSM_C = 8;
+constexpr int MSM_WINDOWS = 32;
+constexpr int MSM_BUCKETS = 256;
+
+struct MsmTerm {
+    uint32_t point;  // index into the affine point array
+};
+
+// ---------------------------------------------------------------- scalars
+// thread i: rp = r^(offset+i); a[i] = rp (plain), b[i] = rp*z_i (plain); per-block partial of
+// sum rp*y_i (Montgomery) to partial[blockIdx].   zs/ys: plain limbs.   r: plain limbs.
+// `offset` is the global index of this shard's first blob (multi-GPU: rank k starts its power
+// table at r^(k n/N) with one square-and-multiply per thread; compute_powers, src/kzg_proof.rs:279-289).
+__global__ __launch_bounds__(256) void k_batch_scalars(const Fr* __restrict__ r_plain, const Fr* __restrict__ zs,
+                                                       const Fr* __restrict__ ys, Fr* __restrict__ a_out,
+                                                       Fr* __restrict__ b_out, Fr* __restrict__ partial, int n,
+                                                       unsigned long long offset) {
+    __shared__ Fr red[256];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr acc = FrF::zero();
+    if (i < n) {
+        Fr r = FrF::to_mont(*r_plain);
+        Fr rp = FrF::one();
+        unsigned long long e = offset + (unsigned long long)i;
+        for (int b = 63 - __clzll(e | 1ull); b >= 0; b--) {
+            rp = FrF::sqr(rp);
+            if ((e >> b) & 1) rp = FrF::mul(rp, r);
+        }
+        a_out[i] = FrF::from_mont(rp);
+        b_out[i] = FrF::mul(rp, zs[i]);        // (r^i R) z R^-1 = r^i z, plain
+        acc = FrF::mul(rp, FrF::to_mont(ys[i]));  // Montgomery
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = FrF::add(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// g = -(sum of partials), plain limbs
+__global__ void k_finish_g(const Fr* __restrict__ partial, int nparts, Fr* __restrict__ g_out) {
+    if (threadIdx.x || blockIdx.x) return;
+    Fr s = FrF::zero();
+    for (int i = 0; i < nparts; i++) s = FrF::add(s, partial[i]);
+    *g_out = FrF::from_mont(FrF::neg(s));
+}
+
+// ---------------------------------------------------------------- bucket accumulation + reduction
+// Term t of output o is (point index, scalar pointer) given by two small tables prepared on the host:
+//   term_point[o][t], term_scalar[o][t]  (indices into points[] / scalars[]); nterms[o].
+// pflag[p] != 0 marks the identity (skipped).
+struct MsmDesc {
+    const G1Aff* points;
+    const uint32_t* pflag;
+    const Fr* scalars;          // plain little-endian limbs
+    const uint32_t* term_point;   // [2][max_terms]
+    const uint32_t* term_scalar;  // [2][max_terms]
+    uint32_t* sorted;             // [2][32][max_terms] scratch
+    G1Jac* window_sums;           // [2][32]
+    int nterms[2];
+    int max_terms;
+};
+
+__device__ __forceinline__ void lds_store_jac(uint32_t* base, int slot, const G1Jac& p) {
+    uint32_t* d = base + slot * 36;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        d[i] = p.x.l[i];
+        d[12 + i] = p.y.l[i];
+        d[24 + i] = p.z.l[i];
+    }
+}
+__device__ __forceinline__ G1Jac lds_load_jac(const uint32_t* base, int slot) {
+    const uint32_t* d = base + slot * 36;
+    G1Jac p;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        p.x.l[i] = d[i];
+        p.y.l[i] = d[12 + i];
+        p.z.l[i] = d[24 + i];
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_msm_window(MsmDesc d) {
+    const int w = blockIdx.x, o = blockIdx.y, tid = threadIdx.x;
+    const int nt = d.nterms[o];
+    const uint32_t* tp = d.term_point + (size_t)o * d.max_terms;
+    const uint32_t* tsc = d.term_scalar + (size_t)o * d.max_terms;
+    uint32_t* sorted = d.sorted + ((size_t)o * MSM_WINDOWS + w) * d.max_terms;
+    __shared__ uint32_t cnt[MSM_BUCKETS], off[MSM_BUCKETS + 1], cur[MSM_BUCKETS];
+    __shared__ uint32_t pts[MSM_BUCKETS * 36];  // 36 KiB: one Jacobian point per thread
+    cnt[tid] = 0;
+    cur[tid] = 0;
+    __syncthreads();
+    const uint8_t* sb = reinterpret_cast<const uint8_t*>(d.scalars);
+    // 1. counting sort by digit
+    for (int t = tid; t < nt; t += 256) {
+        uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + w];
+        atomicAdd(&cnt[dig], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t s = 0;
+        for (int b = 0; b < MSM_BUCKETS; b++) {
+            off[b] = s;
+            s += cnt[b];
+        }
+        off[MSM_BUCKETS] = s;
+    }
+    __syncthreads();
+    for (int t = tid; t < nt; t += 256) {
+        uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + w];
+        uint32_t pos = atomicAdd(&cur[dig], 1u);
+        sorted[off[dig] + pos] = tp[t];
+    }
+    __threadfence_block();
+    __syncthreads();
+    // 2. bucket tid (digit 0 contributes nothing)
+    G1Jac acc = g1_identity();
+    if (tid > 0) {
+        for (uint32_t k = off[tid]; k < off[tid + 1]; k++) acc = g1_add_affine(acc, d.points[sorted[k]]);
+    }
+    // 3. sum_b b*B_b = sum_b S_b,  S_b = sum_{b' >= b} B_b'   (suffix scan, then tree sum)
+    lds_store_jac(pts, tid, acc);
+    __syncthreads();
+    for (int s = 1; s < MSM_BUCKETS; s <<= 1) {
+        G1Jac other = g1_identity();
+        bool has = tid + s < MSM_BUCKETS;
+        if (has) other = lds_load_jac(pts, tid + s);
+        __syncthreads();
+        if (has) {
+            acc = g1_add(acc, other);
+            lds_store_jac(pts, tid, acc);
+        }
+        __syncthreads();
+    }
+    // acc = S_tid; S_0 includes bucket 0 (identity) so sum over tid >= 1
+    if (tid == 0) lds_store_jac(pts, 0, g1_identity());
+    __syncthreads();
+    for (int s = MSM_BUCKETS / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            G1Jac x = lds_load_jac(pts, tid), y = lds_load_jac(pts, tid + s);
+            lds_store_jac(pts, tid, g1_add(x, y));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) d.window_sums[o * MSM_WINDOWS + w] = lds_load_jac(pts, 0);
+}
+
+// out[o] = sum_w 2^(8w) W[o][w]   (Horner from the top window)
+__global__ void k_msm_combine(const G1Jac* __restrict__ window_sums, G1Jac* __restrict__ out) {
+    int o = blockIdx.x;
+    if (threadIdx.x) return;
+    G1Jac acc = window_sums[o * MSM_WINDOWS + MSM_WINDOWS - 1];
+    for (int w = MSM_WINDOWS - 2; w >= 0; w--) {
+        for (int k = 0; k < MSM_C; k++) acc = g1_dbl(acc);
+        acc = g1_add(acc, window_sums[o * MSM_WINDOWS + w]);
+    }
+    out[o] = acc;
+}
+
+}  // namespace kzg
