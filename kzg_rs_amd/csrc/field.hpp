@@ -44,15 +44,20 @@ struct FpParams {
 };
 
 // ---------------------------------------------------------------- carry helpers
+// clang's carry builtins lower to real v_add_co_u32 / v_addc_co_u32 (v_sub_co / v_subb_co) chains on
+// gfx950: one VALU instruction per limb.  (The portable `(uint64_t)a + b + carry` idiom is compiled by
+// hipcc into 64-bit adds plus register-pair shuffling, ~7 instructions per limb.)
 KZG_DEV uint32_t addc(uint32_t a, uint32_t b, uint32_t& carry) {
-    uint64_t s = (uint64_t)a + b + carry;
-    carry = (uint32_t)(s >> 32);
-    return (uint32_t)s;
+    unsigned c = carry;
+    uint32_t r = __builtin_addc(a, b, c, &c);
+    carry = c;
+    return r;
 }
 KZG_DEV uint32_t subb(uint32_t a, uint32_t b, uint32_t& borrow) {
-    uint64_t d = (uint64_t)a - b - borrow;
-    borrow = (uint32_t)(d >> 63);
-    return (uint32_t)d;
+    unsigned c = borrow;
+    uint32_t r = __builtin_subc(a, b, c, &c);
+    borrow = c;
+    return r;
 }
 
 #include "mac_chains.inc"
@@ -123,10 +128,12 @@ struct Field {
         uint32_t borrow = 0;
 #pragma unroll
         for (int i = 0; i < N; i++) d.l[i] = subb(a.l[i], b.l[i], borrow);
-        uint32_t mask = 0u - borrow, c = 0;
-        E r;
+        E t, r;
+        uint32_t c = 0;
 #pragma unroll
-        for (int i = 0; i < N; i++) r.l[i] = addc(d.l[i], P::mod(i) & mask, c);
+        for (int i = 0; i < N; i++) t.l[i] = addc(d.l[i], P::mod(i), c);
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = borrow ? t.l[i] : d.l[i];
         return r;
     }
     KZG_DEV static E neg(const E& a) { return sub(zero(), a); }

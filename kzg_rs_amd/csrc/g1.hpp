@@ -85,7 +85,7 @@ __device__ inline G1Jac g1_from_affine(const G1Aff& a) {
 }
 
 // dbl-2009-l (a = 0): 2M + 5S
-__device__ __noinline__ G1Jac g1_dbl(G1Jac p) {
+__device__ __forceinline__ G1Jac g1_dbl(const G1Jac& p) {
     Fp A = fp_sqr(p.x), B = fp_sqr(p.y), C = fp_sqr(B);
     Fp t = fp_sqr(fp_add(p.x, B));
     Fp D = fp_dbl(fp_sub(fp_sub(t, A), C));
@@ -100,7 +100,7 @@ __device__ __noinline__ G1Jac g1_dbl(G1Jac p) {
 }
 
 // general Jacobian addition with every special case handled (identity operands, P+P, P-P)
-__device__ __noinline__ G1Jac g1_add(G1Jac p, G1Jac q) {
+__device__ __noinline__ G1Jac g1_add(const G1Jac& p, const G1Jac& q) {
     if (g1_is_identity(p)) return q;
     if (g1_is_identity(q)) return p;
     Fp Z1Z1 = fp_sqr(p.z), Z2Z2 = fp_sqr(q.z);
@@ -120,7 +120,7 @@ __device__ __noinline__ G1Jac g1_add(G1Jac p, G1Jac q) {
 }
 
 // mixed addition p + (affine q, q != identity)
-__device__ __noinline__ G1Jac g1_add_affine(G1Jac p, G1Aff q) {
+__device__ __noinline__ G1Jac g1_add_affine(const G1Jac& p, const G1Aff& q) {
     if (g1_is_identity(p)) return g1_from_affine(q);
     Fp Z1Z1 = fp_sqr(p.z);
     Fp U2 = fp_mul(q.x, Z1Z1), S2 = fp_mul(fp_mul(q.y, p.z), Z1Z1);

@@ -35,12 +35,14 @@ __asm__(".section .rodata\n"
 extern "C" const unsigned char kzg_slp_prep_begin[], kzg_slp_prep_end[], kzg_slp_verify_begin[], kzg_slp_verify_end[];
 
 // ---------------------------------------------------------------- small kernels
-__global__ __launch_bounds__(64) void k_g1_decode(const uint8_t* __restrict__ bytes, G1Aff* __restrict__ out,
-                                                  uint32_t* __restrict__ flag, int n, int check_subgroup) {
+// points [0, n0) come from bytes0, [n0, n) from bytes1 (commitments then proofs in one launch)
+__global__ __launch_bounds__(64) void k_g1_decode(const uint8_t* __restrict__ bytes0, const uint8_t* __restrict__ bytes1, int n0,
+                                                  G1Aff* __restrict__ out, uint32_t* __restrict__ flag, int n, int check_subgroup) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const uint8_t* src = i < n0 ? bytes0 + (size_t)i * 48 : bytes1 + (size_t)(i - n0) * 48;
     G1Aff a;
-    uint32_t st = g1_decompress(a, bytes + (size_t)i * 48, check_subgroup != 0);
+    uint32_t st = g1_decompress(a, src, check_subgroup != 0);
     out[i] = a;
     flag[i] = st;
 }
@@ -92,12 +94,17 @@ __global__ void k_batch_terms(uint32_t* __restrict__ term_point, uint32_t* __res
     if (t == 0) {
         term_point[max_terms + 2 * n] = 2 * n;
         term_scalar[max_terms + 2 * n] = 2 * n;
-        G1Aff g;
-        g.x = fp_const(consts::G1_GEN_X_MONT);
-        g.y = fp_const(consts::G1_GEN_Y_MONT);
-        points[2 * n] = g;
-        pflag[2 * n] = 0;
     }
+}
+
+// the G1 generator as point `idx` (the -(sum r^i y_i) G term of the batch equation)
+__global__ void k_set_generator(G1Aff* __restrict__ points, uint32_t* __restrict__ pflag, int idx) {
+    if (threadIdx.x || blockIdx.x) return;
+    G1Aff g;
+    g.x = fp_const(consts::G1_GEN_X_MONT);
+    g.y = fp_const(consts::G1_GEN_Y_MONT);
+    points[idx] = g;
+    pflag[idx] = 0;
 }
 
 // plain msm: output 0 over terms (point t, scalar t)
@@ -276,7 +283,7 @@ struct Workspace {
     Fr *d_z = nullptr, *d_y = nullptr, *d_scalars = nullptr, *d_partial = nullptr, *d_r = nullptr;
     uint32_t *d_status = nullptr, *d_pflag = nullptr, *d_term_point = nullptr, *d_term_scalar = nullptr, *d_sorted = nullptr;
     G1Aff* d_points = nullptr;
-    G1Jac *d_window = nullptr, *d_ab = nullptr;
+    G1Jac *d_window = nullptr, *d_ab = nullptr, *d_mult = nullptr;
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
     uint8_t *d_stage_blobs = nullptr, *d_stage_cp = nullptr, *d_bytes = nullptr;
     // pinned host mirrors
@@ -319,9 +326,14 @@ static KzgRet upload_program(DevProgram& dp, const unsigned char* begin, const u
 }
 
 static KzgRet run_program(const DevProgram& dp, const Fp* d_in, const Fp* d_set, Fp* d_out, int instances, hipStream_t st) {
-    size_t lds = (size_t)dp.p.n_slots * 48;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_slp_run, dim3(instances), dim3(dp.p.lanes), lds, st, dp.p, d_in, d_set, d_out);
+    size_t lds = (size_t)dp.p.n_slots * 48 + (size_t)2 * SLP_GROUP * dp.p.lanes * sizeof(uint2);  // slots | descriptor ring
+    if (dp.p.lanes == 64) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp_run<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_slp_run<false>, dim3(instances), dim3(64), lds, st, dp.p, d_in, d_set, d_out);
+    } else {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp_run<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_slp_run<true>, dim3(instances), dim3(dp.p.lanes), lds, st, dp.p, d_in, d_set, d_out);
+    }
     HIPCHK(hipGetLastError());
     return KZG_OK;
 }
@@ -422,7 +434,7 @@ extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_
 
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
-                    w.d_sorted, w.d_points, w.d_window, w.d_ab, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes};
+                    w.d_sorted, w.d_points, w.d_window, w.d_ab, w.d_mult, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w.h_buf) (void)hipHostFree(w.h_buf);
@@ -466,6 +478,7 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t n, bool stage) {
         HIPCHK(hipMalloc(&w.d_sorted, 4 * 2 * MSM_WINDOWS * mt));
         HIPCHK(hipMalloc(&w.d_points, sizeof(G1Aff) * mt));
         HIPCHK(hipMalloc(&w.d_window, sizeof(G1Jac) * 2 * MSM_WINDOWS));
+        HIPCHK(hipMalloc(&w.d_mult, sizeof(G1Jac) * MSM_CHUNKS * mt));
         HIPCHK(hipMalloc(&w.d_ab, sizeof(G1Jac) * 2));
         HIPCHK(hipMalloc(&w.d_slp_in, sizeof(Fp) * 6));
         HIPCHK(hipMalloc(&w.d_slp_out, sizeof(Fp) * 16));
@@ -495,7 +508,7 @@ static KzgRet run_msm(const KzgSettings* s, size_t n) {
     hipLaunchKernelGGL(k_batch_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar,
                        w.d_points, w.d_pflag, (int)n, mt);
     MsmDesc d{};
-    d.points = w.d_points;
+    d.mult = w.d_mult;
     d.pflag = w.d_pflag;
     d.scalars = w.d_scalars;
     d.term_point = w.d_term_point;
@@ -505,8 +518,9 @@ static KzgRet run_msm(const KzgSettings* s, size_t n) {
     d.nterms[0] = (int)n;
     d.nterms[1] = (int)(2 * n + 1);
     d.max_terms = mt;
+    d.stride = mt;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
-    hipLaunchKernelGGL(k_msm_window, dim3(MSM_WINDOWS, 2), dim3(256), 0, s->s1, d);
+    hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, 2), dim3(256), 0, s->s1, d);
     hipLaunchKernelGGL(k_msm_combine, dim3(2), dim3(64), 0, s->s1, w.d_window, w.d_ab);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
@@ -542,9 +556,14 @@ static KzgRet run_tail(bool* ok, const KzgSettings* s, size_t n) {
 // decode 2n points (C then pi) from device bytes [commitments | proofs] into ws.d_points / d_pflag on stream s2
 static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, const void* d_proofs, size_t n) {
     Workspace& w = s->ws;
-    unsigned blocks = (unsigned)((n + 63) / 64);
-    hipLaunchKernelGGL(k_g1_decode, dim3(blocks), dim3(64), 0, s->s2, (const uint8_t*)d_commitments, w.d_points, w.d_pflag, (int)n, 1);
-    hipLaunchKernelGGL(k_g1_decode, dim3(blocks), dim3(64), 0, s->s2, (const uint8_t*)d_proofs, w.d_points + n, w.d_pflag + n, (int)n, 1);
+    unsigned blocks = (unsigned)((2 * n + 63) / 64);
+    hipLaunchKernelGGL(k_g1_decode, dim3(blocks), dim3(64), 0, s->s2, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, (int)n,
+                       w.d_points, w.d_pflag, (int)(2 * n), 1);
+    // the generator is point 2n; then 2^(64j) multiples of all 2n+1 points (still off the critical path)
+    int mt = (int)(2 * w.cap_n + 1);
+    hipLaunchKernelGGL(k_set_generator, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, (int)(2 * n));
+    hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((2 * n + 1 + 63) / 64)), dim3(64), 0, s->s2, w.d_points, w.d_pflag, w.d_mult,
+                       (int)(2 * n + 1), mt);
     HIPCHK(hipGetLastError());
     return KZG_OK;
 }
@@ -831,7 +850,7 @@ extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const 
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     HIPCHK(hipMemcpyAsync(w.d_bytes, points48, 48 * n, hipMemcpyHostToDevice, s->s1));
-    hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_bytes, w.d_points, w.d_pflag, (int)n, 1);
+    hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_bytes, w.d_bytes, (int)n, w.d_points, w.d_pflag, (int)n, 1);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> st(n);
     HIPCHK(hipMemcpyAsync(st.data(), w.d_pflag, 4 * n, hipMemcpyDeviceToHost, s->s1));
@@ -867,7 +886,7 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     if (n) {
         HIPCHK(hipMemcpyAsync(w.d_bytes, points48, 48 * n, hipMemcpyHostToDevice, s->s1));
         HIPCHK(hipMemcpyAsync(w.d_scalars, le.data(), 32 * n, hipMemcpyHostToDevice, s->s1));
-        hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_bytes, w.d_points, w.d_pflag, (int)n, 0);
+        hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_bytes, w.d_bytes, (int)n, w.d_points, w.d_pflag, (int)n, 0);
         hipLaunchKernelGGL(k_plain_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar, (int)n);
         HIPCHK(hipGetLastError());
         std::vector<uint32_t> st(n);
@@ -876,8 +895,9 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
         for (size_t i = 0; i < n; i++)
             if (st[i] == G1_INVALID) return fail(KZG_BADARGS, "invalid G1 point");
     }
+    if (n) hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_points, w.d_pflag, w.d_mult, (int)n, mt);
     MsmDesc d{};
-    d.points = w.d_points;
+    d.mult = w.d_mult;
     d.pflag = w.d_pflag;
     d.scalars = w.d_scalars;
     d.term_point = w.d_term_point;
@@ -887,8 +907,9 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     d.nterms[0] = (int)n;
     d.nterms[1] = 0;
     d.max_terms = mt;
+    d.stride = mt;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
-    hipLaunchKernelGGL(k_msm_window, dim3(MSM_WINDOWS, 1), dim3(256), 0, s->s1, d);
+    hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, 1), dim3(256), 0, s->s1, d);
     hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, w.d_window, w.d_ab);
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
     hipLaunchKernelGGL(k_jac_compress, dim3(1), dim3(64), 0, s->s1, w.d_ab, w.d_bytes, 1);
@@ -934,7 +955,7 @@ extern "C" KzgRet kzg_pairing_check(bool* ok, const uint8_t a[48], const uint8_t
     Workspace& w = s->ws;
     HIPCHK(hipMemcpyAsync(w.d_bytes, a, 48, hipMemcpyHostToDevice, s->s1));
     HIPCHK(hipMemcpyAsync(w.d_bytes + 48, b, 48, hipMemcpyHostToDevice, s->s1));
-    hipLaunchKernelGGL(k_g1_decode, dim3(1), dim3(64), 0, s->s1, w.d_bytes, w.d_points, w.d_pflag, 2, 0);
+    hipLaunchKernelGGL(k_g1_decode, dim3(1), dim3(64), 0, s->s1, w.d_bytes, w.d_bytes, 2, w.d_points, w.d_pflag, 2, 0);
     hipLaunchKernelGGL(k_aff_to_slp, dim3(1), dim3(64), 0, s->s1, w.d_points, w.d_pflag, w.d_slp_in);
     HIPCHK(hipGetLastError());
     uint32_t* h = reinterpret_cast<uint32_t*>(w.h_buf);
@@ -996,6 +1017,50 @@ extern "C" KzgRet kzg_settings_tau_g2(const KzgSettings* s, uint8_t out[96]) {
     HIPCHK(hipMemcpyAsync(out, d, 96, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
     HIPCHK(hipFree(d));
+    return KZG_OK;
+}
+
+// diagnostic: in-kernel shader clock (MHz) = delta s_memtime / delta s_memrealtime * 100 MHz
+__global__ void k_clock_probe(unsigned long long* out, int spin) {
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t x = threadIdx.x;
+    for (int i = 0; i < spin; i++) x = x * 1664525u + 1013904223u;
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = t1 - t0;
+        out[2 * blockIdx.x + 1] = r1 - r0 + (x == 12345u);
+    }
+}
+
+// diagnostic (tools/ only): run the VERIFY program on `instances` copies of zero inputs, `reps` times;
+// returns the average kernel time and the in-kernel shader clock seen by a 1-block probe launched alone.
+extern "C" KzgRet kzg_debug_slp_bench(float* ms_out, float* mhz_out, int instances, int reps, const KzgSettings* s) {
+    if (!s || !ms_out || instances < 1) return fail(KZG_BADARGS, "bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    Fp *d_in, *d_out;
+    unsigned long long* d_clk;
+    HIPCHK(hipMalloc(&d_in, sizeof(Fp) * 6 * instances));
+    HIPCHK(hipMalloc(&d_out, sizeof(Fp) * 6 * instances));
+    HIPCHK(hipMalloc(&d_clk, 16));
+    HIPCHK(hipMemset(d_in, 0, sizeof(Fp) * 6 * instances));
+    KzgRet rc = run_program(s->verify, d_in, s->d_prep, d_out, instances, s->s1);
+    if (rc != KZG_OK) return rc;
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipEventRecord(s->ev[2], s->s1));
+    for (int i = 0; i < reps; i++)
+        if ((rc = run_program(s->verify, d_in, s->d_prep, d_out, instances, s->s1)) != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[3], s->s1));
+    HIPCHK(hipEventSynchronize(s->ev[3]));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
+    *ms_out = ms / reps;
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s->s1, d_clk, 200000);
+    unsigned long long h[2];
+    HIPCHK(hipMemcpyAsync(h, d_clk, 16, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    if (mhz_out) *mhz_out = h[1] ? (float)((double)h[0] / (double)h[1] * 100.0) : 0.f;
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_clk);
     return KZG_OK;
 }
 

@@ -11,19 +11,20 @@
 //     t in [2n,3n)  : (C_t'', a_t'')            -> B
 //     t = 3n        : (G,     g = -sum r^i y_i) -> B
 //
-// Pippenger, window c = 8 bits (32 windows).  One workgroup per (window, output):
+// Pippenger, window c = 8 bits over 4 x 64-bit scalar chunks (see k_g1_multiples).
+// One workgroup per (window, chunk, output):
 //   1. counting sort of the output's terms by their 8-bit digit (LDS histogram + cursor),
 //      so that afterwards every lane walks its own bucket list and all lanes add at once;
 //   2. thread b accumulates bucket b with mixed Jacobian+affine additions;
 //   3. sum_b b*B_b by an LDS suffix scan followed by a tree sum (Jacobian points staged in LDS);
-// then k_msm_combine folds the 32 window sums (Horner, 8 doublings per window).
+// then k_msm_combine folds the chunk sums and the 8 windows (Horner, 8 doublings per window).
 #pragma once
 #include "g1.hpp"
 
 namespace kzg {
 
 constexpr int MSM_C = 8;
-constexpr int MSM_WINDOWS = 32;
+constexpr int MSM_WINDOWS = 32;  // 4 chunks x 8 windows
 constexpr int MSM_BUCKETS = 256;
 
 struct MsmTerm {
@@ -71,20 +72,39 @@ __global__ void k_finish_g(const Fr* __restrict__ partial, int nparts, Fr* __res
     *g_out = FrF::from_mont(FrF::neg(s));
 }
 
+// ---------------------------------------------------------------- precomputed multiples
+// mult[j][p] = 2^(64 j) * points[p], j = 0..3 (Jacobian).  With them a 255-bit scalar splits into four
+// 64-bit chunks, sum_i s_i P_i = sum_i sum_j s_ij (2^(64j) P_i): the MSM needs only 8 windows and the
+// serial window combine 56 doublings instead of 248.  The 192 doublings per point depend only on the
+// INPUT points, so this kernel runs beside the SHA-256 challenge chain, off the critical path.
+constexpr int MSM_CHUNKS = 4;
+__global__ __launch_bounds__(64) void k_g1_multiples(const G1Aff* __restrict__ points, const uint32_t* __restrict__ pflag,
+                                                     G1Jac* __restrict__ mult, int n, int stride) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Jac acc = pflag[i] ? g1_identity() : g1_from_affine(points[i]);
+    mult[i] = acc;
+    for (int j = 1; j < MSM_CHUNKS; j++) {
+        for (int k = 0; k < 64; k++) acc = g1_dbl(acc);
+        mult[(size_t)j * stride + i] = acc;
+    }
+}
+
 // ---------------------------------------------------------------- bucket accumulation + reduction
-// Term t of output o is (point index, scalar pointer) given by two small tables prepared on the host:
+// Term t of output o is (point index, scalar index) given by two small tables:
 //   term_point[o][t], term_scalar[o][t]  (indices into points[] / scalars[]); nterms[o].
-// pflag[p] != 0 marks the identity (skipped).
+// pflag[p] != 0 marks the identity / an invalid point (skipped).
 struct MsmDesc {
-    const G1Aff* points;
+    const G1Jac* mult;            // [4][stride] precomputed multiples
     const uint32_t* pflag;
-    const Fr* scalars;          // plain little-endian limbs
+    const Fr* scalars;            // plain little-endian limbs
     const uint32_t* term_point;   // [2][max_terms]
     const uint32_t* term_scalar;  // [2][max_terms]
     uint32_t* sorted;             // [2][32][max_terms] scratch
-    G1Jac* window_sums;           // [2][32]
+    G1Jac* window_sums;           // [2][4][8]
     int nterms[2];
     int max_terms;
+    int stride;
 };
 
 __device__ __forceinline__ void lds_store_jac(uint32_t* base, int slot, const G1Jac& p) {
@@ -108,21 +128,26 @@ __device__ __forceinline__ G1Jac lds_load_jac(const uint32_t* base, int slot) {
     return p;
 }
 
+// grid (8 windows, 4 chunks, 2 outputs), 256 threads: block (w, j, o) handles digit byte 8j + w of every
+// scalar of output o, against the multiples 2^(64j) P.
 __global__ __launch_bounds__(256) void k_msm_window(MsmDesc d) {
-    const int w = blockIdx.x, o = blockIdx.y, tid = threadIdx.x;
+    const int w = blockIdx.x, j = blockIdx.y, o = blockIdx.z, tid = threadIdx.x;
     const int nt = d.nterms[o];
+    const int wi = (o * MSM_CHUNKS + j) * 8 + w;  // window slot
     const uint32_t* tp = d.term_point + (size_t)o * d.max_terms;
     const uint32_t* tsc = d.term_scalar + (size_t)o * d.max_terms;
-    uint32_t* sorted = d.sorted + ((size_t)o * MSM_WINDOWS + w) * d.max_terms;
+    uint32_t* sorted = d.sorted + (size_t)wi * d.max_terms;
+    const G1Jac* pts_j = d.mult + (size_t)j * d.stride;
     __shared__ uint32_t cnt[MSM_BUCKETS], off[MSM_BUCKETS + 1], cur[MSM_BUCKETS];
     __shared__ uint32_t pts[MSM_BUCKETS * 36];  // 36 KiB: one Jacobian point per thread
     cnt[tid] = 0;
     cur[tid] = 0;
     __syncthreads();
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(d.scalars);
+    const int byte = 8 * j + w;
     // 1. counting sort by digit
     for (int t = tid; t < nt; t += 256) {
-        uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + w];
+        uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
         atomicAdd(&cnt[dig], 1u);
     }
     __syncthreads();
@@ -136,7 +161,7 @@ __global__ __launch_bounds__(256) void k_msm_window(MsmDesc d) {
     }
     __syncthreads();
     for (int t = tid; t < nt; t += 256) {
-        uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + w];
+        uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
         uint32_t pos = atomicAdd(&cur[dig], 1u);
         sorted[off[dig] + pos] = tp[t];
     }
@@ -145,9 +170,9 @@ __global__ __launch_bounds__(256) void k_msm_window(MsmDesc d) {
     // 2. bucket tid (digit 0 contributes nothing)
     G1Jac acc = g1_identity();
     if (tid > 0) {
-        for (uint32_t k = off[tid]; k < off[tid + 1]; k++) acc = g1_add_affine(acc, d.points[sorted[k]]);
+        for (uint32_t k = off[tid]; k < off[tid + 1]; k++) acc = g1_add(acc, pts_j[sorted[k]]);
     }
-    // 3. sum_b b*B_b = sum_b S_b,  S_b = sum_{b' >= b} B_b'   (suffix scan, then tree sum)
+    // 3. sum_b b*B_b = sum_{b>=1} S_b,  S_b = sum_{b' >= b} B_b'   (suffix scan, then tree sum)
     lds_store_jac(pts, tid, acc);
     __syncthreads();
     for (int s = 1; s < MSM_BUCKETS; s <<= 1) {
@@ -161,8 +186,7 @@ __global__ __launch_bounds__(256) void k_msm_window(MsmDesc d) {
         }
         __syncthreads();
     }
-    // acc = S_tid; S_0 includes bucket 0 (identity) so sum over tid >= 1
-    if (tid == 0) lds_store_jac(pts, 0, g1_identity());
+    if (tid == 0) lds_store_jac(pts, 0, g1_identity());  // S_0 is not part of the sum
     __syncthreads();
     for (int s = MSM_BUCKETS / 2; s > 0; s >>= 1) {
         if (tid < s) {
@@ -171,17 +195,24 @@ __global__ __launch_bounds__(256) void k_msm_window(MsmDesc d) {
         }
         __syncthreads();
     }
-    if (tid == 0) d.window_sums[o * MSM_WINDOWS + w] = lds_load_jac(pts, 0);
+    if (tid == 0) d.window_sums[wi] = lds_load_jac(pts, 0);
 }
 
-// out[o] = sum_w 2^(8w) W[o][w]   (Horner from the top window)
-__global__ void k_msm_combine(const G1Jac* __restrict__ window_sums, G1Jac* __restrict__ out) {
-    int o = blockIdx.x;
-    if (threadIdx.x) return;
-    G1Jac acc = window_sums[o * MSM_WINDOWS + MSM_WINDOWS - 1];
-    for (int w = MSM_WINDOWS - 2; w >= 0; w--) {
+// out[o] = sum_w 2^(8w) (sum_j W[o][j][w]): 8 threads fold the chunks, then one Horner chain of 56 doublings
+__global__ __launch_bounds__(64) void k_msm_combine(const G1Jac* __restrict__ window_sums, G1Jac* __restrict__ out) {
+    const int o = blockIdx.x, tid = threadIdx.x;
+    __shared__ uint32_t pts[8 * 36];
+    if (tid < 8) {
+        G1Jac s = window_sums[(o * MSM_CHUNKS + 0) * 8 + tid];
+        for (int j = 1; j < MSM_CHUNKS; j++) s = g1_add(s, window_sums[(o * MSM_CHUNKS + j) * 8 + tid]);
+        lds_store_jac(pts, tid, s);
+    }
+    __syncthreads();
+    if (tid) return;
+    G1Jac acc = lds_load_jac(pts, 7);
+    for (int w = 6; w >= 0; w--) {
         for (int k = 0; k < MSM_C; k++) acc = g1_dbl(acc);
-        acc = g1_add(acc, window_sums[o * MSM_WINDOWS + w]);
+        acc = g1_add(acc, lds_load_jac(pts, w));
     }
     out[o] = acc;
 }

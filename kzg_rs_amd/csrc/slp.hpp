@@ -40,38 +40,80 @@ __device__ __forceinline__ void slp_store(uint32_t* slots, uint32_t s, const Fp&
     p[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
 }
 
+// one step for one lane; d = this lane's descriptor.  The three step kinds are separate wave-uniform
+// branches, each with its own store, so that add/sub and multiply steps carry no vmcnt dependence.
+template <bool MULTI_WAVE>
+__device__ __forceinline__ void slp_exec(uint32_t* slots, const uint2 d, const SlpProgram& prog, const Fp* my_in,
+                                         const Fp* settings_inputs) {
+    const uint32_t op = (d.y >> 16) & 0x3fffu, dst = d.y & 0xffffu;
+    const uint32_t kind = __builtin_amdgcn_readfirstlane(d.y >> 30);  // identical in every lane
+    if (kind == 1) {
+        Fp a = slp_load(slots, d.x & 0xffffu), b = slp_load(slots, d.x >> 16);
+        Fp r = FpF::mul(a, b);
+        if (op != SLP_NOP) slp_store(slots, dst, r);
+    } else if (kind == 0) {
+        Fp a = slp_load(slots, d.x & 0xffffu), b = slp_load(slots, d.x >> 16);
+        Fp r = (op == SLP_ADD) ? FpF::add(a, b) : FpF::sub(a, b);
+        if (op != SLP_NOP) slp_store(slots, dst, r);
+    } else {
+        if (op != SLP_NOP) {
+            const Fp* src = op == SLP_LOADC ? prog.consts : op == SLP_LOADI ? my_in : settings_inputs;
+            Fp r = src[d.x];
+            slp_store(slots, dst, r);
+        }
+    }
+    // Step boundary.  With lanes == 64 the workgroup is ONE wavefront: LDS instructions of a wave execute
+    // in issue order, so the next step's ds_reads see this step's ds_writes without any barrier.
+    if (MULTI_WAVE) __syncthreads();
+    else asm volatile("" ::: "memory");
+}
+
 // inputs: [instances][n_in] Fp (Montgomery); settings_inputs: [n_set] Fp; outputs: [instances][n_out] Fp
+//
+// Descriptor streaming: a step lasts 0.15-1.5 us, shorter than a dependent global load, so descriptors are
+// fetched a GROUP (16 steps) ahead into registers while the current group executes, parked in a small
+// per-lane LDS ring at the group boundary (the only place that waits on vmcnt), and the (non-unrolled)
+// step loop reads its descriptor from LDS one step ahead.  Dynamic LDS = slots | descriptor ring.
+constexpr int SLP_GROUP = 16;
+template <bool MULTI_WAVE>
 __global__ void k_slp_run(SlpProgram prog, const Fp* __restrict__ inputs, const Fp* __restrict__ settings_inputs,
                           Fp* __restrict__ outputs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t slots[];
-    const uint32_t tid = threadIdx.x, inst = blockIdx.x, lanes = prog.lanes;
+    const uint32_t tid = threadIdx.x, inst = blockIdx.x, lanes = prog.lanes, n_steps = prog.n_steps;
+    uint2* ring = reinterpret_cast<uint2*>(slots + (size_t)12 * prog.n_slots);  // [2][SLP_GROUP][lanes]
     const Fp* my_in = inputs + (size_t)inst * prog.n_in;
-    uint2 d = prog.desc[tid];
-    for (uint32_t s = 0; s < prog.n_steps; s++) {
-        uint2 dn = make_uint2(0, 0);
-        if (s + 1 < prog.n_steps) dn = prog.desc[(size_t)(s + 1) * lanes + tid];  // prefetch
-        const uint32_t op = d.y >> 16, dst = d.y & 0xffffu;
-        const uint32_t kind = prog.kinds[s];  // wave-uniform
-        Fp r;
-        if (kind == 1) {
-            Fp a = slp_load(slots, d.x & 0xffffu), b = slp_load(slots, d.x >> 16);
-            r = FpF::mul(a, b);
-        } else {
-            if (op == SLP_ADD || op == SLP_SUB) {
-                Fp a = slp_load(slots, d.x & 0xffffu), b = slp_load(slots, d.x >> 16);
-                r = (op == SLP_ADD) ? FpF::add(a, b) : FpF::sub(a, b);
-            } else if (op == SLP_LOADC) {
-                r = prog.consts[d.x];
-            } else if (op == SLP_LOADI) {
-                r = my_in[d.x];
-            } else if (op == SLP_LOADS) {
-                r = settings_inputs[d.x];
-            }
-        }
-        if (op != SLP_NOP) slp_store(slots, dst, r);
-        __syncthreads();
-        d = dn;
+    const uint32_t last = n_steps - 1;
+    uint2 r[SLP_GROUP];
+#pragma unroll
+    for (int k = 0; k < SLP_GROUP; k++) {
+        uint32_t st = (uint32_t)k < last ? (uint32_t)k : last;
+        ring[(size_t)k * lanes + tid] = prog.desc[(size_t)st * lanes + tid];
     }
+    if (MULTI_WAVE) __syncthreads();
+    const uint32_t n_groups = (n_steps + SLP_GROUP - 1) / SLP_GROUP;
+    for (uint32_t g = 0; g < n_groups; g++) {
+        const uint32_t base = g * SLP_GROUP;
+        // issue the next group's descriptor loads (clamped: always SLP_GROUP loads, so nothing is conditional)
+#pragma unroll
+        for (int k = 0; k < SLP_GROUP; k++) {
+            uint32_t st = base + SLP_GROUP + k;
+            st = st < last ? st : last;
+            r[k] = prog.desc[(size_t)st * lanes + tid];
+        }
+        const uint2* cur = ring + (size_t)(g & 1) * SLP_GROUP * lanes + tid;
+        const uint32_t cnt = n_steps - base < (uint32_t)SLP_GROUP ? n_steps - base : (uint32_t)SLP_GROUP;
+        uint2 d = cur[0];
+#pragma unroll 1
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint2 dn = cur[(size_t)(k + 1 < (uint32_t)SLP_GROUP ? k + 1 : k) * lanes];
+            slp_exec<MULTI_WAVE>(slots, d, prog, my_in, settings_inputs);
+            d = dn;
+        }
+        uint2* nxt = ring + (size_t)((g + 1) & 1) * SLP_GROUP * lanes + tid;
+#pragma unroll
+        for (int k = 0; k < SLP_GROUP; k++) nxt[(size_t)k * lanes] = r[k];
+    }
+    if (MULTI_WAVE) __syncthreads();
     for (uint32_t o = tid; o < prog.n_out; o += lanes) outputs[(size_t)inst * prog.n_out + o] = slp_load(slots, prog.out_slots[o]);
 }
 

@@ -13,9 +13,9 @@ Binary format (little-endian u32 words):
   [4] n_const   [5] n_inputs   [6] n_settings_inputs   [7] n_outputs   [8..15] reserved
   const pool : n_const * 12 words   (Montgomery form, R = 2^384)
   out slots  : n_outputs words
-  step kinds : n_steps words        (0 = LIN, 1 = MUL)
+  step kinds : n_steps words        (0 = LIN (add/sub), 1 = MUL, 2 = LOAD)
   descriptors: n_steps * lanes * 2 words:  w0 = a | b << 16  (LOAD*: w0 = index),
-                                           w1 = dst | op << 16
+                                           w1 = dst | op << 16 | step_kind << 30
   ops: 0 NOP, 1 ADD, 2 SUB, 3 MUL, 4 LOADC (const pool), 5 LOADI (per-instance input),
        6 LOADS (per-settings input table)
 """
@@ -118,13 +118,20 @@ def schedule(g, lanes=64, n_instance_inputs=None, mul_cost=12, lin_cost=1):
     while ready_mul or ready_lin or wanted_loads:
         # all available linear work first (cheap steps)
         while ready_lin or wanted_loads:
-            batch = []
-            while len(batch) < lanes and wanted_loads:
-                batch.append(heapq.heappop(wanted_loads)[1])
-            while len(batch) < lanes and ready_lin:
-                batch.append(heapq.heappop(ready_lin)[1])
-            steps.append((0, batch))
-            complete(batch)
+            # loads get steps of their own (kind 2): only those steps wait on global memory, so the
+            # interpreter's descriptor prefetch is never drained by an add/sub step
+            while wanted_loads:
+                batch = []
+                while len(batch) < lanes and wanted_loads:
+                    batch.append(heapq.heappop(wanted_loads)[1])
+                steps.append((2, batch))
+                complete(batch)
+            if ready_lin:
+                batch = []
+                while len(batch) < lanes and ready_lin:
+                    batch.append(heapq.heappop(ready_lin)[1])
+                steps.append((0, batch))
+                complete(batch)
         if ready_mul:
             batch = []
             while len(batch) < lanes and ready_mul:
@@ -171,23 +178,24 @@ def schedule(g, lanes=64, n_instance_inputs=None, mul_cost=12, lin_cost=1):
     words += [slot[o] for o in g.outputs]
     words += [k for k, _ in steps]
     for kind, batch in steps:
+        kbit = kind << 30  # step kind (2 bits) replicated into every lane's descriptor (no separate dependent load)
         for li in range(lanes):
             if li >= len(batch):
-                words += [0, OP_NOP << 16]
+                words += [0, OP_NOP << 16 | kbit]
                 continue
             x = batch[li]
             k = g.kind[x]
             if k == CONST:
-                words += [const_index[x], slot[x] | OP_LOADC << 16]
+                words += [const_index[x], slot[x] | OP_LOADC << 16 | kbit]
             elif k == IN:
                 idx = g.a[x]
                 if idx < n_in:
-                    words += [idx, slot[x] | OP_LOADI << 16]
+                    words += [idx, slot[x] | OP_LOADI << 16 | kbit]
                 else:
-                    words += [idx - n_in, slot[x] | OP_LOADS << 16]
+                    words += [idx - n_in, slot[x] | OP_LOADS << 16 | kbit]
             else:
                 op = {MUL: OP_MUL, ADD: OP_ADD, SUB: OP_SUB}[k]
-                words += [slot[g.a[x]] | slot[g.b[x]] << 16, slot[x] | op << 16]
+                words += [slot[g.a[x]] | slot[g.b[x]] << 16, slot[x] | op << 16 | kbit]
     blob = struct.pack("<%dI" % len(words), *words)
     stats = {
         "lanes": lanes,
@@ -195,6 +203,7 @@ def schedule(g, lanes=64, n_instance_inputs=None, mul_cost=12, lin_cost=1):
         "steps": len(steps),
         "mul_steps": sum(1 for k, _ in steps if k == 1),
         "lin_steps": sum(1 for k, _ in steps if k == 0),
+        "load_steps": sum(1 for k, _ in steps if k == 2),
         "mul_ops": sum(len(b) for k, b in steps if k == 1),
         "lin_ops": sum(len(b) for k, b in steps if k == 0),
         "consts": len(const_nodes),
@@ -237,9 +246,12 @@ def run_reference(blob, inputs, settings_inputs=()):
         reads = set()
         for li in range(lanes):
             w0, w1 = desc[2 * (s * lanes + li)], desc[2 * (s * lanes + li) + 1]
-            op, dst = w1 >> 16, w1 & 0xFFFF
+            op, dst = (w1 >> 16) & 0x3FFF, w1 & 0xFFFF
+            assert (w1 >> 30) == pr["kinds"][s]
             if op == OP_NOP:
                 continue
+            if op in (OP_LOADC, OP_LOADI, OP_LOADS):
+                assert pr["kinds"][s] == 2, "load outside a load step"
             if op == OP_LOADC:
                 r = consts[w0]
             elif op == OP_LOADI:
@@ -252,6 +264,7 @@ def run_reference(blob, inputs, settings_inputs=()):
                 reads.add(w0 >> 16)
                 assert a is not None and b is not None, "read of an unwritten slot"
                 assert (op == OP_MUL) == (pr["kinds"][s] == 1), "op kind does not match step kind"
+                assert pr["kinds"][s] != 2, "arithmetic op in a load step"
                 r = (a * b if op == OP_MUL else a + b if op == OP_ADD else a - b) % P
             writes.append((dst, r))
         dsts = [d for d, _ in writes]
