@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
 """Benchmark of the north-star path: verify_blob_kzg_proof_batch on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--blobs 1024]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--blobs 1024] [--group G] [--inflight F]
 
-One "step" = one verify_blob_kzg_proof_batch call over a batch of synthetic blobs already resident
-in HBM (BASELINE.json configs[1]: 1 024 blobs of 4096 Fr per GPU).  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) the batch is N * blobs, sharded by blob, with the two tiny
-all-gathers of kzg_rs_amd/distributed.py; per-GPU work is fixed, so scaling is "weak".
+One "step" = one verify_blob_kzg_proof_batch over a batch of `--blobs` synthetic blobs per GPU that are already
+resident in HBM (BASELINE.json configs[1]: 1 024 blobs of 4096 Fr per GPU).  Every step is a complete, independent
+verification (its own transcript, challenge r, MSMs and pairing; its own boolean).  At this batch size each phase
+is a latency-bound serial chain that occupies a sliver of the chip, so steps are issued in LAUNCH GROUPS of G
+independent batches (a batch dimension inside every kernel) and F groups are kept in flight by a fixed-order
+software pipeline on one host thread.  `--group 1 --inflight 1` gives strictly sequential single-batch steps; that
+latency is also measured and reported as `single_batch` in the same JSON line.
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every batch is N * blobs, sharded by blob, with the
+two small all-gathers of kzg_rs_amd/distributed.py (RCCL); per-GPU work is fixed, so scaling is "weak".
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -17,14 +23,16 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# ROCm gives a process 4 hardware queues by default; the pipeline uses 2 streams per in-flight group
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 BYTES_PER_BLOB = 131072
 # algorithmic bytes per unit, per kernel (DESIGN.md 5 / SURVEY.md 8d)
 ALG_BYTES = {
     "k_blob_challenge": BYTES_PER_BLOB + 48 + 32,   # blob + commitment read, z written       (per blob)
     "k_blob_evaluate": BYTES_PER_BLOB + 32 + 32,    # blob + z read, y written                (per blob)
-    "k_g1_decode": 2 * (48 + 96 + 4),               # two points per blob: bytes in, affine + flag out
-    "k_msm": 3 * 128 ,                              # three (point, scalar) terms per blob, 96 + 32 B each
+    "k_g1_decode+multiples": 2 * (48 + 96 + 4 + 4 * 144),  # two points per blob: bytes in, affine + flag + 4 multiples out
+    "k_msm": 3 * 128,                               # three (point, scalar) terms per blob, 96 + 32 B each
     "k_slp_run(pairing)": 0,
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
@@ -58,9 +66,11 @@ def cpu_baseline(blobs, cs, ps, tau_g2, max_blobs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--blobs", type=int, default=1024, help="blobs per GPU per step")
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--blobs", type=int, default=1024, help="blobs per GPU per step (batch)")
+    ap.add_argument("--group", type=int, default=32, help="independent batches per launch group (batch dimension inside the kernels)")
+    ap.add_argument("--inflight", type=int, default=2, help="launch groups kept in flight by the fixed-order software pipeline")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -82,58 +92,103 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from kzg_rs_amd import api, synth
-    from kzg_rs_amd.distributed import HipBackend, verify_blob_kzg_proof_batch_sharded
+    from kzg_rs_amd.distributed import HipBackend, PipelinedVerifier, verify_blob_kzg_proof_batch_sharded
 
-    n = args.blobs
+    n, G, F = args.blobs, max(1, args.group), max(1, args.inflight)
     blobs, cs, ps, settings = synth.make_valid_batch(n, seed=1000 + rank)
     d_blobs = torch.from_numpy(blobs).to(dev)
     d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).to(dev)
     d_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
-    backend = HipBackend(settings)
-    shard = (d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+    backend0 = HipBackend(settings)
 
-    def step():
-        if world == 1:
-            ok = api.KzgProof.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, settings)
-        else:
-            ok = verify_blob_kzg_proof_batch_sharded(shard, n, backend, dist, dev)
-        if not ok:
+    # ---- pipeline: depth (d1, d2, d3) groups between the phases; one handle (2 HIP streams + workspace) per group in flight
+    if F <= 1:
+        depth = (0, 0, 0)
+    elif world > 1:
+        depth = (max(1, F - 2), 1, 1)
+    else:
+        depth = (F - 1, 0, 1)
+    n_handles = sum(depth) + 1
+    handles = [settings] + [api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1]) for _ in range(n_handles - 1)]
+    backends = [backend0] + [HipBackend(h) for h in handles[1:]]
+    pipe = PipelinedVerifier(backends, dist, dev, depth)
+    # every batch is a different permutation of the rank's shard (different transcript and r), at its own HBM address
+    gen = torch.Generator(device="cpu").manual_seed(7 + rank)
+    c_t, p_t = d_c.view(n, 48), d_p.view(n, 48)
+    variants = []
+    for v in range(n_handles):
+        perms = [torch.randperm(n, generator=gen).to(dev) if (v or g) else torch.arange(n, device=dev) for g in range(G)]
+        variants.append((torch.cat([d_blobs[p] for p in perms]).contiguous(), torch.cat([c_t[p] for p in perms]).contiguous(),
+                         torch.cat([p_t[p] for p in perms]).contiguous()))
+    torch.cuda.synchronize()
+
+    def run_batches(k):
+        """k independent batches = ceil(k / G) launch groups (the last one possibly smaller)."""
+        groups, left, i = [], k, 0
+        while left > 0:
+            g = min(G, left)
+            v = variants[i % n_handles]
+            groups.append(((v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), n), g))
+            left -= g
+            i += 1
+        res = pipe.run(groups)
+        if not all(all(r) for r in res):
             raise SystemExit("verification of a valid synthetic batch returned false")
+        return groups
 
-    for _ in range(args.warmup):
-        step()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kt = [0.0] * 8
-    for _ in range(args.steps):
-        step()
-        tm = settings.last_timings()
-        kt = [a + b for a, b in zip(kt, tm)]
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fn):
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    if args.warmup:
+        run_batches(args.warmup * G)
+    K = args.steps
+    elapsed, groups = timed(lambda: run_batches(K))
+    # kernel times (HIP events on the library's own streams) of the last group that ran on handle 0
+    idx0 = max(i for i in range(len(groups)) if i % n_handles == 0)
+    g0 = groups[idx0][1]
+    tm = settings.last_timings()
+    kernels = {"k_blob_challenge": tm[5], "k_blob_evaluate": tm[4], "k_g1_decode+multiples": tm[6], "k_msm": tm[2],
+               "k_slp_run(pairing)": tm[3]}
+
+    # ---- strictly sequential single-batch steps (latency), same inputs
+    def seq_steps(k):
+        for _ in range(k):
+            if world == 1:
+                ok = api.KzgProof.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, settings)
+            else:
+                ok = verify_blob_kzg_proof_batch_sharded((d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n), n, backend0, dist, dev)
+            if not ok:
+                raise SystemExit("verification of a valid synthetic batch returned false")
+
+    seq_steps(2)
+    KS = 8
+    seq_elapsed, _ = timed(lambda: seq_steps(KS))
+    seq_tm = settings.last_timings()
     if rank != 0:
         if dist:
             dist.destroy_process_group()
         return
-    K = args.steps
-    kt = [x / K for x in kt]  # average ms per launch over the timed region (HIP events on the library's streams)
-    kernels = {"k_blob_challenge": kt[5], "k_blob_evaluate": kt[4], "k_g1_decode": kt[6], "k_msm": kt[2], "k_slp_run(pairing)": kt[3]}
     dom = max(kernels, key=kernels.get)
-    achieved = ALG_BYTES[dom] * n / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
-    total_blobs = n * world * K
+    units = n * g0
+    achieved = ALG_BYTES[dom] * units / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
     out = {
         "metric": "blobs/sec verify_blob_kzg_proof_batch",
-        "value": round(total_blobs / elapsed, 2),
+        "value": round(n * world * K / elapsed, 2),
         "unit": "blobs/s",
         "n_gpus": world,
         "steps": K,
@@ -144,14 +199,19 @@ def main():
         "vs_baseline": None,
         "dtype": "u32 limbs (255-bit Fr / 381-bit Fp modular integers)",
         "data": "synthetic",
-        "config": {"workload": "verify_blob_kzg_proof_batch, %d synthetic blobs (4096 Fr each) per GPU, device-resident, "
-                               "known-tau test setup (BASELINE.json configs[1])" % n,
-                   "blobs_per_gpu": n, "batch": n * world, "parallelism": "shard-by-blob x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                     "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 5)"},
-        "kernel_ms": {k: round(v, 4) for k, v in kernels.items()},
-        "device_ms_per_step": round(kt[0], 4),
+        "config": {"workload": "verify_blob_kzg_proof_batch, %d synthetic blobs (4096 Fr each) per GPU per step, device-resident, "
+                               "known-tau test setup (BASELINE.json configs[1]); every step is an independent batch verification"
+                               % n,
+                   "blobs_per_gpu": n, "batch": n * world, "parallelism": "shard-by-blob x%d" % world,
+                   "batches_per_launch_group": G, "groups_in_flight": F},
+        "roofline": {"bound": "hbm", "kernel": dom, "units_per_launch": units, "launch_ms": round(kernels[dom], 4),
+                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                     "traffic": None, "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 5)"},
+        "kernel_ms_per_launch_group": {k: round(v, 4) for k, v in kernels.items()},
+        "single_batch": {"value": round(n * world * KS / seq_elapsed, 2), "unit": "blobs/s", "ms_per_step": round(seq_elapsed / KS * 1e3, 4),
+                         "steps": KS, "kernel_ms": {"k_blob_challenge": round(seq_tm[5], 4), "k_blob_evaluate": round(seq_tm[4], 4),
+                                                     "k_g1_decode+multiples": round(seq_tm[6], 4), "k_msm": round(seq_tm[2], 4),
+                                                     "k_slp_run(pairing)": round(seq_tm[3], 4)}},
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blobs, cs, ps, synth.synthetic_setup()[1], args.cpu_sample)

@@ -102,6 +102,30 @@ KzgRet kzg_shard_phase1(uint8_t *records_out, const void *d_blobs, const void *d
 KzgRet kzg_shard_phase2(uint8_t partial_out[288], const uint8_t *all_records, size_t n_total, size_t offset,
                         size_t n_local, const KzgSettings *s);
 KzgRet kzg_shard_finish(bool *ok, const uint8_t *partials, size_t world, const KzgSettings *s);
+/* The same three phases split into launch (enqueue on the handle's HIP streams, returns at once) and wait
+ * (block on that handle only), and generalised to a launch GROUP of n_batches independent batches of n_local
+ * blobs each (contiguous device arrays of n_batches * n_local entries; batch b = entries [b n, (b+1) n); every
+ * batch has its own transcript, challenge r, MSM and pairing instance).  At n = 1024 every phase of a batch is
+ * a latency-bound serial chain that occupies a sliver of the chip, so the batch dimension inside the kernels is
+ * what fills the machine; several handles additionally let ONE host thread pipeline groups in a fixed,
+ * collective-safe order (kzg_rs_amd/distributed.py).  A handle runs one group at a time: phase1 -> phase2 -> finish.
+ *   records_out : [n_batches][n_local] x 160 B;  bad_out (optional): n_batches flags, 1 = batch holds an invalid
+ *                 input (without bad_out such a group returns KZG_BADARGS)
+ *   all_records : [n_batches][n_total] x 160 B, each batch's records of ALL ranks in global blob order
+ *   partial_out : [n_batches] x 288 B;  partials: [world][n_batches] x 288 B (NULL: single rank, no fold) */
+KzgRet kzg_shard_phase1_launch(const void *d_blobs, const void *d_commitments, const void *d_proofs, size_t n_local,
+                               size_t n_batches, const KzgSettings *s);
+KzgRet kzg_shard_phase1_wait(uint8_t *records_out, uint8_t *bad_out, const KzgSettings *s);
+KzgRet kzg_shard_phase2_launch(const uint8_t *all_records, size_t n_total, size_t offset, const KzgSettings *s);
+KzgRet kzg_shard_phase2_wait(uint8_t *partial_out, const KzgSettings *s);
+KzgRet kzg_shard_finish_launch(const uint8_t *partials, size_t world, size_t n_batches, const KzgSettings *s);
+KzgRet kzg_shard_finish_wait(bool *ok /* n_batches */, const KzgSettings *s);
+/* n_batches independent verify_blob_kzg_proof_batch calls (src/kzg_proof.rs:472-525) of n blobs each in one
+ * launch group, device-resident inputs.  ok_out[b] is the result of batch b; err_out[b] (optional) = 1 where the
+ * reference would return Err (then ok_out[b] = false); without err_out any invalid input fails the whole call. */
+KzgRet kzg_verify_blob_kzg_proof_batches_device(bool *ok_out, uint8_t *err_out, const void *d_blobs,
+                                                const void *d_commitments, const void *d_proofs, size_t n,
+                                                size_t n_batches, const KzgSettings *s);
 
 /* ---- pieces of the path, exposed for parity tests and the per-kernel benchmarks ---- */
 /* compute_challenge (src/kzg_proof.rs:46-72) for n blobs: z_out = n * 32 bytes, big-endian canonical.

@@ -77,6 +77,7 @@ def lib():
         L.kzg_verify_blob_kzg_proof.argtypes = [bp, u8, u8, u8, vp]
         L.kzg_verify_blob_kzg_proof_batch.argtypes = [bp, u8, u8, u8, sz, vp]
         L.kzg_verify_blob_kzg_proof_batch_device.argtypes = [bp, vp, vp, vp, sz, vp]
+        L.kzg_verify_blob_kzg_proof_batches_device.argtypes = [bp, u8, vp, vp, vp, sz, sz, vp]
         L.kzg_compute_challenges.argtypes = [u8, u8, u8, sz, vp]
         L.kzg_evaluate_polynomials.argtypes = [u8, u8, u8, sz, vp]
         L.kzg_evaluate_polynomials_device.argtypes = [vp, vp, vp, sz, vp]
@@ -239,6 +240,16 @@ class KzgProof:
         _chk(lib().kzg_verify_blob_kzg_proof_batch_device(C.byref(ok), d_blobs, d_commitments, d_proofs, n,
                                                           kzg_settings._h))
         return bool(ok.value)
+
+
+def verify_blob_kzg_proof_batches_device(d_blobs, d_commitments, d_proofs, n, n_batches, kzg_settings):
+    """n_batches independent verify_blob_kzg_proof_batch calls of n blobs each in one launch group (device pointers).
+    Returns a list with True / False per batch, or None where the reference would return Err."""
+    ok = (C.c_bool * n_batches)()
+    err = C.create_string_buffer(n_batches)
+    _chk(lib().kzg_verify_blob_kzg_proof_batches_device(ok, err, d_blobs, d_commitments, d_proofs, n, n_batches,
+                                                        kzg_settings._h))
+    return [None if err.raw[b] else bool(ok[b]) for b in range(n_batches)]
 
 
 # ---- pieces of the path (parity tests / per-kernel benchmarks) ----

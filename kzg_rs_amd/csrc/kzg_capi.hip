@@ -77,23 +77,27 @@ __global__ void k_g2_compress(const Fp* __restrict__ in4, uint8_t* __restrict__ 
     if (largest) out96[0] |= 0x20;
 }
 
-// term tables of the batch equation (msm.hpp) + the generator as point 2n
-__global__ void k_batch_terms(uint32_t* __restrict__ term_point, uint32_t* __restrict__ term_scalar, G1Aff* __restrict__ points,
-                              uint32_t* __restrict__ pflag, int n, int max_terms) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+// term tables of the batch equation (msm.hpp) for a launch group of B batches of n blobs (T = B n):
+// points: C of all batches [0, T), pi of all batches [T, 2T), generator at 2T; scalars of batch b at b(2n+1).
+// blockIdx.y = batch.  Tables are [2B][max_terms], row 2b = output A, row 2b+1 = output B.
+__global__ void k_batch_terms(uint32_t* __restrict__ term_point, uint32_t* __restrict__ term_scalar, int n, int T, int max_terms) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, bt = blockIdx.y;
+    uint32_t* tpA = term_point + (size_t)(2 * bt) * max_terms;
+    uint32_t* tsA = term_scalar + (size_t)(2 * bt) * max_terms;
+    uint32_t* tpB = tpA + max_terms;
+    uint32_t* tsB = tsA + max_terms;
+    const uint32_t sb = (uint32_t)bt * (2 * n + 1);
     if (t < n) {
-        // output 0 (A): (pi_t, a_t)
-        term_point[t] = n + t;
-        term_scalar[t] = t;
-        // output 1 (B): (pi_t, b_t) and (C_t, a_t)
-        term_point[max_terms + t] = n + t;
-        term_scalar[max_terms + t] = n + t;
-        term_point[max_terms + n + t] = t;
-        term_scalar[max_terms + n + t] = t;
+        tpA[t] = T + bt * n + t;  // (pi_t, a_t) -> A
+        tsA[t] = sb + t;
+        tpB[t] = T + bt * n + t;  // (pi_t, b_t) -> B
+        tsB[t] = sb + n + t;
+        tpB[n + t] = bt * n + t;  // (C_t, a_t) -> B
+        tsB[n + t] = sb + t;
     }
     if (t == 0) {
-        term_point[max_terms + 2 * n] = 2 * n;
-        term_scalar[max_terms + 2 * n] = 2 * n;
+        tpB[2 * n] = 2 * T;       // (G, g) -> B
+        tsB[2 * n] = sb + 2 * n;
     }
 }
 
@@ -116,20 +120,23 @@ __global__ void k_plain_terms(uint32_t* __restrict__ term_point, uint32_t* __res
     }
 }
 
-// n==1 / verify_kzg_proof scalars: a_0 = 1, b_0 = z, g = -y   (r^0 = 1, so no transcript hash is needed)
+// n==1 / verify_kzg_proof scalars: a_0 = 1, b_0 = z, g = -y   (r^0 = 1, so no transcript hash is needed); block = batch
 __global__ void k_single_scalars(const Fr* __restrict__ z, const Fr* __restrict__ y, Fr* __restrict__ scalars) {
-    if (threadIdx.x || blockIdx.x) return;
+    if (threadIdx.x) return;
+    const int bt = blockIdx.x;
     Fr one = FrF::zero();
     one.l[0] = 1;
-    scalars[0] = one;
-    scalars[1] = *z;
-    scalars[2] = FrF::from_mont(FrF::neg(FrF::to_mont(*y)));
+    scalars[3 * bt] = one;
+    scalars[3 * bt + 1] = z[bt];
+    scalars[3 * bt + 2] = FrF::from_mont(FrF::neg(FrF::to_mont(y[bt])));
 }
 
 // MSM results (Jacobian) -> SLP inputs; the identity is canonicalised to (0, 1, 0)
 __global__ void k_jac_to_slp(const G1Jac* __restrict__ ab, Fp* __restrict__ slp_in) {
     int o = threadIdx.x;
-    if (o >= 2 || blockIdx.x) return;
+    if (o >= 2) return;
+    ab += 2 * blockIdx.x;       // block = batch
+    slp_in += 6 * blockIdx.x;
     G1Jac p = ab[o];
     if (g1_is_identity(p)) p = g1_identity();
     slp_in[3 * o] = p.x;
@@ -138,12 +145,14 @@ __global__ void k_jac_to_slp(const G1Jac* __restrict__ ab, Fp* __restrict__ slp_
 }
 
 // sum `world` partial (A_k, B_k) pairs (multi-GPU fold; src/kzg_proof.rs:433 generalised)
-__global__ void k_fold_partials(const G1Jac* __restrict__ partials, int world, G1Jac* __restrict__ ab) {
+// partials: [world][B][2]; block = batch
+__global__ void k_fold_partials(const G1Jac* __restrict__ partials, int world, int B, G1Jac* __restrict__ ab) {
     int o = threadIdx.x;
-    if (o >= 2 || blockIdx.x) return;
-    G1Jac acc = partials[o];
-    for (int k = 1; k < world; k++) acc = g1_add(acc, partials[2 * k + o]);
-    ab[o] = acc;
+    if (o >= 2) return;
+    const int bt = blockIdx.x;
+    G1Jac acc = partials[2 * bt + o];
+    for (int k = 1; k < world; k++) acc = g1_add(acc, partials[(size_t)2 * (k * B + bt) + o]);
+    ab[2 * bt + o] = acc;
 }
 
 // Jacobian -> 48-byte compressed
@@ -209,9 +218,17 @@ extern "C" const char* kzg_last_error(void) { return g_err.c_str(); }
         }                                                                                                  \
     } while (0)
 
+// event timing that never leaves a sticky HIP error behind (an event may not have been recorded on this path)
+static void elapsed(float* out, hipEvent_t a, hipEvent_t b) {
+    if (hipEventElapsedTime(out, a, b) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = 0.f;
+    }
+}
+
 // SHA-256 (FIPS 180-4) for the batch transcript - host code, independent of the device kernel
 namespace hostsha {
-static const uint32_t K[64] = {
+alignas(16) static const uint32_t K[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
     0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
     0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
@@ -235,10 +252,60 @@ static void block(uint32_t st[8], const uint8_t* p) {
     }
     st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
 }
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+}  // namespace hostsha
+#include <immintrin.h>
+namespace hostsha {
+// x86 SHA extensions (runtime-detected): the batch transcript is one serial chain, so per-block latency is
+// what matters; sha256rnds2 does it at ~1.5 GB/s per core.
+__attribute__((target("sha,sse4.1,ssse3"))) static void blocks_ni(uint32_t st[8], const uint8_t* data, size_t nblocks) {
+    const __m128i MASK = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+    __m128i TMP = _mm_loadu_si128((const __m128i*)&st[0]);
+    __m128i STATE1 = _mm_loadu_si128((const __m128i*)&st[4]);
+    TMP = _mm_shuffle_epi32(TMP, 0xB1);
+    STATE1 = _mm_shuffle_epi32(STATE1, 0x1B);
+    __m128i STATE0 = _mm_alignr_epi8(TMP, STATE1, 8);
+    STATE1 = _mm_blend_epi16(STATE1, TMP, 0xF0);
+    while (nblocks--) {
+        const __m128i ABEF = STATE0, CDGH = STATE1;
+        __m128i M[4];
+        for (int g = 0; g < 16; g++) {
+            if (g < 4) M[g] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(data + 16 * g)), MASK);
+            __m128i msg = _mm_add_epi32(M[g & 3], _mm_loadu_si128((const __m128i*)&K[4 * g]));
+            STATE1 = _mm_sha256rnds2_epu32(STATE1, STATE0, msg);
+            if (g >= 3 && g < 15) {
+                __m128i t = _mm_alignr_epi8(M[g & 3], M[(g - 1) & 3], 4);
+                M[(g + 1) & 3] = _mm_sha256msg2_epu32(_mm_add_epi32(M[(g + 1) & 3], t), M[g & 3]);
+            }
+            msg = _mm_shuffle_epi32(msg, 0x0E);
+            STATE0 = _mm_sha256rnds2_epu32(STATE0, STATE1, msg);
+            if (g >= 1 && g < 13) M[(g - 1) & 3] = _mm_sha256msg1_epu32(M[(g - 1) & 3], M[g & 3]);
+        }
+        STATE0 = _mm_add_epi32(STATE0, ABEF);
+        STATE1 = _mm_add_epi32(STATE1, CDGH);
+        data += 64;
+    }
+    TMP = _mm_shuffle_epi32(STATE0, 0x1B);
+    STATE1 = _mm_shuffle_epi32(STATE1, 0xB1);
+    STATE0 = _mm_blend_epi16(TMP, STATE1, 0xF0);
+    STATE1 = _mm_alignr_epi8(STATE1, TMP, 8);
+    _mm_storeu_si128((__m128i*)&st[0], STATE0);
+    _mm_storeu_si128((__m128i*)&st[4], STATE1);
+}
+static bool have_ni() {
+    static const bool v = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
+    return v;
+}
+#else
+static bool have_ni() { return false; }
+static void blocks_ni(uint32_t*, const uint8_t*, size_t) {}
+#endif
 static void digest(uint8_t out[32], const uint8_t* data, size_t len) {
     uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
     size_t full = len / 64;
-    for (size_t i = 0; i < full; i++) block(st, data + 64 * i);
+    if (have_ni()) blocks_ni(st, data, full);
+    else
+        for (size_t i = 0; i < full; i++) block(st, data + 64 * i);
     uint8_t tail[128] = {0};
     size_t rem = len - 64 * full;
     memcpy(tail, data + 64 * full, rem);
@@ -277,13 +344,17 @@ struct DevProgram {
     void* blob = nullptr;  // device copy of the whole program
 };
 
+constexpr size_t MAX_WORLD = 64;
 struct Workspace {
     size_t cap_n = 0;       // batch capacity
+    size_t cap_b = 0;       // batches-per-group capacity
+    size_t pending_n = 0, pending_b = 0, finish_b = 0;  // group currently in flight on this handle
+    size_t off_r = 0, off_part = 0, off_out = 0, off_parts = 0;  // pinned-buffer layout
     size_t cap_stage = 0;   // staged host-input capacity (blobs)
     Fr *d_z = nullptr, *d_y = nullptr, *d_scalars = nullptr, *d_partial = nullptr, *d_r = nullptr;
     uint32_t *d_status = nullptr, *d_pflag = nullptr, *d_term_point = nullptr, *d_term_scalar = nullptr, *d_sorted = nullptr;
     G1Aff* d_points = nullptr;
-    G1Jac *d_window = nullptr, *d_ab = nullptr, *d_mult = nullptr;
+    G1Jac *d_window = nullptr, *d_ab = nullptr, *d_mult = nullptr, *d_parts = nullptr;
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
     uint8_t *d_stage_blobs = nullptr, *d_stage_cp = nullptr, *d_bytes = nullptr;
     // pinned host mirrors
@@ -434,7 +505,7 @@ extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_
 
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
-                    w.d_sorted, w.d_points, w.d_window, w.d_ab, w.d_mult, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes};
+                    w.d_sorted, w.d_points, w.d_window, w.d_ab, w.d_mult, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w.h_buf) (void)hipHostFree(w.h_buf);
@@ -454,44 +525,55 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     delete s;
 }
 
-static KzgRet ws_reserve(const KzgSettings* s, size_t n, bool stage) {
+// Workspace for a launch group of B batches with T blobs in total (B = 1 for the single-call entry points).
+static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
     Workspace& w = s->ws;
-    if (n > w.cap_n) {
+    if (T > w.cap_n || B > w.cap_b) {
         size_t keep_stage = w.cap_stage;
         uint8_t *sb = w.d_stage_blobs, *sc = w.d_stage_cp;
         w.d_stage_blobs = nullptr;
         w.d_stage_cp = nullptr;
+        size_t capT = T > w.cap_n ? T : w.cap_n, capB = B > w.cap_b ? B : w.cap_b;
         ws_free(w);
         w.d_stage_blobs = sb;
         w.d_stage_cp = sc;
         w.cap_stage = keep_stage;
-        size_t cap = n < 16 ? 16 : n, mt = 2 * cap + 1;
-        HIPCHK(hipMalloc(&w.d_z, sizeof(Fr) * cap));
-        HIPCHK(hipMalloc(&w.d_y, sizeof(Fr) * cap));
-        HIPCHK(hipMalloc(&w.d_scalars, sizeof(Fr) * mt));
-        HIPCHK(hipMalloc(&w.d_partial, sizeof(Fr) * ((cap + 255) / 256)));
-        HIPCHK(hipMalloc(&w.d_r, sizeof(Fr)));
-        HIPCHK(hipMalloc(&w.d_status, 4 * cap));
-        HIPCHK(hipMalloc(&w.d_pflag, 4 * mt));
-        HIPCHK(hipMalloc(&w.d_term_point, 4 * 2 * mt));
-        HIPCHK(hipMalloc(&w.d_term_scalar, 4 * 2 * mt));
-        HIPCHK(hipMalloc(&w.d_sorted, 4 * 2 * MSM_WINDOWS * mt));
-        HIPCHK(hipMalloc(&w.d_points, sizeof(G1Aff) * mt));
-        HIPCHK(hipMalloc(&w.d_window, sizeof(G1Jac) * 2 * MSM_WINDOWS));
-        HIPCHK(hipMalloc(&w.d_mult, sizeof(G1Jac) * MSM_CHUNKS * mt));
-        HIPCHK(hipMalloc(&w.d_ab, sizeof(G1Jac) * 2));
-        HIPCHK(hipMalloc(&w.d_slp_in, sizeof(Fp) * 6));
-        HIPCHK(hipMalloc(&w.d_slp_out, sizeof(Fp) * 16));
-        HIPCHK(hipMalloc(&w.d_bytes, 96 * mt));
-        w.h_cap = 256 * cap + 4096;
+        if (capT < 16) capT = 16;
+        const size_t np = 2 * capT + 1;            // points: C's, pi's, generator
+        const size_t nsc = 2 * capT + capB;        // scalars: (2n+1) per batch
+        const size_t nterm = 4 * capT + 2 * capB;  // term table rows: [2B][2n+1]
+        HIPCHK(hipMalloc(&w.d_z, sizeof(Fr) * capT));
+        HIPCHK(hipMalloc(&w.d_y, sizeof(Fr) * capT));
+        HIPCHK(hipMalloc(&w.d_scalars, sizeof(Fr) * nsc));
+        HIPCHK(hipMalloc(&w.d_partial, sizeof(Fr) * ((capT + 255) / 256 + capB)));
+        HIPCHK(hipMalloc(&w.d_r, sizeof(Fr) * capB));
+        HIPCHK(hipMalloc(&w.d_status, 4 * capT));
+        HIPCHK(hipMalloc(&w.d_pflag, 4 * np));
+        HIPCHK(hipMalloc(&w.d_term_point, 4 * nterm));
+        HIPCHK(hipMalloc(&w.d_term_scalar, 4 * nterm));
+        HIPCHK(hipMalloc(&w.d_sorted, 4 * MSM_WINDOWS * nterm));
+        HIPCHK(hipMalloc(&w.d_points, sizeof(G1Aff) * np));
+        HIPCHK(hipMalloc(&w.d_window, sizeof(G1Jac) * 2 * MSM_WINDOWS * capB));
+        HIPCHK(hipMalloc(&w.d_mult, sizeof(G1Jac) * MSM_CHUNKS * np));
+        HIPCHK(hipMalloc(&w.d_ab, sizeof(G1Jac) * 2 * capB));
+        HIPCHK(hipMalloc(&w.d_parts, sizeof(G1Jac) * 2 * capB * MAX_WORLD));
+        HIPCHK(hipMalloc(&w.d_slp_in, sizeof(Fp) * 6 * capB));
+        HIPCHK(hipMalloc(&w.d_slp_out, sizeof(Fp) * 6 * capB));
+        HIPCHK(hipMalloc(&w.d_bytes, 96 * np));
+        w.off_r = 256 * capT + 4096;                 // pinned layout: [per-blob area | r | own partials | out | gathered partials]
+        w.off_part = w.off_r + 32 * capB;
+        w.off_out = w.off_part + 288 * capB;
+        w.off_parts = w.off_out + 288 * capB;
+        w.h_cap = w.off_parts + 288 * capB * MAX_WORLD;
         HIPCHK(hipHostMalloc(&w.h_buf, w.h_cap));
-        w.cap_n = cap;
+        w.cap_n = capT;
+        w.cap_b = capB;
     }
-    if (stage && n > w.cap_stage) {
+    if (stage && T > w.cap_stage) {
         if (w.d_stage_blobs) (void)hipFree(w.d_stage_blobs);
         if (w.d_stage_cp) (void)hipFree(w.d_stage_cp);
         w.d_stage_blobs = w.d_stage_cp = nullptr;
-        size_t cap = n < 4 ? 4 : n;
+        size_t cap = T < 4 ? 4 : T;
         HIPCHK(hipMalloc(&w.d_stage_blobs, (size_t)BLOB_BYTES * cap));
         HIPCHK(hipMalloc(&w.d_stage_cp, 96 * cap));
         w.cap_stage = cap;
@@ -500,13 +582,13 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t n, bool stage) {
 }
 
 // ---------------------------------------------------------------- the tail: MSM + pairing
-// scalars[0..n) = a, [n..2n) = b, [2n] = g already on the device; points [0..n) = C, [n..2n) = pi decoded.
-// Leaves the two partial sums (A_k, B_k) in ws.d_ab.
-static KzgRet run_msm(const KzgSettings* s, size_t n) {
+// Group of B batches of n blobs (T = B n).  scalars of batch b at b(2n+1): a [0,n), b [n,2n), g at 2n;
+// points: C [0,T), pi [T,2T), G at 2T, multiples with stride 2T+1.  Leaves (A, B) of batch b in ws.d_ab[2b..].
+static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     Workspace& w = s->ws;
-    int mt = (int)(2 * w.cap_n + 1);
-    hipLaunchKernelGGL(k_batch_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar,
-                       w.d_points, w.d_pflag, (int)n, mt);
+    const int T = (int)(n * B), mt = (int)(2 * n + 1);
+    hipLaunchKernelGGL(k_batch_terms, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, s->s1, w.d_term_point,
+                       w.d_term_scalar, (int)n, T, mt);
     MsmDesc d{};
     d.mult = w.d_mult;
     d.pflag = w.d_pflag;
@@ -518,100 +600,99 @@ static KzgRet run_msm(const KzgSettings* s, size_t n) {
     d.nterms[0] = (int)n;
     d.nterms[1] = (int)(2 * n + 1);
     d.max_terms = mt;
-    d.stride = mt;
+    d.stride = 2 * T + 1;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
-    hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, 2), dim3(256), 0, s->s1, d);
-    hipLaunchKernelGGL(k_msm_combine, dim3(2), dim3(64), 0, s->s1, w.d_window, w.d_ab);
+    hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, (unsigned)(2 * B)), dim3(256), 0, s->s1, d);
+    hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(2 * B)), dim3(64), 0, s->s1, w.d_window, w.d_ab);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
     return KZG_OK;
 }
 
-// pairing check on the (A, B) in ws.d_ab
-static KzgRet run_pairing(bool* ok, const KzgSettings* s) {
+// decode 2T points (all C then all pi) into ws.d_points / d_pflag, generator as point 2T, then the 2^(64j)
+// multiples of all 2T+1 points - all on stream s2, beside the SHA-256 chain
+static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, const void* d_proofs, size_t T) {
     Workspace& w = s->ws;
-    hipLaunchKernelGGL(k_jac_to_slp, dim3(1), dim3(64), 0, s->s1, w.d_ab, w.d_slp_in);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(s->ev[4], s->s1));
-    KzgRet rc = run_program(s->verify, w.d_slp_in, s->d_prep, w.d_slp_out, 1, s->s1);
-    if (rc != KZG_OK) return rc;
-    HIPCHK(hipEventRecord(s->ev[9], s->s1));
-    uint32_t* h = reinterpret_cast<uint32_t*>(w.h_buf);
-    HIPCHK(hipMemcpyAsync(h, w.d_slp_out, sizeof(Fp) * 6, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipStreamSynchronize(s->s1));
-    uint32_t any = 0;
-    for (int i = 0; i < 72; i++) any |= h[i];
-    *ok = any == 0;
-    (void)hipEventElapsedTime(&s->timings[2], s->ev[2], s->ev[3]);
-    (void)hipEventElapsedTime(&s->timings[3], s->ev[4], s->ev[9]);
-    return KZG_OK;
-}
-
-static KzgRet run_tail(bool* ok, const KzgSettings* s, size_t n) {
-    KzgRet rc = run_msm(s, n);
-    if (rc != KZG_OK) return rc;
-    return run_pairing(ok, s);
-}
-
-// decode 2n points (C then pi) from device bytes [commitments | proofs] into ws.d_points / d_pflag on stream s2
-static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, const void* d_proofs, size_t n) {
-    Workspace& w = s->ws;
-    unsigned blocks = (unsigned)((2 * n + 63) / 64);
-    hipLaunchKernelGGL(k_g1_decode, dim3(blocks), dim3(64), 0, s->s2, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, (int)n,
-                       w.d_points, w.d_pflag, (int)(2 * n), 1);
-    // the generator is point 2n; then 2^(64j) multiples of all 2n+1 points (still off the critical path)
-    int mt = (int)(2 * w.cap_n + 1);
-    hipLaunchKernelGGL(k_set_generator, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, (int)(2 * n));
-    hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((2 * n + 1 + 63) / 64)), dim3(64), 0, s->s2, w.d_points, w.d_pflag, w.d_mult,
-                       (int)(2 * n + 1), mt);
+    unsigned blocks = (unsigned)((2 * T + 63) / 64);
+    hipLaunchKernelGGL(k_g1_decode, dim3(blocks), dim3(64), 0, s->s2, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, (int)T,
+                       w.d_points, w.d_pflag, (int)(2 * T), 1);
+    hipLaunchKernelGGL(k_set_generator, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, (int)(2 * T));
+    hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((2 * T + 1 + 63) / 64)), dim3(64), 0, s->s2, w.d_points, w.d_pflag, w.d_mult,
+                       (int)(2 * T + 1), (int)(2 * T + 1));
     HIPCHK(hipGetLastError());
     return KZG_OK;
 }
 
-// Phase 1 (per shard, no communication): point decode || (challenge -> evaluate) for n blobs.
-// records_out: n * 160 bytes  C(48) || z(32, LE) || y(32, LE) || pi(48) - exactly the per-blob slice of the
-// batch transcript of src/kzg_proof.rs:314-334.
-static KzgRet phase1_locked(uint8_t* records_out, const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n,
-                            const KzgSettings* s) {
+// ---------------------------------------------------------------- the three phases, each as launch + wait
+// A handle is a small state machine: phase1_launch -> phase1_wait -> phase2_launch -> phase2_wait ->
+// finish_launch -> finish_wait.  Launch halves only enqueue work on the handle's streams (plus the host
+// transcript hashes in phase 2); wait halves block on this handle's stream only.  A call processes a launch
+// GROUP of B independent batches of n blobs each (own transcript, r, MSM and pairing instance per batch): at
+// n = 1024 every phase is a latency-bound serial chain that uses a sliver of the chip, so the batch dimension
+// inside the kernels is what fills the machine.
+
+// Phase 1 (no communication): point decode + multiples || (challenge -> evaluate) for all T = B n blobs.
+static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n, size_t B,
+                                   const KzgSettings* s) {
     Workspace& w = s->ws;
+    const size_t T = n * B;
     KzgRet rc;
     HIPCHK(hipEventRecord(s->ev[0], s->s1));
     HIPCHK(hipStreamWaitEvent(s->s2, s->ev[0], 0));
     HIPCHK(hipEventRecord(s->ev[5], s->s2));
-    if ((rc = launch_decode(s, d_commitments, d_proofs, n)) != KZG_OK) return rc;
+    if ((rc = launch_decode(s, d_commitments, d_proofs, T)) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[6], s->s2));
-    HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * n, s->s1));
-    hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, (const uint8_t*)d_blobs,
-                       (const uint8_t*)d_commitments, w.d_z, (int)n);
+    HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * T, s->s1));
+    hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, s->s1, (const uint8_t*)d_blobs,
+                       (const uint8_t*)d_commitments, w.d_z, (int)T);
     HIPCHK(hipEventRecord(s->ev[7], s->s1));
-    hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)n), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, w.d_z, s->d_M, s->d_DM, w.d_y,
+    hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, w.d_z, s->d_M, s->d_DM, w.d_y,
                        w.d_status);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[8], s->s1));
     HIPCHK(hipStreamWaitEvent(s->s1, s->ev[6], 0));
     HIPCHK(hipEventRecord(s->ev[1], s->s1));
     uint8_t* h = w.h_buf;
-    uint8_t *h_z = h, *h_y = h + 32 * n, *h_c = h + 64 * n, *h_p = h + 112 * n;
-    uint32_t* h_status = reinterpret_cast<uint32_t*>(h + 160 * n);
-    uint32_t* h_pflag = h_status + n;
-    HIPCHK(hipMemcpyAsync(h_z, w.d_z, 32 * n, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipMemcpyAsync(h_y, w.d_y, 32 * n, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipMemcpyAsync(h_c, d_commitments, 48 * n, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipMemcpyAsync(h_p, d_proofs, 48 * n, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * n, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * n, hipMemcpyDeviceToHost, s->s1));
+    uint8_t *h_z = h, *h_y = h + 32 * T, *h_c = h + 64 * T, *h_p = h + 112 * T;
+    uint32_t* h_status = reinterpret_cast<uint32_t*>(h + 160 * T);
+    uint32_t* h_pflag = h_status + T;
+    HIPCHK(hipMemcpyAsync(h_z, w.d_z, 32 * T, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(h_y, w.d_y, 32 * T, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(h_c, d_commitments, 48 * T, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(h_p, d_proofs, 48 * T, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * T, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * T, hipMemcpyDeviceToHost, s->s1));
+    w.pending_n = n;
+    w.pending_b = B;
+    return KZG_OK;
+}
+
+// records_out: [B][n] x 160 bytes  C(48) || z(32, LE) || y(32, LE) || pi(48) - exactly the per-blob slices of the
+// batch transcripts of src/kzg_proof.rs:314-334.  bad_out (optional, B bytes): 1 where a batch holds an invalid input
+// (then the call still returns KZG_OK); without bad_out any invalid input makes the whole call return KZG_BADARGS.
+static KzgRet phase1_wait_locked(uint8_t* records_out, uint8_t* bad_out, const KzgSettings* s) {
+    Workspace& w = s->ws;
+    const size_t n = w.pending_n, B = w.pending_b, T = n * B;
     HIPCHK(hipStreamSynchronize(s->s1));
-    (void)hipEventElapsedTime(&s->timings[1], s->ev[0], s->ev[1]);
-    (void)hipEventElapsedTime(&s->timings[4], s->ev[7], s->ev[8]);
-    (void)hipEventElapsedTime(&s->timings[5], s->ev[0], s->ev[7]);
-    (void)hipEventElapsedTime(&s->timings[6], s->ev[5], s->ev[6]);
-    // error order of the reference: commitments (:503), proofs (:508), then blobs (:263)
-    for (size_t i = 0; i < 2 * n; i++)
-        if (h_pflag[i] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
-    for (size_t i = 0; i < n; i++)
-        if (h_status[i]) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");  // (sic) src/kzg_proof.rs:38-40
+    elapsed(&s->timings[1], s->ev[0], s->ev[1]);
+    elapsed(&s->timings[4], s->ev[7], s->ev[8]);
+    elapsed(&s->timings[5], s->ev[0], s->ev[7]);
+    elapsed(&s->timings[6], s->ev[5], s->ev[6]);
+    uint8_t* h = w.h_buf;
+    uint8_t *h_z = h, *h_y = h + 32 * T, *h_c = h + 64 * T, *h_p = h + 112 * T;
+    uint32_t* h_status = reinterpret_cast<uint32_t*>(h + 160 * T);
+    uint32_t* h_pflag = h_status + T;
+    // error order of the reference: commitments (:503), proofs (:508), then blobs (:263); all map to BadArgs
+    bool any_bad = false;
+    for (size_t b = 0; b < B; b++) {
+        bool bad = false;
+        for (size_t i = b * n; i < (b + 1) * n; i++) bad |= h_pflag[i] == G1_INVALID || h_pflag[T + i] == G1_INVALID || h_status[i] != 0;
+        if (bad_out) bad_out[b] = bad;
+        any_bad |= bad;
+    }
+    if (any_bad && !bad_out) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");  // (sic) src/kzg_proof.rs:19-23,38-40
     uint8_t* o = records_out;
-    for (size_t i = 0; i < n; i++, o += 160) {
+    for (size_t i = 0; i < T; i++, o += 160) {
         memcpy(o, h_c + 48 * i, 48);
         memcpy(o + 48, h_z + 32 * i, 32);  // the device limb arrays ARE Scalar::to_bytes() (little-endian), :321,:326
         memcpy(o + 80, h_y + 32 * i, 32);
@@ -620,87 +701,174 @@ static KzgRet phase1_locked(uint8_t* records_out, const void* d_blobs, const voi
     return KZG_OK;
 }
 
-// Phase 2 (per shard): r from the FULL transcript (all n_total records, in global order), this shard's scalars
-// r^(offset+i) and its partial sums A_k, B_k (left in ws.d_ab).  Requires phase 1 of the same shard on this handle.
-static KzgRet phase2_locked(const uint8_t* all_records, size_t n_total, size_t offset, size_t n, const KzgSettings* s) {
+// Phase 2: per batch b, r_b from its FULL transcript (all_records = [B][n_total] records in global blob order), this
+// shard's scalars r_b^(offset+i) and its partial sums (A, B)_b.  Requires phase 1 of the same group on this handle.
+static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, size_t offset, const KzgSettings* s) {
     Workspace& w = s->ws;
+    const size_t n = w.pending_n, B = w.pending_b;
     if (n_total == 1) {
         // verify_blob_kzg_proof path (:482-489): r^0 = 1, no batch challenge
-        hipLaunchKernelGGL(k_single_scalars, dim3(1), dim3(64), 0, s->s1, w.d_z, w.d_y, w.d_scalars);
+        hipLaunchKernelGGL(k_single_scalars, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_z, w.d_y, w.d_scalars);
     } else {
-        // compute_r_powers :291-348
+        // compute_r_powers :291-348, once per batch
         std::vector<uint8_t> t(32 + 160 * n_total);
         memcpy(t.data(), "RCKZGBATCH___V1_", 16);
         memset(t.data() + 16, 0, 16);
         t[22] = (uint8_t)(FE_PER_BLOB >> 8);
         t[23] = (uint8_t)(FE_PER_BLOB & 0xff);
         for (int k = 0; k < 8; k++) t[24 + k] = (uint8_t)((uint64_t)n_total >> (56 - 8 * k));
-        memcpy(t.data() + 32, all_records, 160 * n_total);
-        uint8_t dg[32], r_le[32];
-        hostsha::digest(dg, t.data(), t.size());
-        while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r: at most two subtractions (2^256 < 3r)
-        reverse32(r_le, dg);
-        HIPCHK(hipMemcpyAsync(w.d_r, r_le, 32, hipMemcpyHostToDevice, s->s1));
+        for (size_t b = 0; b < B; b++) {
+            memcpy(t.data() + 32, all_records + 160 * n_total * b, 160 * n_total);
+            uint8_t dg[32];
+            hostsha::digest(dg, t.data(), t.size());
+            while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r: at most two subtractions (2^256 < 3r)
+            reverse32(w.h_buf + w.off_r + 32 * b, dg);  // pinned staging for the async H2D copy
+        }
+        HIPCHK(hipMemcpyAsync(w.d_r, w.h_buf + w.off_r, 32 * B, hipMemcpyHostToDevice, s->s1));
         unsigned blocks = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_batch_scalars, dim3(blocks), dim3(256), 0, s->s1, w.d_r, w.d_z, w.d_y, w.d_scalars, w.d_scalars + n,
+        hipLaunchKernelGGL(k_batch_scalars, dim3(blocks, (unsigned)B), dim3(256), 0, s->s1, w.d_r, w.d_z, w.d_y, w.d_scalars,
                            w.d_partial, (int)n, (unsigned long long)offset);
-        hipLaunchKernelGGL(k_finish_g, dim3(1), dim3(64), 0, s->s1, w.d_partial, (int)blocks, w.d_scalars + 2 * n);
+        hipLaunchKernelGGL(k_finish_g, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_partial, (int)blocks, w.d_scalars, (int)n);
     }
     HIPCHK(hipGetLastError());
-    return run_msm(s, n);
+    KzgRet rc = run_msm(s, n, B);
+    if (rc != KZG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(w.h_buf + w.off_part, w.d_ab, 288 * B, hipMemcpyDeviceToHost, s->s1));
+    return KZG_OK;
+}
+
+static KzgRet phase2_wait_locked(uint8_t* partial_out /* B x 288 */, const KzgSettings* s) {
+    Workspace& w = s->ws;
+    HIPCHK(hipStreamSynchronize(s->s1));
+    elapsed(&s->timings[2], s->ev[2], s->ev[3]);
+    if (partial_out) memcpy(partial_out, w.h_buf + w.off_part, 288 * w.pending_b);
+    return KZG_OK;
+}
+
+// Finish: fold `world` partial sets ([world][B] x 288 B), or take the handle's own (A, B)_b when partials == nullptr,
+// and run one pairing instance per batch.
+static KzgRet finish_launch_locked(const uint8_t* partials, size_t world, size_t B, const KzgSettings* s) {
+    Workspace& w = s->ws;
+    if (partials) {
+        if (world > MAX_WORLD) return fail(KZG_BADARGS, "world size above 64");
+        memcpy(w.h_buf + w.off_parts, partials, 288 * world * B);
+        HIPCHK(hipMemcpyAsync(w.d_parts, w.h_buf + w.off_parts, 288 * world * B, hipMemcpyHostToDevice, s->s1));
+        hipLaunchKernelGGL(k_fold_partials, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_parts, (int)world, (int)B, w.d_ab);
+    }
+    hipLaunchKernelGGL(k_jac_to_slp, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_ab, w.d_slp_in);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev[4], s->s1));
+    KzgRet rc = run_program(s->verify, w.d_slp_in, s->d_prep, w.d_slp_out, (int)B, s->s1);
+    if (rc != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[9], s->s1));
+    HIPCHK(hipMemcpyAsync(w.h_buf + w.off_out, w.d_slp_out, sizeof(Fp) * 6 * B, hipMemcpyDeviceToHost, s->s1));
+    w.finish_b = B;
+    return KZG_OK;
+}
+
+static KzgRet finish_wait_locked(bool* ok /* B */, const KzgSettings* s) {
+    Workspace& w = s->ws;
+    HIPCHK(hipStreamSynchronize(s->s1));
+    const uint32_t* h = reinterpret_cast<const uint32_t*>(w.h_buf + w.off_out);
+    for (size_t b = 0; b < w.finish_b; b++) {
+        uint32_t any = 0;
+        for (int i = 0; i < 72; i++) any |= h[72 * b + i];
+        ok[b] = any == 0;
+    }
+    elapsed(&s->timings[2], s->ev[2], s->ev[3]);
+    elapsed(&s->timings[3], s->ev[4], s->ev[9]);
+    elapsed(&s->timings[0], s->ev[0], s->ev[9]);
+    return KZG_OK;
+}
+
+// pairing check on the (A, B) in ws.d_ab (single instance; used by verify_kzg_proof)
+static KzgRet run_tail(bool* ok, const KzgSettings* s, size_t n) {
+    KzgRet rc = run_msm(s, n, 1);
+    if (rc != KZG_OK) return rc;
+    if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;
+    return finish_wait_locked(ok, s);
 }
 
 static KzgRet batch_device_locked(bool* ok, const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n,
                                   const KzgSettings* s) {
     std::vector<uint8_t> records(160 * n);
-    KzgRet rc = phase1_locked(records.data(), d_blobs, d_commitments, d_proofs, n, s);
-    if (rc != KZG_OK) return rc;
-    if ((rc = phase2_locked(records.data(), n, 0, n, s)) != KZG_OK) return rc;
-    rc = run_pairing(ok, s);
-    (void)hipEventElapsedTime(&s->timings[0], s->ev[0], s->ev[9]);
-    return rc;
+    KzgRet rc;
+    if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, 1, s)) != KZG_OK) return rc;
+    if ((rc = phase1_wait_locked(records.data(), nullptr, s)) != KZG_OK) return rc;
+    if ((rc = phase2_launch_locked(records.data(), n, 0, s)) != KZG_OK) return rc;
+    if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;  // same stream: no host round trip needed
+    return finish_wait_locked(ok, s);
 }
 
-// ---- multi-GPU (one process per GPU): shard by blob, exchange records, fold partial sums ----
+// ---- multi-GPU / grouped / pipelined entry points (include/kzg_rs_amd.h) ----
+#define KZG_ENTER(cond)                                          \
+    if (!(cond)) return fail(KZG_BADARGS, "bad argument");       \
+    std::lock_guard<std::mutex> lk(s->mu);                       \
+    HIPCHK(hipSetDevice(s->device));
+
+extern "C" KzgRet kzg_shard_phase1_launch(const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n_local,
+                                          size_t n_batches, const KzgSettings* s) {
+    KZG_ENTER(s && d_blobs && d_commitments && d_proofs && n_local && n_batches);
+    KzgRet rc = ws_reserve(s, n_local * n_batches, n_batches, false);
+    if (rc != KZG_OK) return rc;
+    return phase1_launch_locked(d_blobs, d_commitments, d_proofs, n_local, n_batches, s);
+}
+extern "C" KzgRet kzg_shard_phase1_wait(uint8_t* records_out, uint8_t* bad_out, const KzgSettings* s) {
+    KZG_ENTER(s && records_out && s->ws.pending_n);
+    return phase1_wait_locked(records_out, bad_out, s);
+}
+extern "C" KzgRet kzg_shard_phase2_launch(const uint8_t* all_records, size_t n_total, size_t offset, const KzgSettings* s) {
+    KZG_ENTER(s && all_records && s->ws.pending_n && offset + s->ws.pending_n <= n_total);
+    return phase2_launch_locked(all_records, n_total, offset, s);
+}
+extern "C" KzgRet kzg_shard_phase2_wait(uint8_t* partial_out, const KzgSettings* s) {
+    KZG_ENTER(s && partial_out);
+    return phase2_wait_locked(partial_out, s);
+}
+extern "C" KzgRet kzg_shard_finish_launch(const uint8_t* partials, size_t world, size_t n_batches, const KzgSettings* s) {
+    KZG_ENTER(s && n_batches && (partials ? world > 0 : true));  // partials == NULL: pair this handle's own sums (single rank)
+    KzgRet rc = ws_reserve(s, 2 * n_batches, n_batches, false);
+    if (rc != KZG_OK) return rc;
+    return finish_launch_locked(partials, world, n_batches, s);
+}
+extern "C" KzgRet kzg_shard_finish_wait(bool* ok, const KzgSettings* s) {
+    KZG_ENTER(s && ok);
+    return finish_wait_locked(ok, s);
+}
+// blocking single-batch forms
 extern "C" KzgRet kzg_shard_phase1(uint8_t* records_out, const void* d_blobs, const void* d_commitments, const void* d_proofs,
                                    size_t n_local, const KzgSettings* s) {
-    if (!s || !records_out || !d_blobs || !d_commitments || !d_proofs || n_local == 0) return fail(KZG_BADARGS, "bad argument");
-    std::lock_guard<std::mutex> lk(s->mu);
-    HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, n_local, false);
-    if (rc != KZG_OK) return rc;
-    return phase1_locked(records_out, d_blobs, d_commitments, d_proofs, n_local, s);
+    KzgRet rc = kzg_shard_phase1_launch(d_blobs, d_commitments, d_proofs, n_local, 1, s);
+    return rc != KZG_OK ? rc : kzg_shard_phase1_wait(records_out, nullptr, s);
 }
-
 extern "C" KzgRet kzg_shard_phase2(uint8_t partial_out[288], const uint8_t* all_records, size_t n_total, size_t offset,
                                    size_t n_local, const KzgSettings* s) {
-    if (!s || !partial_out || !all_records || n_local == 0 || offset + n_local > n_total) return fail(KZG_BADARGS, "bad argument");
-    std::lock_guard<std::mutex> lk(s->mu);
-    HIPCHK(hipSetDevice(s->device));
-    if (n_local > s->ws.cap_n) return fail(KZG_BADARGS, "kzg_shard_phase2 without a matching kzg_shard_phase1");
-    KzgRet rc = phase2_locked(all_records, n_total, offset, n_local, s);
-    if (rc != KZG_OK) return rc;
-    HIPCHK(hipMemcpyAsync(partial_out, s->ws.d_ab, 288, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipStreamSynchronize(s->s1));
-    return KZG_OK;
+    if (s && n_local != s->ws.pending_n) return fail(KZG_BADARGS, "kzg_shard_phase2 without a matching kzg_shard_phase1");
+    KzgRet rc = kzg_shard_phase2_launch(all_records, n_total, offset, s);
+    return rc != KZG_OK ? rc : kzg_shard_phase2_wait(partial_out, s);
+}
+extern "C" KzgRet kzg_shard_finish(bool* ok, const uint8_t* partials, size_t world, const KzgSettings* s) {
+    KzgRet rc = kzg_shard_finish_launch(partials, world, 1, s);
+    return rc != KZG_OK ? rc : kzg_shard_finish_wait(ok, s);
 }
 
-extern "C" KzgRet kzg_shard_finish(bool* ok, const uint8_t* partials, size_t world, const KzgSettings* s) {
-    if (!s || !ok || !partials || world == 0) return fail(KZG_BADARGS, "bad argument");
-    std::lock_guard<std::mutex> lk(s->mu);
-    HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, 2, false);
+// B independent batches of n blobs each in ONE launch group: blobs / commitments / proofs are contiguous device
+// arrays of B*n entries, batch b = entries [b n, (b+1) n); ok_out[b] and (optional) err_out[b] per batch.
+extern "C" KzgRet kzg_verify_blob_kzg_proof_batches_device(bool* ok_out, uint8_t* err_out, const void* d_blobs, const void* d_commitments,
+                                                           const void* d_proofs, size_t n, size_t n_batches, const KzgSettings* s) {
+    KZG_ENTER(s && ok_out && d_blobs && d_commitments && d_proofs && n && n_batches);
+    KzgRet rc = ws_reserve(s, n * n_batches, n_batches, false);
     if (rc != KZG_OK) return rc;
-    G1Jac* d_parts;
-    HIPCHK(hipMalloc(&d_parts, 288 * world));
-    HIPCHK(hipMemcpyAsync(d_parts, partials, 288 * world, hipMemcpyHostToDevice, s->s1));
-    hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(64), 0, s->s1, d_parts, (int)world, s->ws.d_ab);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(s->ev[2], s->s1));
-    HIPCHK(hipEventRecord(s->ev[3], s->s1));
-    rc = run_pairing(ok, s);
-    (void)hipFree(d_parts);
-    return rc;
+    std::vector<uint8_t> records(160 * n * n_batches);
+    if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, n_batches, s)) != KZG_OK) return rc;
+    if ((rc = phase1_wait_locked(records.data(), err_out, s)) != KZG_OK) return rc;
+    if ((rc = phase2_launch_locked(records.data(), n, 0, s)) != KZG_OK) return rc;
+    if ((rc = finish_launch_locked(nullptr, 1, n_batches, s)) != KZG_OK) return rc;
+    if ((rc = finish_wait_locked(ok_out, s)) != KZG_OK) return rc;
+    if (err_out)
+        for (size_t b = 0; b < n_batches; b++)
+            if (err_out[b]) ok_out[b] = false;
+    return KZG_OK;
 }
 
 extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_device(bool* ok, const void* d_blobs, const void* d_commitments,
@@ -713,7 +881,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_device(bool* ok, const void* d
     if (!d_blobs || !d_commitments || !d_proofs) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, n, false);
+    KzgRet rc = ws_reserve(s, n, 1, false);
     if (rc != KZG_OK) return rc;
     return batch_device_locked(ok, d_blobs, d_commitments, d_proofs, n, s);
 }
@@ -728,7 +896,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
     if (!blobs || !commitments || !proofs) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, n, true);
+    KzgRet rc = ws_reserve(s, n, 1, true);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
@@ -750,7 +918,7 @@ extern "C" KzgRet kzg_verify_kzg_proof(bool* ok, const uint8_t commitment[48], c
     if (be_geq_r(z) || be_geq_r(y)) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, 1, true);
+    KzgRet rc = ws_reserve(s, 1, 1, true);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     uint8_t le[64];
@@ -778,7 +946,7 @@ extern "C" KzgRet kzg_compute_challenges(uint8_t* z_out, const uint8_t* blobs, c
     if (n == 0) return KZG_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, n, true);
+    KzgRet rc = ws_reserve(s, n, 1, true);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
@@ -803,7 +971,7 @@ static KzgRet evaluate_device_locked(void* d_y, const void* d_blobs, const void*
     uint32_t* h_status = reinterpret_cast<uint32_t*>(w.h_buf + 64 * n);
     HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * n, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
-    (void)hipEventElapsedTime(&s->timings[4], s->ev[7], s->ev[8]);
+    elapsed(&s->timings[4], s->ev[7], s->ev[8]);
     *any_bad = false;
     for (size_t i = 0; i < n; i++) *any_bad |= h_status[i] != 0;
     return KZG_OK;
@@ -814,7 +982,7 @@ extern "C" KzgRet kzg_evaluate_polynomials_device(void* d_y, const void* d_blobs
     if (n == 0) return KZG_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, n, false);
+    KzgRet rc = ws_reserve(s, n, 1, false);
     if (rc != KZG_OK) return rc;
     bool bad = false;
     if ((rc = evaluate_device_locked(d_y, d_blobs, d_z, n, s, &bad)) != KZG_OK) return rc;
@@ -826,7 +994,7 @@ extern "C" KzgRet kzg_evaluate_polynomials(uint8_t* ys_out, const uint8_t* blobs
     if (n == 0) return KZG_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, n, true);
+    KzgRet rc = ws_reserve(s, n, 1, true);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     for (size_t i = 0; i < n; i++) reverse32(w.h_buf + 32 * i, zs + 32 * i);
@@ -846,7 +1014,7 @@ extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const 
     if (n == 0) return KZG_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, false);
+    KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, 1, false);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     HIPCHK(hipMemcpyAsync(w.d_bytes, points48, 48 * n, hipMemcpyHostToDevice, s->s1));
@@ -871,10 +1039,10 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     if (!s || !out || (n && (!points48 || !scalars))) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, false);
+    KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, 1, false);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
-    int mt = (int)(2 * w.cap_n + 1);
+    int mt = (int)(n ? n : 1);
     // scalars: big-endian, reduced mod r on the host (at most two subtractions), little-endian limbs on the device
     std::vector<uint8_t> le(32 * (n ? n : 1));
     for (size_t i = 0; i < n; i++) {
@@ -916,7 +1084,7 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, w.d_bytes, 48, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
-    (void)hipEventElapsedTime(&s->timings[2], s->ev[2], s->ev[3]);
+    elapsed(&s->timings[2], s->ev[2], s->ev[3]);
     return KZG_OK;
 }
 
@@ -950,7 +1118,7 @@ extern "C" KzgRet kzg_pairing_check(bool* ok, const uint8_t a[48], const uint8_t
     if (!ok || !a || !b || !s) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, 2, false);
+    KzgRet rc = ws_reserve(s, 2, 1, false);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     HIPCHK(hipMemcpyAsync(w.d_bytes, a, 48, hipMemcpyHostToDevice, s->s1));
@@ -965,7 +1133,7 @@ extern "C" KzgRet kzg_pairing_check(bool* ok, const uint8_t a[48], const uint8_t
     HIPCHK(hipEventRecord(s->ev[4], s->s1));
     HIPCHK(hipMemcpyAsync(h + 2, w.d_slp_out, sizeof(Fp) * 6, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
-    (void)hipEventElapsedTime(&s->timings[3], s->ev[3], s->ev[4]);
+    elapsed(&s->timings[3], s->ev[3], s->ev[4]);
     if (h[0] == G1_INVALID || h[1] == G1_INVALID) return fail(KZG_BADARGS, "invalid G1 point");
     uint32_t any = 0;
     for (int i = 0; i < 72; i++) any |= h[2 + i];
@@ -1018,6 +1186,19 @@ extern "C" KzgRet kzg_settings_tau_g2(const KzgSettings* s, uint8_t out[96]) {
     HIPCHK(hipStreamSynchronize(s->s1));
     HIPCHK(hipFree(d));
     return KZG_OK;
+}
+
+// diagnostic / test hook: the host-side SHA-256 used for the batch transcript (force_portable skips SHA-NI)
+extern "C" int kzg_debug_host_sha256(uint8_t out[32], const uint8_t* data, size_t len, int force_portable) {
+    if (force_portable) {
+        uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+        if (len % 64) return -1;
+        for (size_t i = 0; i < len / 64; i++) hostsha::block(st, data + 64 * i);
+        for (int i = 0; i < 8; i++) { out[4*i] = (uint8_t)(st[i] >> 24); out[4*i+1] = (uint8_t)(st[i] >> 16); out[4*i+2] = (uint8_t)(st[i] >> 8); out[4*i+3] = (uint8_t)st[i]; }
+        return 0;
+    }
+    hostsha::digest(out, data, len);
+    return hostsha::have_ni() ? 1 : 0;
 }
 
 // diagnostic: in-kernel shader clock (MHz) = delta s_memtime / delta s_memrealtime * 100 MHz

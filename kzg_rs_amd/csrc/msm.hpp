@@ -36,15 +36,21 @@ struct MsmTerm {
 // sum rp*y_i (Montgomery) to partial[blockIdx].   zs/ys: plain limbs.   r: plain limbs.
 // `offset` is the global index of this shard's first blob (multi-GPU: rank k starts its power
 // table at r^(k n/N) with one square-and-multiply per thread; compute_powers, src/kzg_proof.rs:279-289).
+// blockIdx.y = batch b of a launch group: r[b], zs/ys + b*n, scalars + b*(2n+1) (a at +0, b at +n), partial + b*gridDim.x.
 __global__ __launch_bounds__(256) void k_batch_scalars(const Fr* __restrict__ r_plain, const Fr* __restrict__ zs,
-                                                       const Fr* __restrict__ ys, Fr* __restrict__ a_out,
-                                                       Fr* __restrict__ b_out, Fr* __restrict__ partial, int n,
-                                                       unsigned long long offset) {
+                                                       const Fr* __restrict__ ys, Fr* __restrict__ scalars,
+                                                       Fr* __restrict__ partial, int n, unsigned long long offset) {
     __shared__ Fr red[256];
+    const int bt = blockIdx.y;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    zs += (size_t)bt * n;
+    ys += (size_t)bt * n;
+    Fr* a_out = scalars + (size_t)bt * (2 * n + 1);
+    Fr* b_out = a_out + n;
+    partial += (size_t)bt * gridDim.x;
     Fr acc = FrF::zero();
     if (i < n) {
-        Fr r = FrF::to_mont(*r_plain);
+        Fr r = FrF::to_mont(r_plain[bt]);
         Fr rp = FrF::one();
         unsigned long long e = offset + (unsigned long long)i;
         for (int b = 63 - __clzll(e | 1ull); b >= 0; b--) {
@@ -64,12 +70,13 @@ __global__ __launch_bounds__(256) void k_batch_scalars(const Fr* __restrict__ r_
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-// g = -(sum of partials), plain limbs
-__global__ void k_finish_g(const Fr* __restrict__ partial, int nparts, Fr* __restrict__ g_out) {
-    if (threadIdx.x || blockIdx.x) return;
+// g = -(sum of partials), plain limbs; block b = batch b: partial + b*nparts -> scalars[b*(2n+1) + 2n]
+__global__ void k_finish_g(const Fr* __restrict__ partial, int nparts, Fr* __restrict__ scalars, int n) {
+    if (threadIdx.x) return;
+    const int bt = blockIdx.x;
     Fr s = FrF::zero();
-    for (int i = 0; i < nparts; i++) s = FrF::add(s, partial[i]);
-    *g_out = FrF::from_mont(FrF::neg(s));
+    for (int i = 0; i < nparts; i++) s = FrF::add(s, partial[(size_t)bt * nparts + i]);
+    scalars[(size_t)bt * (2 * n + 1) + 2 * n] = FrF::from_mont(FrF::neg(s));
 }
 
 // ---------------------------------------------------------------- precomputed multiples
@@ -128,14 +135,15 @@ __device__ __forceinline__ G1Jac lds_load_jac(const uint32_t* base, int slot) {
     return p;
 }
 
-// grid (8 windows, 4 chunks, 2 outputs), 256 threads: block (w, j, o) handles digit byte 8j + w of every
+// grid (8 windows, 4 chunks, 2 outputs x batches), 256 threads: block (w, j, o) handles digit byte 8j + w of every
 // scalar of output o, against the multiples 2^(64j) P.
 __global__ __launch_bounds__(256) void k_msm_window(MsmDesc d) {
-    const int w = blockIdx.x, j = blockIdx.y, o = blockIdx.z, tid = threadIdx.x;
+    // blockIdx.z = 2*batch + output
+    const int w = blockIdx.x, j = blockIdx.y, bo = blockIdx.z, o = bo & 1, tid = threadIdx.x;
     const int nt = d.nterms[o];
-    const int wi = (o * MSM_CHUNKS + j) * 8 + w;  // window slot
-    const uint32_t* tp = d.term_point + (size_t)o * d.max_terms;
-    const uint32_t* tsc = d.term_scalar + (size_t)o * d.max_terms;
+    const int wi = (bo * MSM_CHUNKS + j) * 8 + w;  // window slot
+    const uint32_t* tp = d.term_point + (size_t)bo * d.max_terms;
+    const uint32_t* tsc = d.term_scalar + (size_t)bo * d.max_terms;
     uint32_t* sorted = d.sorted + (size_t)wi * d.max_terms;
     const G1Jac* pts_j = d.mult + (size_t)j * d.stride;
     __shared__ uint32_t cnt[MSM_BUCKETS], off[MSM_BUCKETS + 1], cur[MSM_BUCKETS];

@@ -33,6 +33,12 @@ class HipBackend:
         L.kzg_shard_phase1.argtypes = [u8, vp, vp, vp, sz, vp]
         L.kzg_shard_phase2.argtypes = [u8, u8, sz, sz, sz, vp]
         L.kzg_shard_finish.argtypes = [C.POINTER(C.c_bool), u8, sz, vp]
+        L.kzg_shard_phase1_launch.argtypes = [vp, vp, vp, sz, sz, vp]
+        L.kzg_shard_phase1_wait.argtypes = [u8, u8, vp]
+        L.kzg_shard_phase2_launch.argtypes = [u8, sz, sz, vp]
+        L.kzg_shard_phase2_wait.argtypes = [u8, vp]
+        L.kzg_shard_finish_launch.argtypes = [u8, sz, sz, vp]
+        L.kzg_shard_finish_wait.argtypes = [C.POINTER(C.c_bool), vp]
 
     def phase1(self, shard):
         d_blobs, d_commitments, d_proofs, n_local = shard
@@ -49,6 +55,33 @@ class HipBackend:
         ok = C.c_bool(False)
         api._chk(api.lib().kzg_shard_finish(C.byref(ok), partials, world, self.settings._h))
         return bool(ok.value)
+
+    # launch / wait halves over a launch group of n_batches batches (see PipelinedVerifier)
+    def phase1_launch(self, shard, n_batches=1):
+        d_blobs, d_commitments, d_proofs, n_local = shard
+        self._n, self._b = n_local, n_batches
+        api._chk(api.lib().kzg_shard_phase1_launch(d_blobs, d_commitments, d_proofs, n_local, n_batches, self.settings._h))
+
+    def phase1_wait(self):
+        out = C.create_string_buffer(RECORD_BYTES * self._n * self._b)
+        api._chk(api.lib().kzg_shard_phase1_wait(out, None, self.settings._h))
+        return out.raw
+
+    def phase2_launch(self, all_records, n_total, offset):
+        api._chk(api.lib().kzg_shard_phase2_launch(all_records, n_total, offset, self.settings._h))
+
+    def phase2_wait(self):
+        out = C.create_string_buffer(PARTIAL_BYTES * self._b)
+        api._chk(api.lib().kzg_shard_phase2_wait(out, self.settings._h))
+        return out.raw
+
+    def finish_launch(self, partials, world):
+        api._chk(api.lib().kzg_shard_finish_launch(partials, world, self._b, self.settings._h))
+
+    def finish_wait(self):
+        ok = (C.c_bool * self._b)()
+        api._chk(api.lib().kzg_shard_finish_wait(ok, self.settings._h))
+        return [bool(x) for x in ok]
 
 
 def _all_gather_bytes(dist, payload, device):
@@ -101,3 +134,58 @@ def verify_blob_kzg_proof_batch_sharded(shard, n_local, backend, dist=None, devi
     part = backend.phase2(b"".join(gathered), n_total, offset, n_local) if n_local else b""
     parts = [p for p in _all_gather_bytes(dist, part, device) if p]  # exchange 2: 288 B per rank
     return backend.finish(b"".join(parts), len(parts))
+
+
+class PipelinedVerifier:
+    """Throughput mode: launch GROUPS of independent batches, and keep several groups in flight from ONE host
+    thread with a fixed-order software pipeline.
+
+    At n = 1024 every phase of a batch is a latency-bound serial chain that occupies a sliver of the chip (the
+    SHA-256 challenge chain runs on 16 of 1024 SIMDs for ~7 ms), so `group` batches share each kernel launch
+    (batch dimension inside the kernels) and `depth` groups overlap through separate handles (= HIP streams).
+    Iteration t runs, in this order:   phase1_launch(t);   phase1_wait(t-d1) + exchange 1 + phase2_launch;
+    phase2_wait(t-d1-d2) + exchange 2 + finish_launch;   finish_wait(t-d1-d2-d3).
+    The order is the same on every rank, so the collectives of different groups never interleave differently
+    on different ranks.  With one rank the exchanges and the phase-2 host round trip disappear."""
+
+    def __init__(self, backends, dist=None, device="cpu", depth=(1, 1, 1)):
+        self.backends = backends
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.device = device
+        self.depth = depth if self.dist else (depth[0], 0, depth[2])
+        assert len(backends) >= sum(self.depth) + 1, "need depth+1 handles"
+
+    def _regroup(self, gathered, n_batches):
+        """[rank][batch][n_local] records -> [batch][rank][n_local] (each batch's global transcript order)."""
+        per_rank = [[g[i * (len(g) // n_batches): (i + 1) * (len(g) // n_batches)] for i in range(n_batches)] for g in gathered]
+        return b"".join(per_rank[r][b] for b in range(n_batches) for r in range(len(gathered)))
+
+    def run(self, groups):
+        """groups: list of ((d_blobs, d_commitments, d_proofs, n_local), n_batches): this rank's shard of every batch
+        of the group, batches contiguous.  Returns the per-batch results of every group, in order."""
+        K, S = len(groups), len(self.backends)
+        d1, d2, d3 = self.depth
+        results = [None] * K
+        for t in range(K + d1 + d2 + d3):
+            if t < K:
+                self.backends[t % S].phase1_launch(groups[t][0], groups[t][1])
+            i = t - d1
+            if 0 <= i < K:
+                b, nb = self.backends[i % S], groups[i][1]
+                recs = b.phase1_wait()
+                if self.dist:
+                    gathered = _all_gather_bytes(self.dist, recs, self.device)
+                    counts = [len(g) // RECORD_BYTES // nb for g in gathered]
+                    b.phase2_launch(self._regroup(gathered, nb), sum(counts), sum(counts[: self.dist.get_rank()]))
+                else:
+                    b.phase2_launch(recs, len(recs) // RECORD_BYTES // nb, 0)
+                    b.finish_launch(None, 1)
+            j = t - d1 - d2
+            if self.dist and 0 <= j < K:
+                b = self.backends[j % S]
+                parts = _all_gather_bytes(self.dist, b.phase2_wait(), self.device)
+                b.finish_launch(b"".join(parts), len(parts))
+            k = t - d1 - d2 - d3
+            if 0 <= k < K:
+                results[k] = self.backends[k % S].finish_wait()
+        return results

@@ -334,3 +334,42 @@ def test_device_resident_batch_full_size():
         z = api.compute_challenges([b], [cs[i]], st)[0]
         assert z == O.compute_challenge(b, cs[i])
         assert api.evaluate_polynomials([b], [z], st)[0] == O.evaluate_polynomial_in_evaluation_form(b, z, ost)
+
+
+def test_launch_group_of_batches():
+    """Several independent batches in one launch group (batch dimension inside the kernels): each batch must get
+    exactly the result the oracle gives for it alone - a valid one, one with a corrupted proof, one with an
+    invalid blob (Err), one with an invalid commitment (Err), and a second valid one."""
+    import torch
+    from kzg_rs_amd import synth
+    n, B = 6, 5
+    blobs, cs, ps, st = synth.make_valid_batch(n * B, seed=77)
+    ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])
+    blobs = blobs.copy()
+    cs, ps = list(cs), list(ps)
+    ps[1 * n + 2] = O.g1_add(ps[1 * n + 2], G1_GEN)                       # batch 1: wrong proof -> false
+    blobs[2 * n + 3, 32 * 7: 32 * 7 + 32] = list(R.to_bytes(32, "big"))   # batch 2: non-canonical element -> Err
+    cs[3 * n + 1] = bytes([0x81]) + bytes(range(1, 48))                   # batch 3: junk commitment -> Err
+    want = []
+    for b in range(B):
+        bl = [blobs[i].tobytes() for i in range(b * n, (b + 1) * n)]
+        try:
+            want.append(O.verify_blob_kzg_proof_batch(bl, cs[b * n:(b + 1) * n], ps[b * n:(b + 1) * n], ost))
+        except O.OracleError:
+            want.append(None)
+    assert want == [True, False, None, None, True]
+    d_b = torch.from_numpy(blobs).cuda()
+    d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).cuda()
+    d_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    got = api.verify_blob_kzg_proof_batches_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, B, st)
+    assert got == want
+    # and a group of single-blob batches (the n == 1 path of src/kzg_proof.rs:482-489, no batch challenge)
+    got1 = api.verify_blob_kzg_proof_batches_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 1, 12, st)
+    want1 = []
+    for i in range(12):
+        try:
+            want1.append(O.verify_blob_kzg_proof(blobs[i].tobytes(), cs[i], ps[i], ost))
+        except O.OracleError:
+            want1.append(None)
+    assert got1 == want1 and want1.count(True) >= 10 and False in want1
