@@ -147,7 +147,8 @@ KzgRet kzg_evaluate_polynomials_device(void *d_y, const void *d_blobs, const voi
 KzgRet kzg_g1_decompress(uint8_t *status_out, uint8_t *xy_out, const uint8_t *points48, size_t n,
                          const KzgSettings *s);
 /* G1Projective::msm_variable_base (call sites src/kzg_proof.rs:419,429,430): out = sum scalars[i] * points[i];
- * points: n * 48 bytes compressed (subgroup unchecked), scalars: n * 32 bytes big-endian (reduced mod r),
+ * points: n * 48 bytes compressed, must lie in G1 (checked: the MSM uses the GLV endomorphism); scalars: n * 32 bytes
+ * big-endian (reduced mod r),
  * out: 48 bytes compressed.  Host pointers. */
 KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t *points48, const uint8_t *scalars, size_t n, const KzgSettings *s);
 /* out48[i] = compress(scalars[i] * G1::generator()); scalars n * 32 bytes big-endian (reduced mod r).

@@ -602,6 +602,8 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     d.max_terms = mt;
     d.stride = 2 * T + 1;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
+    const int nsc = (int)(B * (2 * n + 1));
+    hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc);
     hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, (unsigned)(2 * B)), dim3(256), 0, s->s1, d);
     hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(2 * B)), dim3(64), 0, s->s1, w.d_window, w.d_ab);
     HIPCHK(hipGetLastError());
@@ -1054,7 +1056,8 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     if (n) {
         HIPCHK(hipMemcpyAsync(w.d_bytes, points48, 48 * n, hipMemcpyHostToDevice, s->s1));
         HIPCHK(hipMemcpyAsync(w.d_scalars, le.data(), 32 * n, hipMemcpyHostToDevice, s->s1));
-        hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_bytes, w.d_bytes, (int)n, w.d_points, w.d_pflag, (int)n, 0);
+        hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_bytes, w.d_bytes, (int)n, w.d_points, w.d_pflag, (int)n, 1);
+        hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, (int)n);
         hipLaunchKernelGGL(k_plain_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar, (int)n);
         HIPCHK(hipGetLastError());
         std::vector<uint32_t> st(n);

@@ -16,7 +16,7 @@
 //   1. counting sort of the output's terms by their 8-bit digit (LDS histogram + cursor),
 //      so that afterwards every lane walks its own bucket list and all lanes add at once;
 //   2. thread b accumulates bucket b with mixed Jacobian+affine additions;
-//   3. sum_b b*B_b by an LDS suffix scan followed by a tree sum (Jacobian points staged in LDS);
+//   3. sum_b b*B_b through row / column sums of the 16 x 16 bucket matrix (Jacobian points staged in LDS);
 // then k_msm_combine folds the chunk sums and the 8 windows (Horner, 8 doublings per window).
 #pragma once
 #include "g1.hpp"
@@ -79,22 +79,88 @@ __global__ void k_finish_g(const Fr* __restrict__ partial, int nparts, Fr* __res
     scalars[(size_t)bt * (2 * n + 1) + 2 * n] = FrF::from_mont(FrF::neg(s));
 }
 
-// ---------------------------------------------------------------- precomputed multiples
-// mult[j][p] = 2^(64 j) * points[p], j = 0..3 (Jacobian).  With them a 255-bit scalar splits into four
-// 64-bit chunks, sum_i s_i P_i = sum_i sum_j s_ij (2^(64j) P_i): the MSM needs only 8 windows and the
-// serial window combine 56 doublings instead of 248.  The 192 doublings per point depend only on the
-// INPUT points, so this kernel runs beside the SHA-256 challenge chain, off the critical path.
+// ---------------------------------------------------------------- scalar chunks and their points
+// A 255-bit scalar is split into FOUR 64-bit chunks so that the MSM needs only 8 windows of 8 bits and the
+// serial window combine 56 doublings instead of 248:
+//     k = k1 + k2 * L,  L = x^2 (GLV: on G1, phi(P) = (beta x, y) = -[x^2]P, so [L]P = -phi(P)),  k1, k2 < 2^128
+//     k P = k1_lo P + k1_hi (2^64 P) + k2_lo (-phi P) + k2_hi (-phi(2^64 P)).
+// mult[0..3][p] = P, 2^64 P, -phi(P), -phi(2^64 P) (Jacobian): 64 doublings + 2 multiplications per point, which
+// depend only on the INPUT points, so k_g1_multiples runs beside the SHA-256 challenge chain, off the critical path.
+// Points must lie in G1 (all callers decode with the subgroup check).
 constexpr int MSM_CHUNKS = 4;
+__device__ __forceinline__ G1Jac g1_neg_phi(const G1Jac& p) {
+    G1Jac r;
+    r.x = fp_mul(p.x, fp_const(consts::FP_BETA_MONT));
+    r.y = fp_neg(p.y);
+    r.z = p.z;
+    return r;
+}
 __global__ __launch_bounds__(64) void k_g1_multiples(const G1Aff* __restrict__ points, const uint32_t* __restrict__ pflag,
                                                      G1Jac* __restrict__ mult, int n, int stride) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     G1Jac acc = pflag[i] ? g1_identity() : g1_from_affine(points[i]);
     mult[i] = acc;
-    for (int j = 1; j < MSM_CHUNKS; j++) {
-        for (int k = 0; k < 64; k++) acc = g1_dbl(acc);
-        mult[(size_t)j * stride + i] = acc;
+    mult[(size_t)2 * stride + i] = g1_neg_phi(acc);
+    for (int k = 0; k < 64; k++) acc = g1_dbl(acc);
+    mult[(size_t)stride + i] = acc;
+    mult[(size_t)3 * stride + i] = g1_neg_phi(acc);
+}
+
+// in place: canonical k (< r) -> k1 (limbs 0..3) | k2 (limbs 4..7) with k = k1 + k2 * x^2.
+// Barrett with M = floor(2^383 / x^2): the quotient estimate is low by at most 1 for k < 2^255.
+__global__ __launch_bounds__(256) void k_glv_split(Fr* __restrict__ scalars, int count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fr k = scalars[i];
+    uint32_t prod[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) prod[j] = 0;
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            uint64_t t = (uint64_t)k.l[a] * consts::GLV_M[b] + prod[a + b] + c;
+            prod[a + b] = (uint32_t)t;
+            c = t >> 32;
+        }
+        prod[a + 8] = (uint32_t)c;
     }
+    uint32_t q[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) q[j] = (prod[11 + j] >> 31) | (prod[12 + j] << 1);
+    // rem = k - q * L  (fits in 160 bits: rem < 2 L)
+    uint32_t ql[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) ql[j] = 0;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            uint64_t t = (uint64_t)q[a] * consts::GLV_L[b] + ql[a + b] + c;
+            ql[a + b] = (uint32_t)t;
+            c = t >> 32;
+        }
+        ql[a + 4] = (uint32_t)c;
+    }
+    uint32_t rem[5], borrow = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) rem[j] = subb(k.l[j], ql[j], borrow);
+    // if rem >= L: rem -= L, q += 1
+    uint32_t d[5], bo = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) d[j] = subb(rem[j], j < 4 ? consts::GLV_L[j] : 0u, bo);
+    const bool ge = bo == 0;
+    uint32_t carry = ge ? 1u : 0u;
+    Fr out;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        out.l[j] = ge ? d[j] : rem[j];
+        out.l[4 + j] = addc(q[j], 0u, carry);
+    }
+    scalars[i] = out;
 }
 
 // ---------------------------------------------------------------- bucket accumulation + reduction
@@ -180,30 +246,62 @@ __global__ __launch_bounds__(256) void k_msm_window(MsmDesc d) {
     if (tid > 0) {
         for (uint32_t k = off[tid]; k < off[tid + 1]; k++) acc = g1_add(acc, pts_j[sorted[k]]);
     }
-    // 3. sum_b b*B_b = sum_{b>=1} S_b,  S_b = sum_{b' >= b} B_b'   (suffix scan, then tree sum)
+    // 3. sum_b b*B_b with b = 16 hi + lo:   16 * sum_hi hi*R_hi + sum_lo lo*C_lo,
+    //    R_hi = row sums, C_lo = column sums of the 16 x 16 bucket matrix.  Two 4-level trees (ops packed into
+    //    the low threads so idle waves skip the additions), then two 16-element weighted sums done by a
+    //    suffix scan + tree on 32 threads, then 4 doublings.  ~19 wave-level point additions per block instead
+    //    of the 64 of a 256-wide scan + tree.
     lds_store_jac(pts, tid, acc);
     __syncthreads();
-    for (int s = 1; s < MSM_BUCKETS; s <<= 1) {
+    for (int s = 1; s < 16; s <<= 1) {  // row trees: dst = 16 hi + 2 s k, src = dst + s
+        const int ops = 128 / s, per_row = 8 / s;
+        if (tid < ops) {
+            const int dst = 16 * (tid / per_row) + 2 * s * (tid % per_row);
+            lds_store_jac(pts, dst, g1_add(lds_load_jac(pts, dst), lds_load_jac(pts, dst + s)));
+        }
+        __syncthreads();
+    }
+    G1Jac x = g1_identity();  // threads 0..15: R_tid, threads 16..31: C_(tid-16)
+    if (tid < 16) x = lds_load_jac(pts, 16 * tid);
+    __syncthreads();
+    lds_store_jac(pts, tid, acc);
+    __syncthreads();
+    for (int s = 1; s < 16; s <<= 1) {  // column trees: dst = 16 (2 s k) + lo, src = dst + 16 s
+        const int ops = 128 / s;
+        if (tid < ops) {
+            const int dst = 16 * (2 * s * (tid >> 4)) + (tid & 15);
+            lds_store_jac(pts, dst, g1_add(lds_load_jac(pts, dst), lds_load_jac(pts, dst + 16 * s)));
+        }
+        __syncthreads();
+    }
+    if (tid >= 16 && tid < 32) x = lds_load_jac(pts, tid - 16);
+    __syncthreads();
+    // weighted sums sum_{k=1..15} k X_k for X = R (threads 0..15) and X = C (threads 16..31): suffix scan, then tree
+    const int idx = tid & 15;
+    if (tid < 32) lds_store_jac(pts, tid, x);
+    __syncthreads();
+    for (int s = 1; s < 16; s <<= 1) {
         G1Jac other = g1_identity();
-        bool has = tid + s < MSM_BUCKETS;
+        const bool has = tid < 32 && idx + s < 16;
         if (has) other = lds_load_jac(pts, tid + s);
         __syncthreads();
         if (has) {
-            acc = g1_add(acc, other);
-            lds_store_jac(pts, tid, acc);
+            x = g1_add(x, other);
+            lds_store_jac(pts, tid, x);
         }
         __syncthreads();
     }
-    if (tid == 0) lds_store_jac(pts, 0, g1_identity());  // S_0 is not part of the sum
+    if (tid < 32 && idx == 0) lds_store_jac(pts, tid, g1_identity());  // S_0 is not part of the sum
     __syncthreads();
-    for (int s = MSM_BUCKETS / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            G1Jac x = lds_load_jac(pts, tid), y = lds_load_jac(pts, tid + s);
-            lds_store_jac(pts, tid, g1_add(x, y));
-        }
+    for (int s = 8; s > 0; s >>= 1) {
+        if (tid < 32 && idx < s) lds_store_jac(pts, tid, g1_add(lds_load_jac(pts, tid), lds_load_jac(pts, tid + s)));
         __syncthreads();
     }
-    if (tid == 0) d.window_sums[wi] = lds_load_jac(pts, 0);
+    if (tid == 0) {
+        G1Jac r = lds_load_jac(pts, 0);  // sum hi * R_hi
+        for (int k = 0; k < 4; k++) r = g1_dbl(r);
+        d.window_sums[wi] = g1_add(r, lds_load_jac(pts, 16));
+    }
 }
 
 // out[o] = sum_w 2^(8w) (sum_j W[o][j][w]): 8 threads fold the chunks, then one Horner chain of 56 doublings

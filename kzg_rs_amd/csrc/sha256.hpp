@@ -27,8 +27,15 @@ __device__ __forceinline__ void sha256_init(Sha256State& s) {
 }
 
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+// gfx950 has a 3-input arbitrary boolean op (v_bitop3_b32); hipcc finds it only partly, so spell it out:
+// truth-table byte indexed by (a << 2 | b << 1 | c).
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t sha_ch(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }
+__device__ __forceinline__ uint32_t sha_maj(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
 
 // one 64-byte block; w[16] = message words (already big-endian decoded); destroyed.
+// ~14 VALU instructions per round + ~10 per scheduled word: 3 v_alignbit + 1 v_bitop3 per Sigma/sigma,
+// one v_bitop3 each for Ch and Maj, v_add3_u32 for the sums.
 __device__ __forceinline__ void sha256_compress(Sha256State& s, uint32_t (&w)[16]) {
     uint32_t a = s.h[0], b = s.h[1], c = s.h[2], d = s.h[3], e = s.h[4], f = s.h[5], g = s.h[6], h = s.h[7];
 #pragma unroll
@@ -38,17 +45,15 @@ __device__ __forceinline__ void sha256_compress(Sha256State& s, uint32_t (&w)[16
             wi = w[i];
         } else {
             uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
-            uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
-            wi = w[i & 15] + s0 + w[(i - 7) & 15] + s1;
+            uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+            uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+            wi = (w[i & 15] + s0) + (w[(i - 7) & 15] + s1);
             w[i & 15] = wi;
         }
-        uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
-        uint32_t ch = (e & f) ^ (~e & g);
-        uint32_t t1 = h + S1 + ch + SHA_K[i] + wi;
-        uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
-        uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
-        uint32_t t2 = S0 + mj;
+        uint32_t S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
+        uint32_t t1 = (h + S1 + sha_ch(e, f, g)) + (SHA_K[i] + wi);
+        uint32_t S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
+        uint32_t t2 = S0 + sha_maj(a, b, c);
         h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     s.h[0] += a; s.h[1] += b; s.h[2] += c; s.h[3] += d; s.h[4] += e; s.h[5] += f; s.h[6] += g; s.h[7] += h;
