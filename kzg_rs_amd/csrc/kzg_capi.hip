@@ -525,6 +525,16 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     delete s;
 }
 
+// challenge kernel selection: producer/consumer form by default; KZG_CHALLENGE_KERNEL=lane selects the
+// one-lane-per-blob form (kept for A/B measurement and as a cross-check in the tests)
+static bool challenge_split() {
+    static const bool v = [] {
+        const char* e = getenv("KZG_CHALLENGE_KERNEL");
+        return !(e && strcmp(e, "lane") == 0);
+    }();
+    return v;
+}
+
 // Workspace for a launch group of B batches with T blobs in total (B = 1 for the single-call entry points).
 static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
     Workspace& w = s->ws;
@@ -645,8 +655,12 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
     if ((rc = launch_decode(s, d_commitments, d_proofs, T)) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[6], s->s2));
     HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * T, s->s1));
-    hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, s->s1, (const uint8_t*)d_blobs,
-                       (const uint8_t*)d_commitments, w.d_z, (int)T);
+    if (challenge_split())
+        hipLaunchKernelGGL(k_blob_challenge_split, dim3((unsigned)((T + 63) / 64)), dim3(128), 0, s->s1, (const uint8_t*)d_blobs,
+                           (const uint8_t*)d_commitments, w.d_z, (int)T);
+    else
+        hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, s->s1, (const uint8_t*)d_blobs,
+                           (const uint8_t*)d_commitments, w.d_z, (int)T);
     HIPCHK(hipEventRecord(s->ev[7], s->s1));
     hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, w.d_z, s->d_M, s->d_DM, w.d_y,
                        w.d_status);
@@ -953,7 +967,10 @@ extern "C" KzgRet kzg_compute_challenges(uint8_t* z_out, const uint8_t* blobs, c
     Workspace& w = s->ws;
     HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
     HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
-    hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_stage_blobs, w.d_stage_cp, w.d_z, (int)n);
+    if (challenge_split())
+        hipLaunchKernelGGL(k_blob_challenge_split, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, s->s1, w.d_stage_blobs, w.d_stage_cp, w.d_z, (int)n);
+    else
+        hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_stage_blobs, w.d_stage_cp, w.d_z, (int)n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(w.h_buf, w.d_z, 32 * n, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));

@@ -59,4 +59,37 @@ __device__ __forceinline__ void sha256_compress(Sha256State& s, uint32_t (&w)[16
     s.h[0] += a; s.h[1] += b; s.h[2] += c; s.h[3] += d; s.h[4] += e; s.h[5] += f; s.h[6] += g; s.h[7] += h;
 }
 
+// ---- split form: the message schedule (+K) and the 64 rounds as separate functions, for the
+// producer / consumer challenge kernel (fr_kernels.hpp: k_blob_challenge_split)
+// kw[t] = W[t] + K[t], t = 0..63, from the 16 message words
+__device__ __forceinline__ void sha256_schedule_kw(uint32_t (&kw)[64], uint32_t (&w)[16]) {
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+        uint32_t wi;
+        if (i < 16) {
+            wi = w[i];
+        } else {
+            uint32_t w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
+            uint32_t s0 = xor3(rotr32(w15, 7), rotr32(w15, 18), w15 >> 3);
+            uint32_t s1 = xor3(rotr32(w2, 17), rotr32(w2, 19), w2 >> 10);
+            wi = (w[i & 15] + s0) + (w[(i - 7) & 15] + s1);
+            w[i & 15] = wi;
+        }
+        kw[i] = wi + SHA_K[i];
+    }
+}
+// four rounds t..t+3 with kw = (K+W)[t..t+3]
+__device__ __forceinline__ void sha256_rounds4(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, uint32_t& e, uint32_t& f,
+                                               uint32_t& g, uint32_t& h, const uint4& kw) {
+    const uint32_t k4[4] = {kw.x, kw.y, kw.z, kw.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t S1 = xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25));
+        uint32_t t1 = (h + S1 + sha_ch(e, f, g)) + k4[i];
+        uint32_t S0 = xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22));
+        uint32_t t2 = S0 + sha_maj(a, b, c);
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+}
+
 }  // namespace kzg
