@@ -225,7 +225,7 @@ __device__ __forceinline__ Fr fr_shfl_xor(const Fr& a, int mask) {
 // z_in: plain little-endian limbs (any value < 2^256; reduced mod r here, like scalar_from_bytes_unchecked)
 // y_out: plain little-endian canonical limbs.  status[b] |= 1 when a blob element is >= r
 // (src/kzg_proof.rs:36-41 -> KzgError::BadArgs).
-__global__ __launch_bounds__(64) void k_blob_evaluate(const uint8_t* __restrict__ blobs, const Fr* __restrict__ z_in,
+__global__ __launch_bounds__(64, 4) void k_blob_evaluate(const uint8_t* __restrict__ blobs, const Fr* __restrict__ z_in,
                                                       const Fr* __restrict__ M, const Fr* __restrict__ DM,
                                                       Fr* __restrict__ y_out, uint32_t* __restrict__ status) {
     const int blob_idx = blockIdx.x;

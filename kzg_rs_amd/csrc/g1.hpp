@@ -5,14 +5,43 @@
 //   G2Affine::from_compressed_unchecked  build.rs:73
 // Encoding: ZCash/IETF compressed BLS12-381 points.
 //
-// Fp multiplication is kept out of line (fp_mul is __noinline__): one Fp product is ~760 VALU
+// Fp multiplication is kept out of line (fp_mul_raw is __noinline__): one Fp product is ~760 VALU
 // instructions, and point formulas use dozens of them; inlining would blow the instruction cache.
+// The point formulas themselves are inlined at (few) call sites: big struct arguments would go through scratch.
 #pragma once
 #include "field.hpp"
 
 namespace kzg {
 
-__device__ __noinline__ Fp fp_mul(Fp a, Fp b) { return FpF::mul(a, b); }
+// Out-of-line Fp product.  Operands travel as 12-lane ext-vectors: AMDGPU passes vector arguments in VGPRs,
+// whereas a 48-byte struct argument goes through scratch memory (a store + load round trip per call).
+typedef uint32_t v12u __attribute__((ext_vector_type(12)));
+__device__ __noinline__ v12u fp_mul_raw(v12u a, v12u b) {
+    Fp x, y;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        x.l[i] = a[i];
+        y.l[i] = b[i];
+    }
+    Fp r = FpF::mul(x, y);
+    v12u o;
+#pragma unroll
+    for (int i = 0; i < 12; i++) o[i] = r.l[i];
+    return o;
+}
+__device__ __forceinline__ Fp fp_mul(const Fp& a, const Fp& b) {
+    v12u x, y;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        x[i] = a.l[i];
+        y[i] = b.l[i];
+    }
+    v12u o = fp_mul_raw(x, y);
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = o[i];
+    return r;
+}
 __device__ __forceinline__ Fp fp_sqr(const Fp& a) { return fp_mul(a, a); }
 __device__ __forceinline__ Fp fp_add(const Fp& a, const Fp& b) { return FpF::add(a, b); }
 __device__ __forceinline__ Fp fp_sub(const Fp& a, const Fp& b) { return FpF::sub(a, b); }
@@ -100,7 +129,7 @@ __device__ __forceinline__ G1Jac g1_dbl(const G1Jac& p) {
 }
 
 // general Jacobian addition with every special case handled (identity operands, P+P, P-P)
-__device__ __noinline__ G1Jac g1_add(const G1Jac& p, const G1Jac& q) {
+__device__ __forceinline__ G1Jac g1_add(const G1Jac& p, const G1Jac& q) {
     if (g1_is_identity(p)) return q;
     if (g1_is_identity(q)) return p;
     Fp Z1Z1 = fp_sqr(p.z), Z2Z2 = fp_sqr(q.z);
@@ -120,7 +149,7 @@ __device__ __noinline__ G1Jac g1_add(const G1Jac& p, const G1Jac& q) {
 }
 
 // mixed addition p + (affine q, q != identity)
-__device__ __noinline__ G1Jac g1_add_affine(const G1Jac& p, const G1Aff& q) {
+__device__ __forceinline__ G1Jac g1_add_affine(const G1Jac& p, const G1Aff& q) {
     if (g1_is_identity(p)) return g1_from_affine(q);
     Fp Z1Z1 = fp_sqr(p.z);
     Fp U2 = fp_mul(q.x, Z1Z1), S2 = fp_mul(fp_mul(q.y, p.z), Z1Z1);
@@ -140,6 +169,7 @@ __device__ __noinline__ G1Jac g1_add_affine(const G1Jac& p, const G1Aff& q) {
 // [|x|]P for the BLS parameter |x| = 0xd201000000010000 (63 doublings + 5 additions)
 __device__ inline G1Jac g1_mul_xabs(const G1Jac& p) {
     G1Jac acc = p;
+#pragma unroll 1
     for (int i = 62; i >= 0; i--) {
         acc = g1_dbl(acc);
         if ((BLS_X_ABS >> i) & 1) acc = g1_add(acc, p);
@@ -152,7 +182,9 @@ __device__ inline G1Jac g1_mul_xabs(const G1Jac& p) {
 // criterion zkcrypto/bls12_381 uses).  Accepts exactly the points with [r]P = O, which is what the
 // oracle checks by definition; tests/test_g1_decode.py compares the two on and off the subgroup.
 __device__ inline bool g1_in_subgroup(const G1Aff& p) {
-    G1Jac q = g1_mul_xabs(g1_mul_xabs(g1_from_affine(p)));  // [x^2]P (the two signs cancel)
+    G1Jac q = g1_from_affine(p);
+#pragma unroll 1
+    for (int rep = 0; rep < 2; rep++) q = g1_mul_xabs(q);  // [x^2]P (the two signs cancel); one copy of the loop body
     if (g1_is_identity(q)) return false;
     Fp zz = fp_sqr(q.z), zzz = fp_mul(zz, q.z);
     Fp bx = fp_mul(p.x, fp_const(consts::FP_BETA_MONT));

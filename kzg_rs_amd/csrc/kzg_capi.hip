@@ -418,7 +418,10 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
     KzgSettings* s = new KzgSettings();
     HIPCHK(hipGetDevice(&s->device));
     HIPCHK(hipStreamCreateWithFlags(&s->s1, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&s->s2, hipStreamNonBlocking));
+    // KZG_SINGLE_STREAM=1 (profiling aid): run the point-decode chain on the same stream as the challenge chain, so
+    // per-dispatch PMC counters are not polluted by a concurrent kernel
+    if (getenv("KZG_SINGLE_STREAM") && getenv("KZG_SINGLE_STREAM")[0] == '1') s->s2 = s->s1;
+    else HIPCHK(hipStreamCreateWithFlags(&s->s2, hipStreamNonBlocking));
     for (auto& e : s->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipMalloc(&s->d_M, sizeof(Fr) * FE_PER_BLOB));
     HIPCHK(hipMalloc(&s->d_DM, sizeof(Fr) * FE_PER_BLOB));
@@ -521,7 +524,7 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     if (s->s1) (void)hipStreamDestroy(s->s1);
-    if (s->s2) (void)hipStreamDestroy(s->s2);
+    if (s->s2 && s->s2 != s->s1) (void)hipStreamDestroy(s->s2);
     delete s;
 }
 

@@ -95,7 +95,7 @@ __device__ __forceinline__ G1Jac g1_neg_phi(const G1Jac& p) {
     r.z = p.z;
     return r;
 }
-__global__ __launch_bounds__(64) void k_g1_multiples(const G1Aff* __restrict__ points, const uint32_t* __restrict__ pflag,
+__global__ __launch_bounds__(64, 4) void k_g1_multiples(const G1Aff* __restrict__ points, const uint32_t* __restrict__ pflag,
                                                      G1Jac* __restrict__ mult, int n, int stride) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -203,7 +203,7 @@ __device__ __forceinline__ G1Jac lds_load_jac(const uint32_t* base, int slot) {
 
 // grid (8 windows, 4 chunks, 2 outputs x batches), 256 threads: block (w, j, o) handles digit byte 8j + w of every
 // scalar of output o, against the multiples 2^(64j) P.
-__global__ __launch_bounds__(256) void k_msm_window(MsmDesc d) {
+__global__ __launch_bounds__(256, 3) void k_msm_window(MsmDesc d) {
     // blockIdx.z = 2*batch + output
     const int w = blockIdx.x, j = blockIdx.y, bo = blockIdx.z, o = bo & 1, tid = threadIdx.x;
     const int nt = d.nterms[o];
@@ -251,54 +251,63 @@ __global__ __launch_bounds__(256) void k_msm_window(MsmDesc d) {
     //    the low threads so idle waves skip the additions), then two 16-element weighted sums done by a
     //    suffix scan + tree on 32 threads, then 4 doublings.  ~19 wave-level point additions per block instead
     //    of the 64 of a 256-wide scan + tree.
+    //    All 21 levels run through ONE loop with a single inlined point addition (level = kind + stride):
+    //      kind 0 rows  : dst = 16 hi + 2 s k, src = dst + s          (ops = 128 / s)
+    //      kind 1 cols  : dst = 16 (2 s k) + lo, src = dst + 16 s     (ops = 128 / s)   on a fresh copy of the buckets
+    //      kind 2 scan  : suffix scan over the two 16-element vectors R (slots 0..15) and C (slots 16..31)
+    //      kind 3 tree  : tree sum of the two scanned vectors (slot 0 / 16 of each zeroed first)
     lds_store_jac(pts, tid, acc);
     __syncthreads();
-    for (int s = 1; s < 16; s <<= 1) {  // row trees: dst = 16 hi + 2 s k, src = dst + s
-        const int ops = 128 / s, per_row = 8 / s;
-        if (tid < ops) {
-            const int dst = 16 * (tid / per_row) + 2 * s * (tid % per_row);
-            lds_store_jac(pts, dst, g1_add(lds_load_jac(pts, dst), lds_load_jac(pts, dst + s)));
+    G1Jac keep = g1_identity();  // threads 0..15: R_tid, threads 16..31: C_(tid-16)
+#pragma unroll 1
+    for (int lvl = 0; lvl < 16; lvl++) {
+        const int kind = lvl >> 2, s = kind == 3 ? (8 >> (lvl & 3)) : (1 << (lvl & 3));
+        if (lvl == 4) {  // rows done: save R, restore the buckets for the column trees
+            if (tid < 16) keep = lds_load_jac(pts, 16 * tid);
+            __syncthreads();
+            lds_store_jac(pts, tid, acc);
+            __syncthreads();
+        } else if (lvl == 8) {  // columns done: lay out R | C for the scans
+            if (tid >= 16 && tid < 32) keep = lds_load_jac(pts, tid - 16);
+            __syncthreads();
+            if (tid < 32) lds_store_jac(pts, tid, keep);
+            __syncthreads();
+        } else if (lvl == 12) {  // scans done: S_0 is not part of sum_{k>=1} S_k
+            if (tid < 32 && (tid & 15) == 0) lds_store_jac(pts, tid, g1_identity());
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    G1Jac x = g1_identity();  // threads 0..15: R_tid, threads 16..31: C_(tid-16)
-    if (tid < 16) x = lds_load_jac(pts, 16 * tid);
-    __syncthreads();
-    lds_store_jac(pts, tid, acc);
-    __syncthreads();
-    for (int s = 1; s < 16; s <<= 1) {  // column trees: dst = 16 (2 s k) + lo, src = dst + 16 s
-        const int ops = 128 / s;
-        if (tid < ops) {
-            const int dst = 16 * (2 * s * (tid >> 4)) + (tid & 15);
-            lds_store_jac(pts, dst, g1_add(lds_load_jac(pts, dst), lds_load_jac(pts, dst + 16 * s)));
+        bool active;
+        int dst, src;
+        if (kind == 0) {
+            const int per_row = 8 / s;
+            active = tid < 128 / s;
+            dst = 16 * (tid / per_row) + 2 * s * (tid % per_row);
+            src = dst + s;
+        } else if (kind == 1) {
+            active = tid < 128 / s;
+            dst = 16 * (2 * s * (tid >> 4)) + (tid & 15);
+            src = dst + 16 * s;
+        } else if (kind == 2) {
+            active = tid < 32 && (tid & 15) + s < 16;
+            dst = tid;
+            src = tid + s;
+        } else {
+            active = tid < 32 && (tid & 15) < s;
+            dst = tid;
+            src = tid + s;
         }
-        __syncthreads();
-    }
-    if (tid >= 16 && tid < 32) x = lds_load_jac(pts, tid - 16);
-    __syncthreads();
-    // weighted sums sum_{k=1..15} k X_k for X = R (threads 0..15) and X = C (threads 16..31): suffix scan, then tree
-    const int idx = tid & 15;
-    if (tid < 32) lds_store_jac(pts, tid, x);
-    __syncthreads();
-    for (int s = 1; s < 16; s <<= 1) {
-        G1Jac other = g1_identity();
-        const bool has = tid < 32 && idx + s < 16;
-        if (has) other = lds_load_jac(pts, tid + s);
-        __syncthreads();
-        if (has) {
-            x = g1_add(x, other);
-            lds_store_jac(pts, tid, x);
+        G1Jac x = g1_identity(), y = g1_identity();
+        if (active) {
+            x = lds_load_jac(pts, dst);
+            y = lds_load_jac(pts, src);
         }
-        __syncthreads();
-    }
-    if (tid < 32 && idx == 0) lds_store_jac(pts, tid, g1_identity());  // S_0 is not part of the sum
-    __syncthreads();
-    for (int s = 8; s > 0; s >>= 1) {
-        if (tid < 32 && idx < s) lds_store_jac(pts, tid, g1_add(lds_load_jac(pts, tid), lds_load_jac(pts, tid + s)));
+        __syncthreads();  // scan levels read a slot that its owner rewrites in the same level
+        if (active) lds_store_jac(pts, dst, g1_add(x, y));
         __syncthreads();
     }
     if (tid == 0) {
         G1Jac r = lds_load_jac(pts, 0);  // sum hi * R_hi
+#pragma unroll 1
         for (int k = 0; k < 4; k++) r = g1_dbl(r);
         d.window_sums[wi] = g1_add(r, lds_load_jac(pts, 16));
     }
