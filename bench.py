@@ -31,7 +31,8 @@ BYTES_PER_BLOB = 131072
 ALG_BYTES = {
     "k_blob_challenge": BYTES_PER_BLOB + 48 + 32,   # blob + commitment read, z written       (per blob)
     "k_blob_evaluate": BYTES_PER_BLOB + 32 + 32,    # blob + z read, y written                (per blob)
-    "k_g1_decode+multiples": 2 * (48 + 96 + 4 + 4 * 144),  # two points per blob: bytes in, affine + flag + 4 multiples out
+    "k_g1_decode": 2 * (48 + 96 + 4),               # two points per blob: compressed in, affine + flag out
+    "k_g1_multiples": 2 * (96 + 4 * 144),           # two points per blob: affine in, 4 Jacobian multiples out
     "k_msm": 3 * 128,                               # three (point, scalar) terms per blob, 96 + 32 B each
     "k_slp_run(pairing)": 0,
 }
@@ -162,7 +163,7 @@ def main():
     idx0 = max(i for i in range(len(groups)) if i % n_handles == 0)
     g0 = groups[idx0][1]
     tm = settings.last_timings()
-    kernels = {"k_blob_challenge": tm[5], "k_blob_evaluate": tm[4], "k_g1_decode+multiples": tm[6], "k_msm": tm[2],
+    kernels = {"k_blob_challenge": tm[5], "k_blob_evaluate": tm[4], "k_g1_decode": tm[6], "k_g1_multiples": tm[7], "k_msm": tm[2],
                "k_slp_run(pairing)": tm[3]}
 
     # ---- strictly sequential single-batch steps (latency), same inputs
@@ -186,6 +187,15 @@ def main():
     dom = max(kernels, key=kernels.get)
     units = n * g0
     achieved = ALG_BYTES[dom] * units / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
+    # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot run inside
+    # this process): bytes per launch, scaled to this launch's unit count
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"].get(dom)
+        if pmc:
+            traffic = round(pmc["hbm_bytes_corrected"] * units / pmc["units"])
+    except Exception:
+        traffic = None
     out = {
         "metric": "blobs/sec verify_blob_kzg_proof_batch",
         "value": round(n * world * K / elapsed, 2),
@@ -206,11 +216,13 @@ def main():
                    "batches_per_launch_group": G, "groups_in_flight": F},
         "roofline": {"bound": "hbm", "kernel": dom, "units_per_launch": units, "launch_ms": round(kernels[dom], 4),
                      "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                     "traffic": None, "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 5)"},
+                     "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH x2 gfx950 correction)",
+                     "algorithmic_bytes_per_launch": ALG_BYTES[dom] * units,
+                     "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 5)"},
         "kernel_ms_per_launch_group": {k: round(v, 4) for k, v in kernels.items()},
         "single_batch": {"value": round(n * world * KS / seq_elapsed, 2), "unit": "blobs/s", "ms_per_step": round(seq_elapsed / KS * 1e3, 4),
                          "steps": KS, "kernel_ms": {"k_blob_challenge": round(seq_tm[5], 4), "k_blob_evaluate": round(seq_tm[4], 4),
-                                                     "k_g1_decode+multiples": round(seq_tm[6], 4), "k_msm": round(seq_tm[2], 4),
+                                                     "k_g1_decode": round(seq_tm[6], 4), "k_g1_multiples": round(seq_tm[7], 4), "k_msm": round(seq_tm[2], 4),
                                                      "k_slp_run(pairing)": round(seq_tm[3], 4)}},
     }
     if not args.no_cpu_baseline:

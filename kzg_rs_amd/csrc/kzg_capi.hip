@@ -369,7 +369,7 @@ struct KzgSettings {
     Fp* d_prep = nullptr;   // prepared lines: [tau]G2 then generator (2 * 408 Fp)
     DevProgram prep, verify;
     hipStream_t s1 = nullptr, s2 = nullptr;
-    hipEvent_t ev[10] = {};
+    hipEvent_t ev[12] = {};
     mutable std::mutex mu;
     mutable Workspace ws;
     mutable float timings[8] = {};
@@ -631,6 +631,7 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
     unsigned blocks = (unsigned)((2 * T + 63) / 64);
     hipLaunchKernelGGL(k_g1_decode, dim3(blocks), dim3(64), 0, s->s2, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, (int)T,
                        w.d_points, w.d_pflag, (int)(2 * T), 1);
+    HIPCHK(hipEventRecord(s->ev[10], s->s2));  // decode | multiples boundary
     hipLaunchKernelGGL(k_set_generator, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, (int)(2 * T));
     hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((2 * T + 1 + 63) / 64)), dim3(64), 0, s->s2, w.d_points, w.d_pflag, w.d_mult,
                        (int)(2 * T + 1), (int)(2 * T + 1));
@@ -696,7 +697,8 @@ static KzgRet phase1_wait_locked(uint8_t* records_out, uint8_t* bad_out, const K
     elapsed(&s->timings[1], s->ev[0], s->ev[1]);
     elapsed(&s->timings[4], s->ev[7], s->ev[8]);
     elapsed(&s->timings[5], s->ev[0], s->ev[7]);
-    elapsed(&s->timings[6], s->ev[5], s->ev[6]);
+    elapsed(&s->timings[6], s->ev[5], s->ev[10]);
+    elapsed(&s->timings[7], s->ev[10], s->ev[6]);
     uint8_t* h = w.h_buf;
     uint8_t *h_z = h, *h_y = h + 32 * T, *h_c = h + 64 * T, *h_p = h + 112 * T;
     uint32_t* h_status = reinterpret_cast<uint32_t*>(h + 160 * T);
