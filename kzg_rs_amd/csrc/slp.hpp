@@ -76,7 +76,7 @@ __device__ __forceinline__ void slp_exec(uint32_t* slots, const uint2 d, const S
 // step loop reads its descriptor from LDS one step ahead.  Dynamic LDS = slots | descriptor ring.
 constexpr int SLP_GROUP = 16;
 template <bool MULTI_WAVE>
-__global__ void k_slp_run(SlpProgram prog, const Fp* __restrict__ inputs, const Fp* __restrict__ settings_inputs,
+__global__ __launch_bounds__(MULTI_WAVE ? 256 : 64) void k_slp_run(SlpProgram prog, const Fp* __restrict__ inputs, const Fp* __restrict__ settings_inputs,
                           Fp* __restrict__ outputs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t slots[];
     const uint32_t tid = threadIdx.x, inst = blockIdx.x, lanes = prog.lanes, n_steps = prog.n_steps;
