@@ -72,6 +72,13 @@ KzgRet kzg_settings_tau_g2(const KzgSettings *s, uint8_t out[96]);
 /* KzgProof::verify_kzg_proof (src/kzg_proof.rs:353-397). */
 KzgRet kzg_verify_kzg_proof(bool *ok, const uint8_t commitment[48], const uint8_t z[32], const uint8_t y[32],
                             const uint8_t proof[48], const KzgSettings *s);
+/* KzgProof::verify_kzg_proof_batch (src/kzg_proof.rs:399-444): n (commitment, z, y, proof) tuples checked with one
+ * random linear combination (r from compute_r_powers, :291-348) and ONE pairing.  The reference takes decoded
+ * &[G1Affine] / &[Scalar]; across the C ABI they are n*48 compressed bytes and n*32 big-endian canonical bytes in
+ * HOST memory, decoded on the device with the same checks as Bytes48/Bytes32 decoding (:17-43) - an undecodable
+ * point or a non-canonical scalar is KZG_BADARGS.  n == 0 -> *ok = true (both sides are the identity). */
+KzgRet kzg_verify_kzg_proof_batch(bool *ok, const uint8_t *commitments, const uint8_t *zs, const uint8_t *ys,
+                                  const uint8_t *proofs, size_t n, const KzgSettings *s);
 /* KzgProof::verify_blob_kzg_proof (src/kzg_proof.rs:446-470). */
 KzgRet kzg_verify_blob_kzg_proof(bool *ok, const uint8_t *blob, const uint8_t commitment[48], const uint8_t proof[48],
                                  const KzgSettings *s);

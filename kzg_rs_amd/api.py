@@ -74,6 +74,7 @@ def lib():
         L.kzg_settings_root_of_unity.argtypes = [vp, sz, u8]
         L.kzg_settings_tau_g2.argtypes = [vp, u8]
         L.kzg_verify_kzg_proof.argtypes = [bp, u8, u8, u8, u8, vp]
+        L.kzg_verify_kzg_proof_batch.argtypes = [bp, u8, u8, u8, u8, sz, vp]
         L.kzg_verify_blob_kzg_proof.argtypes = [bp, u8, u8, u8, vp]
         L.kzg_verify_blob_kzg_proof_batch.argtypes = [bp, u8, u8, u8, sz, vp]
         L.kzg_verify_blob_kzg_proof_batch_device.argtypes = [bp, vp, vp, vp, sz, vp]
@@ -203,6 +204,21 @@ class KzgProof:
         ok = C.c_bool(False)
         _chk(lib().kzg_verify_kzg_proof(C.byref(ok), commitment_bytes.data, z_bytes.data, y_bytes.data, proof_bytes.data,
                                         kzg_settings._h))
+        return bool(ok.value)
+
+    @staticmethod
+    def verify_kzg_proof_batch(commitments, zs, ys, proofs, kzg_settings):
+        """src/kzg_proof.rs:399-444: n (commitment, z, y, proof) tuples, one random linear combination, one pairing.
+        The reference takes decoded &[G1Affine] / &[Scalar]; here they are Bytes48 / Bytes32 (big-endian, canonical)
+        and decoding (with the subgroup check) is part of the call.  Slices of unequal length index out of bounds in
+        the reference (a panic): IndexError here."""
+        n = len(commitments)
+        if len(zs) < n or len(ys) < n or len(proofs) < n:
+            raise IndexError("index out of bounds")
+        ok = C.c_bool(False)
+        _chk(lib().kzg_verify_kzg_proof_batch(
+            C.byref(ok), b"".join(c.data for c in commitments), b"".join(z.data for z in zs[:n]),
+            b"".join(y.data for y in ys[:n]), b"".join(p.data for p in proofs[:n]), n, kzg_settings._h))
         return bool(ok.value)
 
     @staticmethod

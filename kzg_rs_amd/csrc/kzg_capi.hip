@@ -802,14 +802,6 @@ static KzgRet finish_wait_locked(bool* ok /* B */, const KzgSettings* s) {
     return KZG_OK;
 }
 
-// pairing check on the (A, B) in ws.d_ab (single instance; used by verify_kzg_proof)
-static KzgRet run_tail(bool* ok, const KzgSettings* s, size_t n) {
-    KzgRet rc = run_msm(s, n, 1);
-    if (rc != KZG_OK) return rc;
-    if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;
-    return finish_wait_locked(ok, s);
-}
-
 static KzgRet batch_device_locked(bool* ok, const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n,
                                   const KzgSettings* s) {
     std::vector<uint8_t> records(160 * n);
@@ -932,32 +924,62 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof(bool* ok, const uint8_t* blob, const
     return kzg_verify_blob_kzg_proof_batch(ok, blob, commitment, proof, 1, s);
 }
 
+extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitments, const uint8_t* zs, const uint8_t* ys,
+                                             const uint8_t* proofs, size_t n, const KzgSettings* s);
 extern "C" KzgRet kzg_verify_kzg_proof(bool* ok, const uint8_t commitment[48], const uint8_t z[32], const uint8_t y[32],
                                        const uint8_t proof[48], const KzgSettings* s) {
-    if (!ok || !s || !commitment || !z || !y || !proof) return fail(KZG_BADARGS, "null argument");
-    // safe_scalar_affine_from_bytes (:27-43) for z then y, before the points (:360-383)
-    if (be_geq_r(z) || be_geq_r(y)) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    // src/kzg_proof.rs:353-397: the same equation as the batch form with the single scalar r^0 = 1:
+    // e(pi, [tau]G2) == e(C - [y]G + [z]pi, G2)  <=>  e(pi, [tau - z]G2) == e(C - [y]G, G2)
+    if (!commitment || !z || !y || !proof) return fail(KZG_BADARGS, "null argument");
+    return kzg_verify_kzg_proof_batch(ok, commitment, z, y, proof, 1, s);
+}
+
+// KzgProof::verify_kzg_proof_batch (src/kzg_proof.rs:399-444) over byte inputs: n (commitment, z, y, proof) tuples checked
+// with ONE random linear combination and ONE pairing.  Same pipeline as the blob batch minus challenge + evaluation.
+extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitments, const uint8_t* zs, const uint8_t* ys,
+                                             const uint8_t* proofs, size_t n, const KzgSettings* s) {
+    if (!ok || !s) return fail(KZG_BADARGS, "null argument");
+    if (n == 0) {  // compute_r_powers on an empty batch: both MSMs are the identity, e(O, .) == e(O, .)
+        *ok = true;
+        return KZG_OK;
+    }
+    if (!commitments || !zs || !ys || !proofs) return fail(KZG_BADARGS, "null argument");
+    for (size_t i = 0; i < n; i++)
+        if (be_geq_r(zs + 32 * i) || be_geq_r(ys + 32 * i)) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, 1, 1, true);
+    KzgRet rc = ws_reserve(s, n, 1, true);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
-    uint8_t le[64];
-    reverse32(le, z);
-    reverse32(le + 32, y);
-    HIPCHK(hipMemcpyAsync(w.d_z, le, 32, hipMemcpyHostToDevice, s->s1));
-    HIPCHK(hipMemcpyAsync(w.d_y, le + 32, 32, hipMemcpyHostToDevice, s->s1));
-    HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitment, 48, hipMemcpyHostToDevice, s->s1));
-    HIPCHK(hipMemcpyAsync(w.d_stage_cp + 48, proof, 48, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipEventRecord(s->ev[0], s->s1));
+    // z, y: big-endian -> the device's little-endian limb arrays (= the transcript's encoding)
+    std::vector<uint8_t> records(160 * n);
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* o = records.data() + 160 * i;
+        memcpy(o, commitments + 48 * i, 48);
+        reverse32(o + 48, zs + 32 * i);
+        reverse32(o + 80, ys + 32 * i);
+        memcpy(o + 112, proofs + 48 * i, 48);
+        memcpy(w.h_buf + 32 * i, o + 48, 32);
+        memcpy(w.h_buf + 32 * n + 32 * i, o + 80, 32);
+    }
+    HIPCHK(hipMemcpyAsync(w.d_z, w.h_buf, 32 * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(w.d_y, w.h_buf + 32 * n, 32 * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(w.d_stage_cp + 48 * n, proofs, 48 * n, hipMemcpyHostToDevice, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
-    if ((rc = launch_decode(s, w.d_stage_cp, w.d_stage_cp + 48, 1)) != KZG_OK) return rc;
-    uint32_t* h_pflag = reinterpret_cast<uint32_t*>(w.h_buf);
-    HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8, hipMemcpyDeviceToHost, s->s2));
+    if ((rc = launch_decode(s, w.d_stage_cp, w.d_stage_cp + 48 * n, n)) != KZG_OK) return rc;
+    uint32_t* h_pflag = reinterpret_cast<uint32_t*>(w.h_buf + 64 * n);
+    HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * n, hipMemcpyDeviceToHost, s->s2));
     HIPCHK(hipStreamSynchronize(s->s2));
-    if (h_pflag[0] == G1_INVALID || h_pflag[1] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
-    hipLaunchKernelGGL(k_single_scalars, dim3(1), dim3(64), 0, s->s1, w.d_z, w.d_y, w.d_scalars);
-    HIPCHK(hipGetLastError());
-    return run_tail(ok, s, 1);
+    for (size_t i = 0; i < 2 * n; i++)
+        if (h_pflag[i] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    w.pending_n = n;
+    w.pending_b = 1;
+    // n == 1: r^0 = 1 whatever the transcript hashes to, which is phase 2's n_total == 1 branch (scalars 1, z, -y)
+    if ((rc = phase2_launch_locked(records.data(), n, 0, s)) != KZG_OK) return rc;
+    if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;
+    return finish_wait_locked(ok, s);
 }
 
 // ---------------------------------------------------------------- pieces

@@ -53,3 +53,21 @@ def make_valid_batch(n, seed, settings=None, chunk=256):
         commitments += cs
         proofs += api.g1_mul_generator(qs, settings)
     return blobs, commitments, proofs, settings
+
+
+def make_valid_proofs(n, seed, settings=None):
+    """n valid (commitment, z, y, proof) tuples for verify_kzg_proof_batch under the synthetic setup: any scalars
+    a, z, y with C = [a]G and pi = [(a - y) / (tau - z)]G satisfy the KZG equation.  Returns lists of big-endian
+    bytes (48, 32, 32, 48) and the settings."""
+    tau, tau_g2 = synthetic_setup()
+    if settings is None:
+        settings = api.KzgSettings.from_tau_g2(tau_g2)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    raw = rng.integers(0, 256, size=(3, n, 32), dtype=np.uint8)
+    raw[:, :, 0] &= 0x3F
+    a, z, y = ([raw[k, i].tobytes() for i in range(n)] for k in range(3))
+    qs = []
+    for ai, zi, yi in zip(a, z, y):
+        q = (int.from_bytes(ai, "big") - int.from_bytes(yi, "big")) * pow(tau - int.from_bytes(zi, "big"), -1, R) % R
+        qs.append(q.to_bytes(32, "big"))
+    return api.g1_mul_generator(a, settings), z, y, api.g1_mul_generator(qs, settings), settings

@@ -349,11 +349,11 @@ static void *slice_run(void *arg) {
 static int verify_kzg_proof_batch(int *ok, const g1a_t *commitments, const uint8_t *cbytes, const fr_t *zs,
                                   const fr_t *ys, const g1a_t *proofs, const uint8_t *pbytes, size_t n,
                                   const oracle_settings *s, int be, uint8_t r_be[32], uint8_t A48[48], uint8_t B48[48]) {
-    fr_t r, *r_powers = (fr_t *)malloc(2 * n * sizeof(fr_t)), *r_times_z = r_powers + n;
-    g1a_t *c_minus_y = (g1a_t *)malloc(n * sizeof(g1a_t));
+    fr_t r, *r_powers = (fr_t *)malloc((2 * n + 1) * sizeof(fr_t)), *r_times_z = r_powers + n;
+    g1a_t *c_minus_y = (g1a_t *)malloc((n + 1) * sizeof(g1a_t));
     compute_r(&r, cbytes, zs, ys, pbytes, n, be);
     /* compute_powers :279-289 */
-    fr_one(&r_powers[0]);
+    if (n) fr_one(&r_powers[0]); /* :281-283: an empty batch has no powers */
     for (size_t i = 1; i < n; i++) fr_mul(&r_powers[i], &r_powers[i - 1], &r);
     g1_t proof_lincomb, proof_z_lincomb, c_minus_y_lincomb, rhs, gen, t, c;
     g1_msm(&proof_lincomb, proofs, r_powers, n); /* :419 */
@@ -433,6 +433,24 @@ int oracle_verify_blob_kzg_proof_batch(int *ok, const uint8_t *blobs, const uint
                                        int be) {
     return oracle_verify_blob_kzg_proof_batch_ex(ok, blobs, commitments, proofs, n, s, nthreads, be, NULL, NULL, NULL,
                                                  NULL, NULL);
+}
+
+/* src/kzg_proof.rs:399-444 with byte inputs: commitments/proofs compressed (decoded WITH the subgroup check, as the
+ * typed &[G1Affine] arguments of the reference can only hold valid points), zs/ys big-endian canonical. */
+int oracle_verify_kzg_proof_batch(int *ok, const uint8_t *commitments, const uint8_t *zs_be, const uint8_t *ys_be,
+                                  const uint8_t *proofs, size_t n, const oracle_settings *s, int be) {
+    bls_init();
+    int rc = ORACLE_OK;
+    g1a_t *cs = (g1a_t *)malloc((2 * n + 1) * sizeof(g1a_t)), *ps = cs + n;
+    fr_t *zs = (fr_t *)malloc((2 * n + 1) * sizeof(fr_t)), *ys = zs + n;
+    for (size_t i = 0; i < n && !rc; i++) {
+        if (fr_from_be_canonical(&zs[i], zs_be + 32 * i) || fr_from_be_canonical(&ys[i], ys_be + 32 * i)) rc = ORACLE_BADARGS;
+        else if (g1_decompress(&cs[i], commitments + 48 * i, 1) || g1_decompress(&ps[i], proofs + 48 * i, 1)) rc = ORACLE_BADARGS;
+    }
+    if (!rc) rc = verify_kzg_proof_batch(ok, cs, commitments, zs, ys, ps, proofs, n, s, be, NULL, NULL, NULL);
+    free(cs);
+    free(zs);
+    return rc;
 }
 
 int oracle_compute_challenge(uint8_t z_be[32], const uint8_t *blob, const uint8_t commitment[48]) {

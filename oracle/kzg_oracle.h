@@ -59,6 +59,10 @@ int oracle_verify_blob_kzg_proof_batch_ex(int *ok, const uint8_t *blobs, const u
                                           int nthreads, int be_transcript, uint8_t *zs, uint8_t *ys,
                                           uint8_t r_be[32], uint8_t A[48], uint8_t B[48]);
 
+/* src/kzg_proof.rs:399-444 (verify_kzg_proof_batch) over byte inputs */
+int oracle_verify_kzg_proof_batch(int *ok, const uint8_t *commitments, const uint8_t *zs_be, const uint8_t *ys_be,
+                                  const uint8_t *proofs, size_t n, const oracle_settings *s, int be_transcript);
+
 /* src/kzg_proof.rs:46-72: z (big-endian canonical) from blob + compressed commitment bytes */
 int oracle_compute_challenge(uint8_t z_be[32], const uint8_t *blob, const uint8_t commitment[48]);
 /* src/kzg_proof.rs:94-133 (blob parsed per src/dtypes.rs:48-57; z given as BE bytes reduced mod r,

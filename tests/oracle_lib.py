@@ -37,6 +37,7 @@ def lib():
         L.oracle_verify_blob_kzg_proof_batch.argtypes = [ip, u8p, u8p, u8p, sz, vp, C.c_int, C.c_int]
         L.oracle_verify_blob_kzg_proof_batch_ex.argtypes = [ip, u8p, u8p, u8p, sz, vp, C.c_int, C.c_int,
                                                             u8p, u8p, u8p, u8p, u8p]
+        L.oracle_verify_kzg_proof_batch.argtypes = [ip, u8p, u8p, u8p, u8p, sz, vp, C.c_int]
         L.oracle_compute_challenge.argtypes = [u8p, u8p, u8p]
         L.oracle_evaluate_polynomial_in_evaluation_form.argtypes = [u8p, u8p, u8p, vp]
         L.oracle_compute_r.argtypes = [u8p, u8p, u8p, u8p, u8p, sz, C.c_int]
@@ -131,6 +132,14 @@ def verify_blob_kzg_proof_batch_ex(blobs, cs, ps, s, nthreads=1, be=False):
     _chk(lib().oracle_verify_blob_kzg_proof_batch_ex(C.byref(ok), b"".join(blobs), b"".join(cs), b"".join(ps), n, s.h,
                                                      nthreads, int(be), zs, ys, r, A, B))
     return bool(ok.value), zs.raw, ys.raw, r.raw, A.raw, B.raw
+
+
+def verify_kzg_proof_batch(cs, zs, ys, ps, s, be=False):
+    """src/kzg_proof.rs:399-444 on lists of bytes."""
+    ok = C.c_int(0)
+    _chk(lib().oracle_verify_kzg_proof_batch(C.byref(ok), b"".join(cs), b"".join(zs), b"".join(ys), b"".join(ps), len(cs), s.h,
+                                             int(be)))
+    return bool(ok.value)
 
 
 def compute_challenge(blob, c):

@@ -18,7 +18,7 @@ def declared_symbols():
 
 def test_header_declares_the_reference_entry_points():
     syms = declared_symbols()
-    for s in ("kzg_verify_kzg_proof", "kzg_verify_blob_kzg_proof", "kzg_verify_blob_kzg_proof_batch",
+    for s in ("kzg_verify_kzg_proof", "kzg_verify_kzg_proof_batch", "kzg_verify_blob_kzg_proof", "kzg_verify_blob_kzg_proof_batch",
               "kzg_verify_blob_kzg_proof_batch_device", "kzg_settings_load_trusted_setup", "kzg_settings_free"):
         assert s in syms
 

@@ -57,6 +57,69 @@ def test_verify_kzg_proof(settings):
         assert _result(lambda: KzgProof.verify_kzg_proof(*args, settings)) == c["output"], c["name"]
 
 
+def test_verify_kzg_proof_batch_vectors(settings, osettings):
+    """verify_kzg_proof_batch (src/kzg_proof.rs:399-444) fed from the single-proof vectors: all the true ones as ONE
+    batch -> true; with any false one mixed in -> false; undecodable input -> Err.  Every case also against the oracle."""
+    good, bad, broken = [], [], []
+    for c in G.vectors()["verify_kzg_proof"]:
+        try:
+            t = (Bytes48.from_hex(c["commitment"]), Bytes32.from_hex(c["z"]), Bytes32.from_hex(c["y"]),
+                 Bytes48.from_hex(c["proof"]))
+        except KzgError:
+            continue
+        (good if c["output"] is True else bad if c["output"] is False else broken).append(t)
+    assert len(good) > 20 and len(bad) > 20 and len(broken) > 10
+
+    def both(ts):
+        cols = list(zip(*ts)) if ts else ([], [], [], [])
+        got = _result(lambda: KzgProof.verify_kzg_proof_batch(*[list(c) for c in cols], settings))
+        try:
+            want = O.verify_kzg_proof_batch(*[[x.data for x in c] for c in cols], osettings)
+        except O.OracleError:
+            want = None
+        assert got == want
+        return got
+
+    assert both(good) is True
+    assert both([]) is True
+    assert both(good[:1]) is True
+    for k in (0, len(bad) // 2, len(bad) - 1):
+        assert both(good[:7] + [bad[k]] + good[7:11]) is False
+        assert both([bad[k]]) is False
+    for k in range(0, len(broken), 3):
+        assert both(good[:3] + [broken[k]]) is None
+    with pytest.raises(IndexError):
+        KzgProof.verify_kzg_proof_batch([g[0] for g in good], [g[1] for g in good][:-1], [g[2] for g in good],
+                                        [g[3] for g in good], settings)
+
+
+@pytest.mark.parametrize("n", [2, 3, 65, 1000])
+def test_verify_kzg_proof_batch_synthetic(n):
+    """Seeded valid tuples under the known-tau setup; a changed y, a swapped pair of proofs and a swapped pair of z
+    must each flip the result.  Against the oracle where it finishes in seconds."""
+    from kzg_rs_amd import synth
+    cs, zs, ys, ps, st = synth.make_valid_proofs(n, seed=1000 + n)
+    ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])
+    wrap = lambda c, z, y, p: ([Bytes48(x) for x in c], [Bytes32(x) for x in z], [Bytes32(x) for x in y], [Bytes48(x) for x in p])
+
+    def both(c, z, y, p):
+        got = KzgProof.verify_kzg_proof_batch(*wrap(c, z, y, p), st)
+        if n <= 65:
+            assert got == O.verify_kzg_proof_batch(c, z, y, p, ost)
+        return got
+
+    assert both(cs, zs, ys, ps) is True
+    y2 = list(ys)
+    y2[n // 2] = ((int.from_bytes(ys[n // 2], "big") + 1) % R).to_bytes(32, "big")
+    assert both(cs, zs, y2, ps) is False
+    p2 = list(ps)
+    p2[0], p2[n - 1] = p2[n - 1], p2[0]
+    assert both(cs, zs, ys, p2) is False
+    z2 = list(zs)
+    z2[0], z2[1] = z2[1], z2[0]
+    assert both(cs, z2, ys, ps) is False
+
+
 def test_verify_blob_kzg_proof(settings):
     """src/kzg_proof.rs:654-680 over the 29 vectors."""
     for c in G.vectors()["verify_blob_kzg_proof"]:

@@ -58,6 +58,26 @@ def test_verify_kzg_proof_vectors(settings):
         _expect(lambda: O.verify_kzg_proof(*f, settings), c["output"])
 
 
+def test_verify_kzg_proof_batch_from_single_vectors(settings):
+    """verify_kzg_proof_batch (src/kzg_proof.rs:399-444) has no vector file of its own; it must agree with the
+    single-proof vectors: all true tuples as one batch -> true, any false tuple mixed in -> false, each tuple alone
+    as a 1-element batch -> its own expected output (r^0 = 1 makes the equations identical)."""
+    good, bad = [], []
+    for c in G.vectors()["verify_kzg_proof"]:
+        f = [bytes.fromhex(c[k]) for k in ("commitment", "z", "y", "proof")]
+        if [len(x) for x in f] != [48, 32, 32, 48]:
+            continue
+        _expect(lambda: O.verify_kzg_proof_batch(*[[x] for x in f], settings), c["output"])
+        if c["output"] is not None:
+            (good if c["output"] else bad).append(f)
+    assert len(good) == 54 and len(bad) == 48
+    cols = lambda ts: [list(c) for c in zip(*ts)]
+    assert O.verify_kzg_proof_batch(*cols(good), settings) is True
+    for b in bad[::5]:
+        assert O.verify_kzg_proof_batch(*cols(good[:9] + [b] + good[9:20]), settings) is False
+    assert O.verify_kzg_proof_batch([], [], [], [], settings) is True
+
+
 def test_verify_blob_kzg_proof_vectors(settings):
     cases = G.vectors()["verify_blob_kzg_proof"]
     assert len(cases) == 29
