@@ -129,88 +129,104 @@ __global__ __launch_bounds__(64) void k_blob_challenge(const uint8_t* __restrict
 // ---------------------------------------------------------------- challenge, producer / consumer form
 // Same result as k_blob_challenge.  The 2050-block SHA-256 chain of a blob is serial, and a wave that is alone
 // on its SIMD issues only one instruction every ~4-5 cycles, so what matters is the INSTRUCTION COUNT ON THE
-// CHAIN.  A workgroup of two waves serves 64 blobs: wave 1 (producer) loads the next 64-byte block, expands the
-// message schedule and adds the round constants (~580 instructions), and hands the 64 (K+W) words to wave 0
-// (consumer) through a double-buffered LDS tile; the consumer only runs the 64 rounds (~930 instructions per
-// block instead of ~1400).  The two waves sit on different SIMDs of the CU; one barrier per block.
+// CHAIN.  A PAIR of waves serves 64 blobs: the producer loads the next 64-byte block, expands the message
+// schedule and adds the round constants (~580 instructions), and hands the 64 (K+W) words to the consumer through
+// a double-buffered LDS tile; the consumer only runs the 64 rounds (~930 instructions per block instead of
+// ~1400).  One barrier per block.
+//
+// A workgroup holds PAIRS pairs: waves [0, PAIRS) consume, waves [PAIRS, 2 PAIRS) produce, pair p = waves p and
+// p + PAIRS.  The hardware deals a workgroup's waves round-robin over the CU's four SIMDs, so
+//   PAIRS = 1: the two waves of a pair sit on different SIMDs - the lowest latency for a single batch;
+//   PAIRS = 4: one workgroup fills a CU with exactly one consumer and one producer per SIMD.  With many small
+//              workgroups instead the placement is left to the dispatcher, which measured 2.3x slower at 4 per CU
+//              (consumers doubling up on a SIMD, and only ~60% of the workgroups resident at a time).
 __device__ __forceinline__ void bswap4(uint32_t* w, const uint4& q) {
     w[0] = __builtin_bswap32(q.x); w[1] = __builtin_bswap32(q.y); w[2] = __builtin_bswap32(q.z); w[3] = __builtin_bswap32(q.w);
 }
-__global__ __launch_bounds__(128) void k_blob_challenge_split(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
-                                                              Fr* __restrict__ z_out, int n) {
-    __shared__ uint4 tile[2][16][64];  // [buffer][round quad][lane]: 32 KiB, conflict-free b128 rows
+constexpr int CHALLENGE_TILE_U4 = 2 * 16 * 64;  // per pair: [buffer][round quad][lane] uint4 = 32 KiB, conflict-free b128 rows
+template <int PAIRS>
+__global__ __launch_bounds__(128 * PAIRS) void k_blob_challenge_split(const uint8_t* __restrict__ blobs,
+                                                                      const uint8_t* __restrict__ commitments,
+                                                                      Fr* __restrict__ z_out, int n) {
+    extern __shared__ uint4 challenge_tiles[];
     const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 consumer, 1 producer
-    int i = blockIdx.x * 64 + lane;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = wave / PAIRS, pair = wave % PAIRS;  // role 0 consumer, 1 producer
+    uint4* tile = challenge_tiles + pair * CHALLENGE_TILE_U4;
+    int i = (blockIdx.x * PAIRS + pair) * 64 + lane;
     const bool live = i < n;
     if (!live) i = n - 1;  // redundant work keeps the barriers uniform
-    const uint4* blob = reinterpret_cast<const uint4*>(blobs + (size_t)i * BLOB_BYTES);
-    const uint4* cm = reinterpret_cast<const uint4*>(commitments + (size_t)i * 48);
     constexpr int NBLK = 2050;
 
-    // producer state: raw 64 bytes of the next block to expand
-    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
-    auto fetch = [&](int b) {  // raw data of transcript block b (b >= 1); block 0 is special-cased
-        if (b < 2048) {
-            const uint4* p = blob + (4 * b - 2);
-            q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-        } else if (b == 2048) {
-            q0 = blob[8190]; q1 = blob[8191]; q2 = cm[0]; q3 = cm[1];
-        } else {
-            q0 = cm[2];
-        }
-    };
-    auto produce = [&](int b, int buf) {
-        uint32_t w[16];
-        if (b == 0) {
-            w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;  // "FSBLOBVERIFY_V1_"
-            w[4] = 0; w[5] = 0; w[6] = 0; w[7] = FE_PER_BLOB;
-            bswap4(w + 8, blob[0]);
-            bswap4(w + 12, blob[1]);
-        } else if (b < 2049) {
-            bswap4(w, q0); bswap4(w + 4, q1); bswap4(w + 8, q2); bswap4(w + 12, q3);
-        } else {
-            bswap4(w, q0);
-            w[4] = 0x80000000u;
+    // Both roles run NBLK + 1 barriers; each keeps its own loop so the register allocation of one role does not
+    // carry the other's live state.
+    if (role == 1) {
+        const uint4* blob = reinterpret_cast<const uint4*>(blobs + (size_t)i * BLOB_BYTES);
+        const uint4* cm = reinterpret_cast<const uint4*>(commitments + (size_t)i * 48);
+        uint4 q0 = blob[2], q1 = blob[3], q2 = blob[4], q3 = blob[5];  // raw bytes of transcript block 1
+#pragma unroll 1
+        for (int b = 0; b < NBLK; b++) {
+            uint32_t w[16];
+            if (b == 0) {
+                w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;  // "FSBLOBVERIFY_V1_"
+                w[4] = 0; w[5] = 0; w[6] = 0; w[7] = FE_PER_BLOB;
+                bswap4(w + 8, blob[0]);
+                bswap4(w + 12, blob[1]);
+            } else {
+                bswap4(w, q0);
+                if (b < 2049) {
+                    bswap4(w + 4, q1); bswap4(w + 8, q2); bswap4(w + 12, q3);
+                } else {  // commitment[32..48) + 0x80 pad + bit length
+                    w[4] = 0x80000000u;
 #pragma unroll
-            for (int k = 5; k < 15; k++) w[k] = 0;
-            w[15] = 131152u * 8u;
-        }
-        if (b + 1 < NBLK) fetch(b + 1);  // in flight while this block is expanded
-        uint32_t kw[64];
-        sha256_schedule_kw(kw, w);
+                    for (int k = 5; k < 15; k++) w[k] = 0;
+                    w[15] = 131152u * 8u;
+                }
+                // raw bytes of block b + 1, in flight while block b is expanded
+                if (b + 1 < 2048) {
+                    const uint4* p = blob + (4 * (b + 1) - 2);
+                    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+                } else if (b + 1 == 2048) {
+                    q0 = blob[8190]; q1 = blob[8191]; q2 = cm[0]; q3 = cm[1];
+                } else if (b + 1 == 2049) {
+                    q0 = cm[2];
+                }
+            }
+            uint32_t kw[64];
+            sha256_schedule_kw(kw, w);
+            uint4* dst = tile + (b & 1) * (16 * 64) + lane;
 #pragma unroll
-        for (int t = 0; t < 16; t++) tile[buf][t][lane] = make_uint4(kw[4 * t], kw[4 * t + 1], kw[4 * t + 2], kw[4 * t + 3]);
-    };
-
-    Sha256State st;
-    sha256_init(st);
-    if (role == 1) produce(0, 0);
-    __syncthreads();
-    for (int b = 0; b < NBLK; b++) {
-        if (role == 1) {
-            if (b + 1 < NBLK) produce(b + 1, (b + 1) & 1);
-        } else {
+            for (int t = 0; t < 16; t++) dst[t * 64] = make_uint4(kw[4 * t], kw[4 * t + 1], kw[4 * t + 2], kw[4 * t + 3]);
+            __syncthreads();  // block b is ready; the consumer is done with block b - 1, whose buffer block b + 1 reuses
+        }
+        __syncthreads();
+    } else {
+        Sha256State st;
+        sha256_init(st);
+        __syncthreads();
+#pragma unroll 1
+        for (int b = 0; b < NBLK; b++) {
             uint32_t a = st.h[0], bb = st.h[1], c = st.h[2], d = st.h[3], e = st.h[4], f = st.h[5], g = st.h[6], h = st.h[7];
             // issue all 16 LDS reads of the block at once (they pipeline), then run the rounds out of registers:
             // a just-in-time read every 4 rounds costs one LDS round trip per quad on the serial chain
+            const uint4* src = tile + (b & 1) * (16 * 64) + lane;
             uint4 kw[16];
 #pragma unroll
-            for (int t = 0; t < 16; t++) kw[t] = tile[b & 1][t][lane];
+            for (int t = 0; t < 16; t++) kw[t] = src[t * 64];
 #pragma unroll
             for (int t = 0; t < 16; t++) {
                 asm volatile("" : "+v"(kw[t].x), "+v"(kw[t].y), "+v"(kw[t].z), "+v"(kw[t].w));  // keep the reads hoisted
                 sha256_rounds4(a, bb, c, d, e, f, g, h, kw[t]);
             }
             st.h[0] += a; st.h[1] += bb; st.h[2] += c; st.h[3] += d; st.h[4] += e; st.h[5] += f; st.h[6] += g; st.h[7] += h;
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    if (role == 0 && live) {
-        Fr dgst;
+        if (live) {
+            Fr dgst;
 #pragma unroll
-        for (int k = 0; k < 8; k++) dgst.l[k] = st.h[7 - k];
-        z_out[i] = FrF::from_mont(FrF::to_mont(dgst));
+            for (int k = 0; k < 8; k++) dgst.l[k] = st.h[7 - k];
+            z_out[i] = FrF::from_mont(FrF::to_mont(dgst));
+        }
     }
 }
 

@@ -538,6 +538,29 @@ static bool challenge_split() {
     return v;
 }
 
+// The challenge kernel over T blobs on stream s1.  Producer/consumer pairs per workgroup: 1 while every pair can have
+// a CU of its own (T <= 64 * 256), else 4 = one workgroup fills a CU (fr_kernels.hpp); KZG_CHALLENGE_PAIRS overrides.
+static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const void* d_commitments, Fr* d_z, size_t T) {
+    static const int forced = [] {
+        const char* e = getenv("KZG_CHALLENGE_PAIRS");
+        return e ? atoi(e) : 0;
+    }();
+    const uint8_t *bl = (const uint8_t*)d_blobs, *cm = (const uint8_t*)d_commitments;
+    if (!challenge_split()) {
+        hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, s->s1, bl, cm, d_z, (int)T);
+    } else if (forced == 4 || (forced != 1 && T > 64 * 256)) {
+        constexpr int P = 4;
+        const int lds = P * CHALLENGE_TILE_U4 * (int)sizeof(uint4);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_challenge_split<P>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        hipLaunchKernelGGL(k_blob_challenge_split<P>, dim3((unsigned)((T + 64 * P - 1) / (64 * P))), dim3(128 * P), lds, s->s1, bl, cm, d_z, (int)T);
+    } else {
+        const int lds = CHALLENGE_TILE_U4 * (int)sizeof(uint4);
+        hipLaunchKernelGGL(k_blob_challenge_split<1>, dim3((unsigned)((T + 63) / 64)), dim3(128), lds, s->s1, bl, cm, d_z, (int)T);
+    }
+    HIPCHK(hipGetLastError());
+    return KZG_OK;
+}
+
 // Workspace for a launch group of B batches with T blobs in total (B = 1 for the single-call entry points).
 static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
     Workspace& w = s->ws;
@@ -659,12 +682,7 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
     if ((rc = launch_decode(s, d_commitments, d_proofs, T)) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[6], s->s2));
     HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * T, s->s1));
-    if (challenge_split())
-        hipLaunchKernelGGL(k_blob_challenge_split, dim3((unsigned)((T + 63) / 64)), dim3(128), 0, s->s1, (const uint8_t*)d_blobs,
-                           (const uint8_t*)d_commitments, w.d_z, (int)T);
-    else
-        hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, s->s1, (const uint8_t*)d_blobs,
-                           (const uint8_t*)d_commitments, w.d_z, (int)T);
+    if ((rc = launch_challenge(s, d_blobs, d_commitments, w.d_z, T)) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[7], s->s1));
     hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, w.d_z, s->d_M, s->d_DM, w.d_y,
                        w.d_status);
@@ -994,11 +1012,7 @@ extern "C" KzgRet kzg_compute_challenges(uint8_t* z_out, const uint8_t* blobs, c
     Workspace& w = s->ws;
     HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
     HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
-    if (challenge_split())
-        hipLaunchKernelGGL(k_blob_challenge_split, dim3((unsigned)((n + 63) / 64)), dim3(128), 0, s->s1, w.d_stage_blobs, w.d_stage_cp, w.d_z, (int)n);
-    else
-        hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_stage_blobs, w.d_stage_cp, w.d_z, (int)n);
-    HIPCHK(hipGetLastError());
+    if ((rc = launch_challenge(s, w.d_stage_blobs, w.d_stage_cp, w.d_z, n)) != KZG_OK) return rc;
     HIPCHK(hipMemcpyAsync(w.h_buf, w.d_z, 32 * n, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
     for (size_t i = 0; i < n; i++) reverse32(z_out + 32 * i, w.h_buf + 32 * i);
