@@ -192,6 +192,24 @@ __device__ inline bool g1_in_subgroup(const G1Aff& p) {
     return FpF::eq(q.x, fp_mul(bx, zz)) && FpF::eq(q.y, fp_neg(fp_mul(p.y, zzz)));
 }
 
+// The same test with its first [|x|] taken right-to-left, so that the doubling chain P, 2P, 4P, ... it walks ends in
+// [2^64]P - the multiple the MSM needs anyway (msm.hpp).  64 doublings + 5 additions, then [|x|] of the result
+// left-to-right as above.  p2_64 is valid whether or not the test passes.
+__device__ inline bool g1_in_subgroup_with_multiple(const G1Aff& p, G1Jac& p2_64) {
+    G1Jac r = g1_from_affine(p), q = r;  // q is overwritten at bit 16, the lowest set bit of |x|
+#pragma unroll 1
+    for (int i = 0; i < 64; i++) {
+        if ((BLS_X_ABS >> i) & 1) q = (i == 16) ? r : g1_add(q, r);
+        r = g1_dbl(r);
+    }
+    p2_64 = r;
+    q = g1_mul_xabs(q);
+    if (g1_is_identity(q)) return false;
+    Fp zz = fp_sqr(q.z), zzz = fp_mul(zz, q.z);
+    Fp bx = fp_mul(p.x, fp_const(consts::FP_BETA_MONT));
+    return FpF::eq(q.x, fp_mul(bx, zz)) && FpF::eq(q.y, fp_neg(fp_mul(p.y, zzz)));
+}
+
 enum : uint32_t { G1_OK = 0, G1_INFINITY = 1, G1_INVALID = 2 };
 
 // 48 compressed bytes -> affine (Montgomery).  Returns G1_OK / G1_INFINITY / G1_INVALID.

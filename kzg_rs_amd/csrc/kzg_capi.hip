@@ -111,6 +111,18 @@ __global__ void k_set_generator(G1Aff* __restrict__ points, uint32_t* __restrict
     pflag[idx] = 0;
 }
 
+// the generator and its precomputed multiples (gen_mult[4], made once per settings) as point `idx` of a workspace
+__global__ void k_set_generator_multiples(G1Aff* __restrict__ points, uint32_t* __restrict__ pflag, G1Jac* __restrict__ mult,
+                                          const G1Jac* __restrict__ gen_mult, int idx, int stride) {
+    if (threadIdx.x || blockIdx.x) return;
+    G1Aff g;
+    g.x = fp_const(consts::G1_GEN_X_MONT);
+    g.y = fp_const(consts::G1_GEN_Y_MONT);
+    points[idx] = g;
+    pflag[idx] = 0;
+    for (int j = 0; j < MSM_CHUNKS; j++) mult[(size_t)j * stride + idx] = gen_mult[j];
+}
+
 // plain msm: output 0 over terms (point t, scalar t)
 __global__ void k_plain_terms(uint32_t* __restrict__ term_point, uint32_t* __restrict__ term_scalar, int n) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -367,6 +379,7 @@ struct KzgSettings {
     Fr *d_M = nullptr, *d_DM = nullptr;
     Fp* d_tau4 = nullptr;   // [tau]G2 affine (x.c0 x.c1 y.c0 y.c1), Montgomery
     Fp* d_prep = nullptr;   // prepared lines: [tau]G2 then generator (2 * 408 Fp)
+    G1Jac* d_gen_mult = nullptr;  // G, 2^64 G, -phi(G), -phi(2^64 G)
     DevProgram prep, verify;
     hipStream_t s1 = nullptr, s2 = nullptr;
     hipEvent_t ev[12] = {};
@@ -447,6 +460,19 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
     HIPCHK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipMemcpyAsync(s->d_tau4, d_q, sizeof(Fp) * 4, hipMemcpyDeviceToDevice, s->s1));
     if ((rc = run_program(s->prep, d_q, nullptr, s->d_prep, 2, s->s1)) != KZG_OK) return rc;
+    {  // multiples of the generator (msm.hpp): the same for every batch
+        G1Aff* d_g;
+        uint32_t* d_gf;
+        HIPCHK(hipMalloc(&d_g, sizeof(G1Aff)));
+        HIPCHK(hipMalloc(&d_gf, 4));
+        HIPCHK(hipMalloc(&s->d_gen_mult, sizeof(G1Jac) * MSM_CHUNKS));
+        hipLaunchKernelGGL(k_set_generator, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, 0);
+        hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, s->d_gen_mult, 1, 1);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s->s1));
+        HIPCHK(hipFree(d_g));
+        HIPCHK(hipFree(d_gf));
+    }
     HIPCHK(hipStreamSynchronize(s->s1));
     HIPCHK(hipFree(d_bytes));
     HIPCHK(hipFree(d_flag));
@@ -518,7 +544,7 @@ static void ws_free(Workspace& w) {
 extern "C" void kzg_settings_free(KzgSettings* s) {
     if (!s) return;
     ws_free(s->ws);
-    void* ptrs[] = {s->d_M, s->d_DM, s->d_tau4, s->d_prep, s->prep.blob, s->verify.blob};
+    void* ptrs[] = {s->d_M, s->d_DM, s->d_tau4, s->d_prep, s->d_gen_mult, s->prep.blob, s->verify.blob};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : s->ev)
@@ -617,6 +643,18 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
     return KZG_OK;
 }
 
+// (window, chunk) blocks of the MSM: separate while the launch has few batches (latency), merged per window once the
+// batch dimension alone fills the chip (msm.hpp MsmDesc::chunks_per_block); KZG_MSM_CPB = 1 | 2 | 4 overrides.
+static int msm_chunks_per_block(size_t B) {
+    static const int forced = [] {
+        const char* e = getenv("KZG_MSM_CPB");
+        int v = e ? atoi(e) : 0;
+        return (v == 1 || v == 2 || v == 4) ? v : 0;
+    }();
+    if (forced) return forced;
+    return B >= 32 ? 4 : B >= 16 ? 2 : 1;
+}
+
 // ---------------------------------------------------------------- the tail: MSM + pairing
 // Group of B batches of n blobs (T = B n).  scalars of batch b at b(2n+1): a [0,n), b [n,2n), g at 2n;
 // points: C [0,T), pi [T,2T), G at 2T, multiples with stride 2T+1.  Leaves (A, B) of batch b in ws.d_ab[2b..].
@@ -637,27 +675,28 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     d.nterms[1] = (int)(2 * n + 1);
     d.max_terms = mt;
     d.stride = 2 * T + 1;
+    d.chunks_per_block = msm_chunks_per_block(B);
+    const unsigned slots = MSM_CHUNKS / d.chunks_per_block;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     const int nsc = (int)(B * (2 * n + 1));
     hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc);
-    hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, (unsigned)(2 * B)), dim3(256), 0, s->s1, d);
-    hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(2 * B)), dim3(64), 0, s->s1, w.d_window, w.d_ab);
+    hipLaunchKernelGGL(k_msm_window, dim3(8, slots, (unsigned)(2 * B)), dim3(256), 0, s->s1, d);
+    hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(2 * B)), dim3(64), 0, s->s1, w.d_window, w.d_ab, (int)slots);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
     return KZG_OK;
 }
 
-// decode 2T points (all C then all pi) into ws.d_points / d_pflag, generator as point 2T, then the 2^(64j)
-// multiples of all 2T+1 points - all on stream s2, beside the SHA-256 chain
+// decode 2T points (all C then all pi) into ws.d_points / d_pflag together with their 2^(64j) multiples, generator
+// (precomputed multiples) as point 2T - all on stream s2, beside the SHA-256 chain
 static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, const void* d_proofs, size_t T) {
     Workspace& w = s->ws;
+    const int np = (int)(2 * T + 1);
     unsigned blocks = (unsigned)((2 * T + 63) / 64);
-    hipLaunchKernelGGL(k_g1_decode, dim3(blocks), dim3(64), 0, s->s2, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, (int)T,
-                       w.d_points, w.d_pflag, (int)(2 * T), 1);
-    HIPCHK(hipEventRecord(s->ev[10], s->s2));  // decode | multiples boundary
-    hipLaunchKernelGGL(k_set_generator, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, (int)(2 * T));
-    hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((2 * T + 1 + 63) / 64)), dim3(64), 0, s->s2, w.d_points, w.d_pflag, w.d_mult,
-                       (int)(2 * T + 1), (int)(2 * T + 1));
+    hipLaunchKernelGGL(k_g1_decode_multiples, dim3(blocks), dim3(64), 0, s->s2, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs,
+                       (int)T, w.d_points, w.d_pflag, w.d_mult, (int)(2 * T), np);
+    HIPCHK(hipEventRecord(s->ev[10], s->s2));
+    hipLaunchKernelGGL(k_set_generator_multiples, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, w.d_mult, s->d_gen_mult, (int)(2 * T), np);
     HIPCHK(hipGetLastError());
     return KZG_OK;
 }
@@ -1137,9 +1176,10 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     d.nterms[1] = 0;
     d.max_terms = mt;
     d.stride = mt;
+    d.chunks_per_block = 1;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, 1), dim3(256), 0, s->s1, d);
-    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, w.d_window, w.d_ab);
+    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, w.d_window, w.d_ab, MSM_CHUNKS);
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
     hipLaunchKernelGGL(k_jac_compress, dim3(1), dim3(64), 0, s->s1, w.d_ab, w.d_bytes, 1);
     HIPCHK(hipGetLastError());

@@ -107,6 +107,35 @@ __global__ __launch_bounds__(64, 4) void k_g1_multiples(const G1Aff* __restrict_
     mult[(size_t)3 * stride + i] = g1_neg_phi(acc);
 }
 
+// Decode + subgroup check + multiples in one pass: the subgroup test's first scalar multiplication walks the same
+// doubling chain that produces 2^64 P (g1.hpp g1_in_subgroup_with_multiple), which saves the 64 doublings of a
+// separate k_g1_multiples pass.  bytes0 holds points [0, n0), bytes1 points [n0, n).
+__global__ __launch_bounds__(64) void k_g1_decode_multiples(const uint8_t* __restrict__ bytes0, const uint8_t* __restrict__ bytes1,
+                                                            int n0, G1Aff* __restrict__ points, uint32_t* __restrict__ pflag,
+                                                            G1Jac* __restrict__ mult, int n, int stride) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* src = i < n0 ? bytes0 + (size_t)i * 48 : bytes1 + (size_t)(i - n0) * 48;
+    G1Aff a;
+    uint32_t st = g1_decompress(a, src, false);
+    G1Jac p = g1_identity(), m = p;
+    if (st == G1_OK) {
+        p = g1_from_affine(a);
+        if (!g1_in_subgroup_with_multiple(a, m)) st = G1_INVALID;
+    }
+    if (st != G1_OK) {
+        a.x = FpF::zero();
+        a.y = FpF::zero();
+        p = m = g1_identity();
+    }
+    points[i] = a;
+    pflag[i] = st;
+    mult[i] = p;
+    mult[(size_t)2 * stride + i] = g1_neg_phi(p);
+    mult[(size_t)stride + i] = m;
+    mult[(size_t)3 * stride + i] = g1_neg_phi(m);
+}
+
 // in place: canonical k (< r) -> k1 (limbs 0..3) | k2 (limbs 4..7) with k = k1 + k2 * x^2.
 // Barrett with M = floor(2^383 / x^2): the quotient estimate is low by at most 1 for k < 2^255.
 __global__ __launch_bounds__(256) void k_glv_split(Fr* __restrict__ scalars, int count) {
@@ -178,6 +207,9 @@ struct MsmDesc {
     int nterms[2];
     int max_terms;
     int stride;
+    int chunks_per_block;         // 1: a block per (window, chunk) - most parallel, lowest latency;  4: a block per window
+                                  // sums the four chunks' terms into ONE bucket set - a quarter of the reductions and
+                                  // fuller, better balanced buckets (throughput mode).  gridDim.y = 4 / chunks_per_block
 };
 
 __device__ __forceinline__ void lds_store_jac(uint32_t* base, int slot, const G1Jac& p) {
@@ -201,28 +233,30 @@ __device__ __forceinline__ G1Jac lds_load_jac(const uint32_t* base, int slot) {
     return p;
 }
 
-// grid (8 windows, 4 chunks, 2 outputs x batches), 256 threads: block (w, j, o) handles digit byte 8j + w of every
-// scalar of output o, against the multiples 2^(64j) P.
+// grid (8 windows, 4 / chunks_per_block, 2 outputs x batches), 256 threads: block (w, g, o) handles digit byte 8j + w
+// of every scalar of output o for its chunks j, against the multiples 2^(64j) P.
 __global__ __launch_bounds__(256, 3) void k_msm_window(MsmDesc d) {
     // blockIdx.z = 2*batch + output
-    const int w = blockIdx.x, j = blockIdx.y, bo = blockIdx.z, o = bo & 1, tid = threadIdx.x;
+    const int w = blockIdx.x, bo = blockIdx.z, o = bo & 1, tid = threadIdx.x;
+    const int cpb = d.chunks_per_block, j0 = blockIdx.y * cpb;
     const int nt = d.nterms[o];
-    const int wi = (bo * MSM_CHUNKS + j) * 8 + w;  // window slot
+    const int wi = (bo * gridDim.y + blockIdx.y) * 8 + w;  // window slot
     const uint32_t* tp = d.term_point + (size_t)bo * d.max_terms;
     const uint32_t* tsc = d.term_scalar + (size_t)bo * d.max_terms;
-    uint32_t* sorted = d.sorted + (size_t)wi * d.max_terms;
-    const G1Jac* pts_j = d.mult + (size_t)j * d.stride;
+    uint32_t* sorted = d.sorted + (size_t)wi * cpb * d.max_terms;
     __shared__ uint32_t cnt[MSM_BUCKETS], off[MSM_BUCKETS + 1], cur[MSM_BUCKETS];
     __shared__ uint32_t pts[MSM_BUCKETS * 36];  // 36 KiB: one Jacobian point per thread
     cnt[tid] = 0;
     cur[tid] = 0;
     __syncthreads();
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(d.scalars);
-    const int byte = 8 * j + w;
-    // 1. counting sort by digit
-    for (int t = tid; t < nt; t += 256) {
-        uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
-        atomicAdd(&cnt[dig], 1u);
+    // 1. counting sort by digit of the cpb * nt (chunk, term) pairs; entry = chunk << 30 | point index
+    for (int c = 0; c < cpb; c++) {
+        const int byte = 8 * (j0 + c) + w;
+        for (int t = tid; t < nt; t += 256) {
+            uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
+            atomicAdd(&cnt[dig], 1u);
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -234,17 +268,23 @@ __global__ __launch_bounds__(256, 3) void k_msm_window(MsmDesc d) {
         off[MSM_BUCKETS] = s;
     }
     __syncthreads();
-    for (int t = tid; t < nt; t += 256) {
-        uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
-        uint32_t pos = atomicAdd(&cur[dig], 1u);
-        sorted[off[dig] + pos] = tp[t];
+    for (int c = 0; c < cpb; c++) {
+        const int byte = 8 * (j0 + c) + w;
+        for (int t = tid; t < nt; t += 256) {
+            uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
+            uint32_t pos = atomicAdd(&cur[dig], 1u);
+            sorted[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << 30;
+        }
     }
     __threadfence_block();
     __syncthreads();
     // 2. bucket tid (digit 0 contributes nothing)
     G1Jac acc = g1_identity();
     if (tid > 0) {
-        for (uint32_t k = off[tid]; k < off[tid + 1]; k++) acc = g1_add(acc, pts_j[sorted[k]]);
+        for (uint32_t k = off[tid]; k < off[tid + 1]; k++) {
+            const uint32_t e = sorted[k];
+            acc = g1_add(acc, d.mult[(size_t)(e >> 30) * d.stride + (e & 0x3FFFFFFFu)]);
+        }
     }
     // 3. sum_b b*B_b with b = 16 hi + lo:   16 * sum_hi hi*R_hi + sum_lo lo*C_lo,
     //    R_hi = row sums, C_lo = column sums of the 16 x 16 bucket matrix.  Two 4-level trees (ops packed into
@@ -313,13 +353,13 @@ __global__ __launch_bounds__(256, 3) void k_msm_window(MsmDesc d) {
     }
 }
 
-// out[o] = sum_w 2^(8w) (sum_j W[o][j][w]): 8 threads fold the chunks, then one Horner chain of 56 doublings
-__global__ __launch_bounds__(64) void k_msm_combine(const G1Jac* __restrict__ window_sums, G1Jac* __restrict__ out) {
+// out[o] = sum_w 2^(8w) (sum_g W[o][g][w]): 8 threads fold the nslots chunk groups, then one Horner chain of 56 doublings
+__global__ __launch_bounds__(64) void k_msm_combine(const G1Jac* __restrict__ window_sums, G1Jac* __restrict__ out, int nslots) {
     const int o = blockIdx.x, tid = threadIdx.x;
     __shared__ uint32_t pts[8 * 36];
     if (tid < 8) {
-        G1Jac s = window_sums[(o * MSM_CHUNKS + 0) * 8 + tid];
-        for (int j = 1; j < MSM_CHUNKS; j++) s = g1_add(s, window_sums[(o * MSM_CHUNKS + j) * 8 + tid]);
+        G1Jac s = window_sums[(o * nslots + 0) * 8 + tid];
+        for (int j = 1; j < nslots; j++) s = g1_add(s, window_sums[(o * nslots + j) * 8 + tid]);
         lds_store_jac(pts, tid, s);
     }
     __syncthreads();
