@@ -10,14 +10,16 @@
 // their common denominator cancels the (z^4096 - 1) factor and leaves
 //        y = (1/4096) * N,   N = sum_i p_i w_i prod_{j != i} (z - w_j),
 // an identity of polynomials in z - so it is also correct at z = w_i (the reference's early
-// return :109-111) and needs no inversion and no special case.  N is built by a binary tree over
-// the bit-reversed index order: a block of 2^L consecutive indices k*2^L.. is a coset whose
-// denominator is  D_{L,k} = z^(2^L) - roots[k]  (the first 2^(12-L) roots of the SAME table), so
-//        N_{L+1,k} = Z_L (N_{L,2k} + N_{L,2k+1}) + roots[2k] (N_{L,2k} - N_{L,2k+1}),  Z_L = z^(2^L)
-// (2 multiplications per merge), and the first level folds the leaf products:
-//        N_{1,k} = roots[2k] z (p_2k - p_2k+1) + roots[k] (p_2k + p_2k+1)       (3 per pair).
-// Total 3*2048 + 2*2047 + 12 = 10 250 Fr multiplications per blob instead of ~20 480 + an
-// inversion + a 256-step pow; the result is the same field element, bit for bit.
+// return :109-111) and needs no inversion and no special case.  With  w_i/(z - w_i) = z/(z - w_i) - 1
+// the w_i factor leaves the sum:
+//        N = z * N0 - (z^4096 - 1) * S,   N0 = sum_i p_i prod_{j != i} (z - w_j),   S = sum_i p_i.
+// N0 is built by a binary tree over the bit-reversed index order: a block of 2^L consecutive
+// indices k*2^L.. is a coset whose denominator is  D_{L,k} = z^(2^L) - roots[k]  (the first
+// 2^(12-L) roots of the SAME table, and roots[2k+1] = -roots[2k]), so
+//        N0_{L+1,k} = Z_L (N0_{L,2k} + N0_{L,2k+1}) + roots[2k] (N0_{L,2k} - N0_{L,2k+1}),  Z_L = z^(2^L),
+// from the leaves N0_{0,i} = p_i: 2 multiplications per merge, 2*4095 + 12 (powers of z) + 5 = 8 207
+// Fr multiplications per blob instead of ~20 480 + an inversion + a 256-step pow; the result is the
+// same field element, bit for bit.
 //
 // Mapping: ONE WAVEFRONT PER BLOB.  Lane t owns the 64 consecutive elements 64t..64t+63
 // (2 KiB of the blob), folds them depth-first with a 6-entry LDS stack (levels 1..6), then the
@@ -246,11 +248,15 @@ __global__ __launch_bounds__(64, 4) void k_blob_evaluate(const uint8_t* __restri
                                                       Fr* __restrict__ y_out, uint32_t* __restrict__ status) {
     const int blob_idx = blockIdx.x;
     const int lane = threadIdx.x;
-    __shared__ Fr Z[13];              // Z[L] = z^(2^L), Montgomery
+    __shared__ Fr Z[14];              // Z[L] = z^(2^L), Montgomery; Z[13] = z R^2 (takes plain operands)
     __shared__ uint4 stack[6][2][64]; // levels 1..6, two 16-byte halves, lane-major: conflict-free b128
     if (lane == 0) {
         Fr z = FrF::to_mont(z_in[blob_idx]);
+        Fr r2;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r2.l[i] = consts::FR_R2[i];
         Z[0] = z;
+        Z[13] = FrF::mul(z, r2);
         for (int l = 1; l <= 12; l++) {
             z = FrF::sqr(z);
             Z[l] = z;
@@ -258,17 +264,17 @@ __global__ __launch_bounds__(64, 4) void k_blob_evaluate(const uint8_t* __restri
     }
     __syncthreads();
     const uint4* src = reinterpret_cast<const uint4*>(blobs + (size_t)blob_idx * BLOB_BYTES) + (size_t)lane * 128;
-    const Fr z0 = Z[0];
+    const Fr zd = Z[13];
     bool bad = false;
-    Fr n;
+    Fr n, psum = FrF::zero();  // psum: this lane's share of S = sum_i p_i (plain)
     for (int q = 0; q < 32; q++) {
         uint4 a_hi = src[4 * q], a_lo = src[4 * q + 1], b_hi = src[4 * q + 2], b_lo = src[4 * q + 3];
         Fr pa = fr_from_be_words(a_hi, a_lo), pb = fr_from_be_words(b_hi, b_lo);
         bad |= FrF::geq_mod(pa) | FrF::geq_mod(pb);
         Fr u = FrF::sub(pa, pb), s = FrF::add(pa, pb);
         int k = 32 * lane + q;  // level-1 node index
-        Fr t = FrF::mul(z0, u);  // plain z*u
-        n = FrF::add(FrF::mul(DM[2 * k], t), FrF::mul(DM[k], s));
+        psum = FrF::add(psum, s);
+        n = FrF::add(FrF::mul(zd, s), FrF::mul(DM[2 * k], u));  // z s + roots[2k] u, Montgomery
         int level = 1;
         for (int qq = q; qq & 1; qq >>= 1) {
             Fr na;
@@ -300,12 +306,16 @@ __global__ __launch_bounds__(64, 4) void k_blob_evaluate(const uint8_t* __restri
         Fr sum = FrF::add(na, nb), dif = FrF::sub(na, nb);
         n = FrF::add(FrF::mul(Z[L], sum), FrF::mul(M[j & ~1], dif));
     }
+    for (int sh = 1; sh < 64; sh <<= 1) psum = FrF::add(psum, fr_shfl_xor(psum, sh));
     unsigned long long any_bad = __ballot(bad);
     if (lane == 0) {
         Fr inv;
 #pragma unroll
         for (int i = 0; i < 8; i++) inv.l[i] = consts::FR_INV4096_PLAIN[i];
-        y_out[blob_idx] = FrF::mul(n, inv);  // (N R)(1/4096) R^-1 = N/4096, plain
+        // N = z N0 - (z^4096 - 1) S;  mul(Z[13], S) = z S R, so (z^4096 - 1) S R = Z_12 S R - S R with S R = to_mont(S)
+        Fr sm = FrF::to_mont(psum);
+        Fr nn = FrF::sub(FrF::mul(n, Z[0]), FrF::sub(FrF::mul(Z[12], sm), sm));
+        y_out[blob_idx] = FrF::mul(nn, inv);  // (N R)(1/4096) R^-1 = N/4096, plain
         if (any_bad) atomicOr(&status[blob_idx], 1u);
     }
 }
