@@ -27,6 +27,7 @@
 // publishes the powers of z.
 #pragma once
 #include "field.hpp"
+#include "fr29.hpp"
 #include "sha256.hpp"
 
 namespace kzg {
@@ -243,7 +244,7 @@ __device__ __forceinline__ Fr fr_shfl_xor(const Fr& a, int mask) {
 // z_in: plain little-endian limbs (any value < 2^256; reduced mod r here, like scalar_from_bytes_unchecked)
 // y_out: plain little-endian canonical limbs.  status[b] |= 1 when a blob element is >= r
 // (src/kzg_proof.rs:36-41 -> KzgError::BadArgs).
-__global__ __launch_bounds__(64, 4) void k_blob_evaluate(const uint8_t* __restrict__ blobs, const Fr* __restrict__ z_in,
+__global__ __launch_bounds__(64, 4) void k_blob_evaluate32(const uint8_t* __restrict__ blobs, const Fr* __restrict__ z_in,
                                                       const Fr* __restrict__ M, const Fr* __restrict__ DM,
                                                       Fr* __restrict__ y_out, uint32_t* __restrict__ status) {
     const int blob_idx = blockIdx.x;
@@ -316,6 +317,133 @@ __global__ __launch_bounds__(64, 4) void k_blob_evaluate(const uint8_t* __restri
         Fr sm = FrF::to_mont(psum);
         Fr nn = FrF::sub(FrF::mul(n, Z[0]), FrF::sub(FrF::mul(Z[12], sm), sm));
         y_out[blob_idx] = FrF::mul(nn, inv);  // (N R)(1/4096) R^-1 = N/4096, plain
+        if (any_bad) atomicOr(&status[blob_idx], 1u);
+    }
+}
+
+// ---------------------------------------------------------------- evaluation in radix 2^29 (fr29.hpp)
+// The same tree as k_blob_evaluate32 with every field element in 9 x 29-bit limbs: products accumulate a whole
+// column in one 64-bit register without carry instructions, additions are limb-wise and nothing is reduced inside
+// the tree (value and limb bounds: fr29.hpp).  ~0.6x the VALU cycles of the 8x32 form.
+struct alignas(16) Fr29Mem {  // table entry: 9 limbs padded to 48 bytes (two b128 loads + one b32)
+    uint32_t l[12];
+};
+__device__ __forceinline__ Fr29 fr29_load(const Fr29Mem* p) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p->l), b = *reinterpret_cast<const uint4*>(p->l + 4);
+    Fr29 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = p->l[8];
+    return r;
+}
+__device__ __forceinline__ Fr29 fr29_shfl_xor(const Fr29& a, int mask) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = __shfl_xor((int)a.l[i], mask, 64);
+    return r;
+}
+// M29[j] = roots[j] R' , DM29[j] = roots[j] R'^2  (R' = 2^261; values below 2r, limbs below 2^29), from the 8x32 table M
+__global__ void k_roots_tables29(const Fr* __restrict__ M, Fr29Mem* __restrict__ M29, Fr29Mem* __restrict__ DM29) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= FE_PER_BLOB) return;
+    Fr w = FrF::from_mont(M[j]);
+    const Fr29 r2 = fr29_const(c29::FR29_R2);
+    Fr29 m = fr29_mul(fr29_from_words(w.l), r2), dm = fr29_mul(m, r2);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        M29[j].l[i] = i < 9 ? m.l[i] : 0u;
+        DM29[j].l[i] = i < 9 ? dm.l[i] : 0u;
+    }
+}
+
+// z_in: plain little-endian limbs (any value < 2^256; reduced mod r here, like scalar_from_bytes_unchecked)
+// y_out: plain little-endian canonical limbs.  status[b] |= 1 when a blob element is >= r
+// (src/kzg_proof.rs:36-41 -> KzgError::BadArgs).
+__global__ __launch_bounds__(64, 3) void k_blob_evaluate(const uint8_t* __restrict__ blobs, const Fr* __restrict__ z_in,
+                                                      const Fr29Mem* __restrict__ M, const Fr29Mem* __restrict__ DM,
+                                                      Fr* __restrict__ y_out, uint32_t* __restrict__ status) {
+    const int blob_idx = blockIdx.x;
+    const int lane = threadIdx.x;
+    __shared__ Fr29 Z[14];              // Z[L] = z^(2^L) R'; Z[13] = z R'^2 (takes plain operands)
+    __shared__ uint4 stack_a[6][64], stack_b[6][64];  // levels 1..6, limbs 0..3 / 4..7, lane-major: conflict-free b128
+    __shared__ uint32_t stack_c[6][64];                // limb 8
+    if (lane == 0) {
+        const Fr zin = z_in[blob_idx];
+        const Fr29 r2 = fr29_const(c29::FR29_R2);
+        Fr29 z = fr29_mul(fr29_from_words(zin.l), r2);  // any z < 2^256 < 2.3 r
+        Z[0] = z;
+        Z[13] = fr29_mul(z, r2);
+        for (int l = 1; l <= 12; l++) {
+            z = fr29_mul(z, z);
+            Z[l] = z;
+        }
+    }
+    __syncthreads();
+    const uint4* src = reinterpret_cast<const uint4*>(blobs + (size_t)blob_idx * BLOB_BYTES) + (size_t)lane * 128;
+    const Fr29 zd = Z[13];
+    bool bad = false;
+    Fr29 n, psum;  // psum: this lane's share of S = sum_i p_i (plain integer, < 64 r)
+#pragma unroll
+    for (int i = 0; i < 9; i++) psum.l[i] = 0;
+    for (int q = 0; q < 32; q++) {
+        uint4 a_hi = src[4 * q], a_lo = src[4 * q + 1], b_hi = src[4 * q + 2], b_lo = src[4 * q + 3];
+        Fr wa = fr_from_be_words(a_hi, a_lo), wb = fr_from_be_words(b_hi, b_lo);
+        bad |= FrF::geq_mod(wa) | FrF::geq_mod(wb);
+        const Fr29 pa = fr29_from_words(wa.l), pb = fr29_from_words(wb.l);
+        const Fr29 s = fr29_add(pa, pb), u = fr29_sub_biased(pa, pb);
+        int k = 32 * lane + q;  // level-1 node index
+        psum = fr29_add(psum, s);
+        if (q & 1) psum = fr29_normalize(psum);  // limbs: 2^29 + 2 * 2^30 < 2^32 between normalisations
+        n = fr29_add(fr29_mul(s, zd), fr29_mul(u, fr29_load(DM + 2 * k)));  // z s + roots[2k] u
+        int level = 1;
+        for (int qq = q; qq & 1; qq >>= 1) {
+            Fr29 na;
+            const uint4 h0 = stack_a[level - 1][lane], h1 = stack_b[level - 1][lane];
+            na.l[0] = h0.x; na.l[1] = h0.y; na.l[2] = h0.z; na.l[3] = h0.w;
+            na.l[4] = h1.x; na.l[5] = h1.y; na.l[6] = h1.z; na.l[7] = h1.w;
+            na.l[8] = stack_c[level - 1][lane];
+            const Fr29 sum = fr29_add(na, n), dif = fr29_sub_biased(na, n);
+            n = fr29_add(fr29_mul(sum, Z[level]), fr29_mul(dif, fr29_load(M + (k & ~1))));
+            k >>= 1;
+            level++;
+        }
+        if (level <= 6 && q != 31) {
+            stack_a[level - 1][lane] = make_uint4(n.l[0], n.l[1], n.l[2], n.l[3]);
+            stack_b[level - 1][lane] = make_uint4(n.l[4], n.l[5], n.l[6], n.l[7]);
+            stack_c[level - 1][lane] = n.l[8];
+        }
+    }
+    // n = N0_{6,lane}; fold across lanes
+    for (int L = 6; L < 12; L++) {
+        int sh = L - 6;
+        Fr29 other = fr29_shfl_xor(n, 1 << sh);
+        int j = lane >> sh;  // node index at level L
+        bool left = (j & 1) == 0;
+        Fr29 na, nb;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            na.l[i] = left ? n.l[i] : other.l[i];
+            nb.l[i] = left ? other.l[i] : n.l[i];
+        }
+        const Fr29 sum = fr29_add(na, nb), dif = fr29_sub_biased(na, nb);
+        n = fr29_add(fr29_mul(sum, Z[L]), fr29_mul(dif, fr29_load(M + (j & ~1))));
+    }
+    // S R' per lane (below 2r), then the sum over the 64 lanes (below 128 r), normalised every second step
+    Fr29 sm = fr29_mul(psum, fr29_const(c29::FR29_R2));
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        sm = fr29_add(sm, fr29_shfl_xor(sm, sh));
+        if (sh & 0x2A) sm = fr29_normalize(sm);  // after steps 2, 4, 6
+    }
+    unsigned long long any_bad = __ballot(bad);
+    if (lane == 0) {
+        sm = fr29_mul(sm, fr29_const(c29::FR29_ONE));  // same residue, value back below 3r
+        // N = z N0 - (z^4096 - 1) S = z N0 + S - z^4096 S
+        const Fr29 x = fr29_mul(sm, Z[12]);
+        const Fr29 nw = fr29_sub_biased(fr29_add(fr29_mul(n, Z[0]), sm), x);
+        const Fr29 y29 = fr29_mul(nw, fr29_const(c29::FR29_INV4096_PLAIN));  // (N R')(1/4096) R'^-1 = N/4096, below 2r
+        Fr y;
+        fr29_to_words(y.l, y29);
+        y_out[blob_idx] = FrF::reduce_once(y);
         if (any_bad) atomicOr(&status[blob_idx], 1u);
     }
 }

@@ -376,7 +376,8 @@ struct Workspace {
 
 struct KzgSettings {
     int device = 0;
-    Fr *d_M = nullptr, *d_DM = nullptr;
+    Fr *d_M = nullptr, *d_DM = nullptr;            // roots of unity, 8x32 Montgomery (R, R^2 scalings)
+    Fr29Mem *d_M29 = nullptr, *d_DM29 = nullptr;   // the same in radix 2^29 (fr29.hpp), what k_blob_evaluate reads
     Fp* d_tau4 = nullptr;   // [tau]G2 affine (x.c0 x.c1 y.c0 y.c1), Montgomery
     Fp* d_prep = nullptr;   // prepared lines: [tau]G2 then generator (2 * 408 Fp)
     G1Jac* d_gen_mult = nullptr;  // G, 2^64 G, -phi(G), -phi(2^64 G)
@@ -438,7 +439,10 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
     for (auto& e : s->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipMalloc(&s->d_M, sizeof(Fr) * FE_PER_BLOB));
     HIPCHK(hipMalloc(&s->d_DM, sizeof(Fr) * FE_PER_BLOB));
+    HIPCHK(hipMalloc(&s->d_M29, sizeof(Fr29Mem) * FE_PER_BLOB));
+    HIPCHK(hipMalloc(&s->d_DM29, sizeof(Fr29Mem) * FE_PER_BLOB));
     hipLaunchKernelGGL(k_roots_tables, dim3(FE_PER_BLOB / 64), dim3(64), 0, s->s1, s->d_M, s->d_DM);
+    hipLaunchKernelGGL(k_roots_tables29, dim3(FE_PER_BLOB / 64), dim3(64), 0, s->s1, s->d_M, s->d_M29, s->d_DM29);
     HIPCHK(hipGetLastError());
     KzgRet rc;
     if ((rc = upload_program(s->prep, kzg_slp_prep_begin, kzg_slp_prep_end)) != KZG_OK) return rc;
@@ -544,7 +548,7 @@ static void ws_free(Workspace& w) {
 extern "C" void kzg_settings_free(KzgSettings* s) {
     if (!s) return;
     ws_free(s->ws);
-    void* ptrs[] = {s->d_M, s->d_DM, s->d_tau4, s->d_prep, s->d_gen_mult, s->prep.blob, s->verify.blob};
+    void* ptrs[] = {s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_tau4, s->d_prep, s->d_gen_mult, s->prep.blob, s->verify.blob};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : s->ev)
@@ -562,6 +566,19 @@ static bool challenge_split() {
         return !(e && strcmp(e, "lane") == 0);
     }();
     return v;
+}
+
+// The evaluation kernel over T blobs on stream s1 (radix-2^29 form; KZG_EVALUATE_KERNEL=32 selects the 8x32 form,
+// kept for A/B measurement and as a cross-check).
+static void launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr* d_z, Fr* d_y, uint32_t* d_status, size_t T) {
+    static const bool use32 = [] {
+        const char* e = getenv("KZG_EVALUATE_KERNEL");
+        return e && strcmp(e, "32") == 0;
+    }();
+    if (use32)
+        hipLaunchKernelGGL(k_blob_evaluate32, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, d_z, s->d_M, s->d_DM, d_y, d_status);
+    else
+        hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, d_z, s->d_M29, s->d_DM29, d_y, d_status);
 }
 
 // The challenge kernel over T blobs on stream s1.  Producer/consumer pairs per workgroup: 1 while every pair can have
@@ -723,8 +740,7 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
     HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * T, s->s1));
     if ((rc = launch_challenge(s, d_blobs, d_commitments, w.d_z, T)) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[7], s->s1));
-    hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, w.d_z, s->d_M, s->d_DM, w.d_y,
-                       w.d_status);
+    launch_evaluate(s, d_blobs, w.d_z, w.d_y, w.d_status, T);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[8], s->s1));
     HIPCHK(hipStreamWaitEvent(s->s1, s->ev[6], 0));
@@ -1063,8 +1079,7 @@ static KzgRet evaluate_device_locked(void* d_y, const void* d_blobs, const void*
     Workspace& w = s->ws;
     HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * n, s->s1));
     HIPCHK(hipEventRecord(s->ev[7], s->s1));
-    hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)n), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, (const Fr*)d_z, s->d_M,
-                       s->d_DM, (Fr*)d_y, w.d_status);
+    launch_evaluate(s, d_blobs, (const Fr*)d_z, (Fr*)d_y, w.d_status, n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[8], s->s1));
     uint32_t* h_status = reinterpret_cast<uint32_t*>(w.h_buf + 64 * n);
