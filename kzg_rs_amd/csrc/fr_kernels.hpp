@@ -71,11 +71,28 @@ __device__ __forceinline__ void fr_to_be_words(uint4& hi, uint4& lo, const Fr& a
     lo = make_uint4(__builtin_bswap32(a.l[3]), __builtin_bswap32(a.l[2]), __builtin_bswap32(a.l[1]), __builtin_bswap32(a.l[0]));
 }
 
+__device__ __forceinline__ void bswap4(uint32_t* w, const uint4& q) {
+    w[0] = __builtin_bswap32(q.x); w[1] = __builtin_bswap32(q.y); w[2] = __builtin_bswap32(q.z); w[3] = __builtin_bswap32(q.w);
+}
+
 // ---------------------------------------------------------------- challenge (one lane per blob)
 // transcript = "FSBLOBVERIFY_V1_" || u64_be(0) || u64_be(4096) || blob || commitment   (131 152 B)
 // z = int_be(sha256(transcript)) mod r        (src/kzg_proof.rs:46-91)
 // Output: z as canonical little-endian limbs (plain integer, NOT Montgomery).
-__global__ __launch_bounds__(64) void k_blob_challenge(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
+//
+// Every lane streams a different blob, so one load instruction touches 64 different cache lines.  The transcript is a
+// 32-byte header followed by the blob, so its 64-byte blocks straddle the blob's 128-byte lines: line m = blob bytes
+// [128 m, 128 m + 128) feeds block 2m = (32 bytes carried over | L0 L1), block 2m + 1 = (L2 .. L5) and carries (L6 L7)
+// on.  A lane fetches a WHOLE line with eight back-to-back 16-byte loads, one line ahead of the two compressions that
+// consume it: fetched 16 bytes at a time, a line is re-read from L2 up to eight times once the CU's waves outrun the
+// 32 KiB L1.  No LDS, no barriers: this form runs within a few % of the pure-register SHA-256 issue rate
+// (tools/microbench/shabench.hip) as soon as every SIMD has a wave, which the producer/consumer form below cannot
+// reach; that one exists for the LATENCY of a single batch.
+// 256-thread workgroups on purpose: the hardware deals the four waves of a workgroup round-robin over the CU's four
+// SIMDs, while single-wave workgroups are placed with no regard for balance - the same kernel launched as 1024
+// workgroups of 64 threads ran 1.8x slower (10.3 ms against 5.6 ms for 65 536 blobs) with two waves sharing a SIMD
+// on some CUs and idle SIMDs on others.
+__global__ __launch_bounds__(256) void k_blob_challenge(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
                                                        Fr* __restrict__ z_out, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -83,39 +100,40 @@ __global__ __launch_bounds__(64) void k_blob_challenge(const uint8_t* __restrict
     const uint4* cm = reinterpret_cast<const uint4*>(commitments + (size_t)i * 48);
     Sha256State st;
     sha256_init(st);
-    uint32_t w[16];
-    // block 0: 32-byte header + blob[0..32)
-    w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;  // "FSBLOBVERIFY_V1_"
-    w[4] = 0; w[5] = 0; w[6] = 0; w[7] = FE_PER_BLOB;
-    {
-        uint4 a = blob[0], b = blob[1];
-        w[8] = __builtin_bswap32(a.x); w[9] = __builtin_bswap32(a.y); w[10] = __builtin_bswap32(a.z); w[11] = __builtin_bswap32(a.w);
-        w[12] = __builtin_bswap32(b.x); w[13] = __builtin_bswap32(b.y); w[14] = __builtin_bswap32(b.z); w[15] = __builtin_bswap32(b.w);
+    uint4 L[8], c0, c1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) L[j] = blob[j];
+#pragma unroll 1
+    for (int m = 0; m < 1024; m++) {
+        uint32_t w[16];
+        if (m == 0) {
+            w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;  // "FSBLOBVERIFY_V1_"
+            w[4] = 0; w[5] = 0; w[6] = 0; w[7] = FE_PER_BLOB;                            // u64_be(0) | u64_be(4096)
+        } else {
+            bswap4(w, c0);
+            bswap4(w + 4, c1);
+        }
+        bswap4(w + 8, L[0]);
+        bswap4(w + 12, L[1]);
+        const uint4 n2 = L[2], n3 = L[3], n4 = L[4], n5 = L[5];
+        c0 = L[6];
+        c1 = L[7];
+        if (m + 1 < 1024) {  // the next line, in flight during the two compressions below
+            const uint4* p = blob + 8 * (m + 1);
+#pragma unroll
+            for (int j = 0; j < 8; j++) L[j] = p[j];
+        } else {
+            L[0] = cm[0]; L[1] = cm[1]; L[2] = cm[2];
+        }
+        sha256_compress(st, w);  // block 2m
+        bswap4(w, n2); bswap4(w + 4, n3); bswap4(w + 8, n4); bswap4(w + 12, n5);
+        sha256_compress(st, w);  // block 2m + 1
     }
-    sha256_compress(st, w);
-    // blocks 1..2047: blob[64b-32 .. 64b+32)
-    for (int b = 1; b < 2048; b++) {
-        const uint4* p = blob + (4 * b - 2);
-        uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-        w[0] = __builtin_bswap32(q0.x); w[1] = __builtin_bswap32(q0.y); w[2] = __builtin_bswap32(q0.z); w[3] = __builtin_bswap32(q0.w);
-        w[4] = __builtin_bswap32(q1.x); w[5] = __builtin_bswap32(q1.y); w[6] = __builtin_bswap32(q1.z); w[7] = __builtin_bswap32(q1.w);
-        w[8] = __builtin_bswap32(q2.x); w[9] = __builtin_bswap32(q2.y); w[10] = __builtin_bswap32(q2.z); w[11] = __builtin_bswap32(q2.w);
-        w[12] = __builtin_bswap32(q3.x); w[13] = __builtin_bswap32(q3.y); w[14] = __builtin_bswap32(q3.z); w[15] = __builtin_bswap32(q3.w);
+    {
+        uint32_t w[16];
+        bswap4(w, c0); bswap4(w + 4, c1); bswap4(w + 8, L[0]); bswap4(w + 12, L[1]);  // block 2048: blob tail | commitment[0..32)
         sha256_compress(st, w);
-    }
-    // block 2048: blob[131040..131072) + commitment[0..32)
-    {
-        uint4 q0 = blob[8190], q1 = blob[8191], q2 = cm[0], q3 = cm[1];
-        w[0] = __builtin_bswap32(q0.x); w[1] = __builtin_bswap32(q0.y); w[2] = __builtin_bswap32(q0.z); w[3] = __builtin_bswap32(q0.w);
-        w[4] = __builtin_bswap32(q1.x); w[5] = __builtin_bswap32(q1.y); w[6] = __builtin_bswap32(q1.z); w[7] = __builtin_bswap32(q1.w);
-        w[8] = __builtin_bswap32(q2.x); w[9] = __builtin_bswap32(q2.y); w[10] = __builtin_bswap32(q2.z); w[11] = __builtin_bswap32(q2.w);
-        w[12] = __builtin_bswap32(q3.x); w[13] = __builtin_bswap32(q3.y); w[14] = __builtin_bswap32(q3.z); w[15] = __builtin_bswap32(q3.w);
-        sha256_compress(st, w);
-    }
-    // final block: commitment[32..48) + 0x80 pad + bit length (131152 * 8)
-    {
-        uint4 q = cm[2];
-        w[0] = __builtin_bswap32(q.x); w[1] = __builtin_bswap32(q.y); w[2] = __builtin_bswap32(q.z); w[3] = __builtin_bswap32(q.w);
+        bswap4(w, L[2]);  // block 2049: commitment[32..48) + 0x80 pad + bit length (131152 * 8)
         w[4] = 0x80000000u;
 #pragma unroll
         for (int k = 5; k < 15; k++) w[k] = 0;
@@ -137,70 +155,77 @@ __global__ __launch_bounds__(64) void k_blob_challenge(const uint8_t* __restrict
 // a double-buffered LDS tile; the consumer only runs the 64 rounds (~930 instructions per block instead of
 // ~1400).  One barrier per block.
 //
-// A workgroup holds PAIRS pairs: waves [0, PAIRS) consume, waves [PAIRS, 2 PAIRS) produce, pair p = waves p and
-// p + PAIRS.  The hardware deals a workgroup's waves round-robin over the CU's four SIMDs, so
-//   PAIRS = 1: the two waves of a pair sit on different SIMDs - the lowest latency for a single batch;
-//   PAIRS = 4: one workgroup fills a CU with exactly one consumer and one producer per SIMD.  With many small
-//              workgroups instead the placement is left to the dispatcher, which measured 2.3x slower at 4 per CU
-//              (consumers doubling up on a SIMD, and only ~60% of the workgroups resident at a time).
-__device__ __forceinline__ void bswap4(uint32_t* w, const uint4& q) {
-    w[0] = __builtin_bswap32(q.x); w[1] = __builtin_bswap32(q.y); w[2] = __builtin_bswap32(q.z); w[3] = __builtin_bswap32(q.w);
-}
-constexpr int CHALLENGE_TILE_U4 = 2 * 16 * 64;  // per pair: [buffer][round quad][lane] uint4 = 32 KiB, conflict-free b128 rows
-template <int PAIRS>
-__global__ __launch_bounds__(128 * PAIRS) void k_blob_challenge_split(const uint8_t* __restrict__ blobs,
-                                                                      const uint8_t* __restrict__ commitments,
-                                                                      Fr* __restrict__ z_out, int n) {
-    extern __shared__ uint4 challenge_tiles[];
+// One pair per workgroup: the two waves land on different SIMDs of a CU (a workgroup's waves are dealt round-robin).
+// Used while every pair can have a CU to itself; larger launches use k_blob_challenge, which has the higher throughput.
+constexpr int CHALLENGE_TILE_U4 = 2 * 16 * 64;  // [buffer][round quad][lane] uint4 = 32 KiB, conflict-free b128 rows
+__global__ __launch_bounds__(128) void k_blob_challenge_split(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
+                                                              Fr* __restrict__ z_out, int n) {
+    __shared__ uint4 tile[CHALLENGE_TILE_U4];
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int role = wave / PAIRS, pair = wave % PAIRS;  // role 0 consumer, 1 producer
-    uint4* tile = challenge_tiles + pair * CHALLENGE_TILE_U4;
-    int i = (blockIdx.x * PAIRS + pair) * 64 + lane;
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0 consumer, 1 producer
+    int i = blockIdx.x * 64 + lane;
     const bool live = i < n;
     if (!live) i = n - 1;  // redundant work keeps the barriers uniform
     constexpr int NBLK = 2050;
 
-    // Both roles run NBLK + 1 barriers; each keeps its own loop so the register allocation of one role does not
-    // carry the other's live state.
+    // Both roles run NBLK + 1 barriers; each keeps its own loop so the register allocation of one role does not carry
+    // the other's live state.
     if (role == 1) {
         const uint4* blob = reinterpret_cast<const uint4*>(blobs + (size_t)i * BLOB_BYTES);
         const uint4* cm = reinterpret_cast<const uint4*>(commitments + (size_t)i * 48);
-        uint4 q0 = blob[2], q1 = blob[3], q2 = blob[4], q3 = blob[5];  // raw bytes of transcript block 1
-#pragma unroll 1
-        for (int b = 0; b < NBLK; b++) {
-            uint32_t w[16];
-            if (b == 0) {
-                w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;  // "FSBLOBVERIFY_V1_"
-                w[4] = 0; w[5] = 0; w[6] = 0; w[7] = FE_PER_BLOB;
-                bswap4(w + 8, blob[0]);
-                bswap4(w + 12, blob[1]);
-            } else {
-                bswap4(w, q0);
-                if (b < 2049) {
-                    bswap4(w + 4, q1); bswap4(w + 8, q2); bswap4(w + 12, q3);
-                } else {  // commitment[32..48) + 0x80 pad + bit length
-                    w[4] = 0x80000000u;
-#pragma unroll
-                    for (int k = 5; k < 15; k++) w[k] = 0;
-                    w[15] = 131152u * 8u;
-                }
-                // raw bytes of block b + 1, in flight while block b is expanded
-                if (b + 1 < 2048) {
-                    const uint4* p = blob + (4 * (b + 1) - 2);
-                    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-                } else if (b + 1 == 2048) {
-                    q0 = blob[8190]; q1 = blob[8191]; q2 = cm[0]; q3 = cm[1];
-                } else if (b + 1 == 2049) {
-                    q0 = cm[2];
-                }
-            }
+        // expand the 16 message words of transcript block b, hand (W + K)[0..64) to the consumer
+        auto emit = [=](uint32_t (&w)[16], int b) {
             uint32_t kw[64];
             sha256_schedule_kw(kw, w);
             uint4* dst = tile + (b & 1) * (16 * 64) + lane;
 #pragma unroll
             for (int t = 0; t < 16; t++) dst[t * 64] = make_uint4(kw[4 * t], kw[4 * t + 1], kw[4 * t + 2], kw[4 * t + 3]);
             __syncthreads();  // block b is ready; the consumer is done with block b - 1, whose buffer block b + 1 reuses
+        };
+        // The transcript is a 32-byte header followed by the blob, so its 64-byte blocks straddle the blob's 128-byte
+        // cache lines: line m = blob bytes [128 m, 128 m + 128) feeds block 2m = (32 bytes carried over | L0 L1),
+        // block 2m + 1 = (L2 .. L5) and carries (L6 L7) on.  A lane fetches a WHOLE line with eight back-to-back
+        // 16-byte loads and then lives on it for two blocks: every lane of the wave streams a different blob, so a
+        // load instruction touches 64 different lines, and fetching a line 16 bytes at a time over two blocks re-reads
+        // it from L2 up to eight times once the CU's producers outrun the 32 KiB L1.
+        uint4 L[8], c0, c1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) L[j] = blob[j];
+#pragma unroll 1
+        for (int m = 0; m < 1024; m++) {
+            uint32_t w[16];
+            if (m == 0) {
+                w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;  // "FSBLOBVERIFY_V1_"
+                w[4] = 0; w[5] = 0; w[6] = 0; w[7] = FE_PER_BLOB;                            // u64_be(0) | u64_be(4096)
+            } else {
+                bswap4(w, c0);
+                bswap4(w + 4, c1);
+            }
+            bswap4(w + 8, L[0]);
+            bswap4(w + 12, L[1]);
+            emit(w, 2 * m);
+            bswap4(w, L[2]); bswap4(w + 4, L[3]); bswap4(w + 8, L[4]); bswap4(w + 12, L[5]);
+            c0 = L[6];
+            c1 = L[7];
+            if (m + 1 < 1024) {  // the next line, in flight while block 2m + 1 is expanded
+                const uint4* p = blob + 8 * (m + 1);
+#pragma unroll
+                for (int j = 0; j < 8; j++) L[j] = p[j];
+            } else {
+                L[0] = cm[0]; L[1] = cm[1]; L[2] = cm[2];
+            }
+            emit(w, 2 * m + 1);
+        }
+        {
+            uint32_t w[16];
+            bswap4(w, c0); bswap4(w + 4, c1); bswap4(w + 8, L[0]); bswap4(w + 12, L[1]);  // blob tail | commitment[0..32)
+            emit(w, 2048);
+            bswap4(w, L[2]);  // commitment[32..48) + 0x80 pad + bit length
+            w[4] = 0x80000000u;
+#pragma unroll
+            for (int k = 5; k < 15; k++) w[k] = 0;
+            w[15] = 131152u * 8u;
+            emit(w, 2049);
         }
         __syncthreads();
     } else {

@@ -558,16 +558,6 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     delete s;
 }
 
-// challenge kernel selection: producer/consumer form by default; KZG_CHALLENGE_KERNEL=lane selects the
-// one-lane-per-blob form (kept for A/B measurement and as a cross-check in the tests)
-static bool challenge_split() {
-    static const bool v = [] {
-        const char* e = getenv("KZG_CHALLENGE_KERNEL");
-        return !(e && strcmp(e, "lane") == 0);
-    }();
-    return v;
-}
-
 // The evaluation kernel over T blobs on stream s1 (radix-2^29 form; KZG_EVALUATE_KERNEL=32 selects the 8x32 form,
 // kept for A/B measurement and as a cross-check).
 static void launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr* d_z, Fr* d_y, uint32_t* d_status, size_t T) {
@@ -581,25 +571,20 @@ static void launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr*
         hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, d_z, s->d_M29, s->d_DM29, d_y, d_status);
 }
 
-// The challenge kernel over T blobs on stream s1.  Producer/consumer pairs per workgroup: 1 while every pair can have
-// a CU of its own (T <= 64 * 256), else 4 = one workgroup fills a CU (fr_kernels.hpp); KZG_CHALLENGE_PAIRS overrides.
+// The challenge kernel over T blobs on stream s1: the producer/consumer form (half the serial chain, lowest latency)
+// while every pair of waves can have a CU to itself, the one-lane-per-blob form (highest throughput) beyond that.
+// KZG_CHALLENGE_KERNEL = lane | split forces one of them (A/B measurement, cross-check in the tests).
 static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const void* d_commitments, Fr* d_z, size_t T) {
     static const int forced = [] {
-        const char* e = getenv("KZG_CHALLENGE_PAIRS");
-        return e ? atoi(e) : 0;
+        const char* e = getenv("KZG_CHALLENGE_KERNEL");
+        return !e ? 0 : strcmp(e, "lane") == 0 ? 1 : strcmp(e, "split") == 0 ? 2 : 0;
     }();
     const uint8_t *bl = (const uint8_t*)d_blobs, *cm = (const uint8_t*)d_commitments;
-    if (!challenge_split()) {
-        hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, s->s1, bl, cm, d_z, (int)T);
-    } else if (forced == 4 || (forced != 1 && T > 64 * 256)) {
-        constexpr int P = 4;
-        const int lds = P * CHALLENGE_TILE_U4 * (int)sizeof(uint4);
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_challenge_split<P>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        hipLaunchKernelGGL(k_blob_challenge_split<P>, dim3((unsigned)((T + 64 * P - 1) / (64 * P))), dim3(128 * P), lds, s->s1, bl, cm, d_z, (int)T);
-    } else {
-        const int lds = CHALLENGE_TILE_U4 * (int)sizeof(uint4);
-        hipLaunchKernelGGL(k_blob_challenge_split<1>, dim3((unsigned)((T + 63) / 64)), dim3(128), lds, s->s1, bl, cm, d_z, (int)T);
-    }
+    const bool lane = forced ? forced == 1 : T > 64 * 256;
+    if (lane)
+        hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s->s1, bl, cm, d_z, (int)T);
+    else
+        hipLaunchKernelGGL(k_blob_challenge_split, dim3((unsigned)((T + 63) / 64)), dim3(128), 0, s->s1, bl, cm, d_z, (int)T);
     HIPCHK(hipGetLastError());
     return KZG_OK;
 }

@@ -5,6 +5,7 @@ Laid out like the reference's own tests (src/kzg_proof.rs:604-778): vector-drive
 three entry points + the two scalar KATs, then per-kernel parity on seeded random inputs and
 the edge cases the reference's vectors exercise."""
 import hashlib
+import os
 import random
 
 import pytest
@@ -210,6 +211,31 @@ def test_challenge_and_evaluate_random(settings, osettings):
     pts = [bytes(32), (1).to_bytes(32, "big"), (R - 1).to_bytes(32, "big"), b"\xff" * 32, rng.randrange(R).to_bytes(32, "big")]
     ys = api.evaluate_polynomials(blobs, pts, settings)
     assert ys == [O.evaluate_polynomial_in_evaluation_form(b, z, osettings) for b, z in zip(blobs, pts)]
+
+
+@pytest.mark.parametrize("form", ["lane", "split"])
+def test_challenge_kernel_forms(form):
+    """Both forms of the challenge kernel (fr_kernels.hpp: one lane per blob = the throughput form, producer/consumer =
+    the latency form; the library picks by launch size) on the same 130 blobs, each in a child process that forces it."""
+    import subprocess
+    import sys
+    code = (
+        "import random, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from kzg_rs_amd import api\n"
+        "st = api.KzgSettings.load_trusted_setup_file()\n"
+        "rng = random.Random(99)\n"
+        "blobs = [rng.randbytes(131072) for _ in range(130)]\n"
+        "cs = [rng.randbytes(48) for _ in range(130)]\n"
+        "print(' '.join(z.hex() for z in api.compute_challenges(blobs, cs, st)))\n" % O.ROOT)
+    env = dict(os.environ, KZG_CHALLENGE_KERNEL=form)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = out.stdout.strip().split("\n")[-1].split()
+    rng = random.Random(99)
+    blobs = [rng.randbytes(131072) for _ in range(130)]
+    cs = [rng.randbytes(48) for _ in range(130)]
+    assert got == [O.compute_challenge(b, c).hex() for b, c in zip(blobs, cs)]
 
 
 def test_evaluate_at_roots_of_unity(settings, osettings):
