@@ -17,7 +17,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libkzg_rs_amd.so")
+LIB_PATH = os.environ.get("KZG_LIB_OVERRIDE") or os.path.join(HERE, "libkzg_rs_amd.so")
 TRUSTED_SETUP_PATH = os.path.join(HERE, "data", "trusted_setup.txt")
 
 BYTES_PER_FIELD_ELEMENT = 32

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64, 4) void k_g1_multiples(const G1Aff* __restrict_
 // Decode + subgroup check + multiples in one pass: the subgroup test's first scalar multiplication walks the same
 // doubling chain that produces 2^64 P (g1.hpp g1_in_subgroup_with_multiple), which saves the 64 doublings of a
 // separate k_g1_multiples pass.  bytes0 holds points [0, n0), bytes1 points [n0, n).
-__global__ __launch_bounds__(64) void k_g1_decode_multiples(const uint8_t* __restrict__ bytes0, const uint8_t* __restrict__ bytes1,
+__global__ __launch_bounds__(64, 2) void k_g1_decode_multiples(const uint8_t* __restrict__ bytes0, const uint8_t* __restrict__ bytes1,
                                                             int n0, G1Aff* __restrict__ points, uint32_t* __restrict__ pflag,
                                                             G1Jac* __restrict__ mult, int n, int stride) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -235,7 +235,10 @@ __device__ __forceinline__ G1Jac lds_load_jac(const uint32_t* base, int slot) {
 
 // grid (8 windows, 4 / chunks_per_block, 2 outputs x batches), 256 threads: block (w, g, o) handles digit byte 8j + w
 // of every scalar of output o for its chunks j, against the multiples 2^(64j) P.
-__global__ __launch_bounds__(256, 3) void k_msm_window(MsmDesc d) {
+#ifndef KZG_MSM_OCC
+#define KZG_MSM_OCC 3
+#endif
+__global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     // blockIdx.z = 2*batch + output
     const int w = blockIdx.x, bo = blockIdx.z, o = bo & 1, tid = threadIdx.x;
     const int cpb = d.chunks_per_block, j0 = blockIdx.y * cpb;
@@ -278,10 +281,23 @@ __global__ __launch_bounds__(256, 3) void k_msm_window(MsmDesc d) {
     }
     __threadfence_block();
     __syncthreads();
-    // 2. bucket tid (digit 0 contributes nothing)
+    // 2. one bucket per thread, the buckets handed out in order of decreasing size: a wave runs as long as its largest
+    //    bucket, so wave 0 takes the 64 fullest buckets, wave 3 the 64 emptiest (Poisson-distributed sizes: ~25% fewer
+    //    wave-level additions than bucket tid -> thread tid).  Digit 0 contributes nothing and ranks last.
+    {
+        const uint32_t mine = tid ? cnt[tid] : 0u;
+        uint32_t rank = 0;
+        for (int b = 0; b < MSM_BUCKETS; b++) {
+            const uint32_t c = b ? cnt[b] : 0u;
+            rank += (c > mine) | ((c == mine) & (b < tid));
+        }
+        cur[rank] = tid;  // cur[] is free after the sort: bucket handled by thread `rank`
+    }
+    __syncthreads();
+    const int bucket = cur[tid];
     G1Jac acc = g1_identity();
-    if (tid > 0) {
-        for (uint32_t k = off[tid]; k < off[tid + 1]; k++) {
+    if (bucket > 0) {
+        for (uint32_t k = off[bucket]; k < off[bucket + 1]; k++) {
             const uint32_t e = sorted[k];
             acc = g1_add(acc, d.mult[(size_t)(e >> 30) * d.stride + (e & 0x3FFFFFFFu)]);
         }
@@ -296,8 +312,9 @@ __global__ __launch_bounds__(256, 3) void k_msm_window(MsmDesc d) {
     //      kind 1 cols  : dst = 16 (2 s k) + lo, src = dst + 16 s     (ops = 128 / s)   on a fresh copy of the buckets
     //      kind 2 scan  : suffix scan over the two 16-element vectors R (slots 0..15) and C (slots 16..31)
     //      kind 3 tree  : tree sum of the two scanned vectors (slot 0 / 16 of each zeroed first)
-    lds_store_jac(pts, tid, acc);
+    lds_store_jac(pts, bucket, acc);
     __syncthreads();
+    acc = lds_load_jac(pts, tid);  // from here on thread tid holds bucket tid again
     G1Jac keep = g1_identity();  // threads 0..15: R_tid, threads 16..31: C_(tid-16)
 #pragma unroll 1
     for (int lvl = 0; lvl < 16; lvl++) {
