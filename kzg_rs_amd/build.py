@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
                                                                os.path.join(data, "slp_verify.bin"),
                                                                os.path.join(ROOT, "include", "kzg_rs_amd.h")]
     if force or _newer(LIB, deps):
-        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result",
+        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wno-unused-result",
                '-DKZG_DATA_DIR="%s"' % data, "-I", csrc, "-o", LIB, SRC]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

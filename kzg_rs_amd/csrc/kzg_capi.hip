@@ -10,8 +10,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kzg_rs_amd.h"
@@ -789,19 +791,37 @@ static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, s
         // verify_blob_kzg_proof path (:482-489): r^0 = 1, no batch challenge
         hipLaunchKernelGGL(k_single_scalars, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_z, w.d_y, w.d_scalars);
     } else {
-        // compute_r_powers :291-348, once per batch
-        std::vector<uint8_t> t(32 + 160 * n_total);
-        memcpy(t.data(), "RCKZGBATCH___V1_", 16);
-        memset(t.data() + 16, 0, 16);
-        t[22] = (uint8_t)(FE_PER_BLOB >> 8);
-        t[23] = (uint8_t)(FE_PER_BLOB & 0xff);
-        for (int k = 0; k < 8; k++) t[24 + k] = (uint8_t)((uint64_t)n_total >> (56 - 8 * k));
-        for (size_t b = 0; b < B; b++) {
-            memcpy(t.data() + 32, all_records + 160 * n_total * b, 160 * n_total);
-            uint8_t dg[32];
-            hostsha::digest(dg, t.data(), t.size());
-            while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r: at most two subtractions (2^256 < 3r)
-            reverse32(w.h_buf + w.off_r + 32 * b, dg);  // pinned staging for the async H2D copy
+        // compute_r_powers :291-348, once per batch.  The transcripts are hashed on the host (SHA-NI): one serial chain
+        // of 160 n_total + 32 bytes per batch - hopeless on a GPU lane, ~2 GB/s on a CPU core - and the batches of a
+        // launch group are independent, so they are spread over a few host threads (KZG_HOST_THREADS, default 16).
+        auto digest_range = [&](size_t b0, size_t b1) {
+            std::vector<uint8_t> t(32 + 160 * n_total);
+            memcpy(t.data(), "RCKZGBATCH___V1_", 16);
+            memset(t.data() + 16, 0, 16);
+            t[22] = (uint8_t)(FE_PER_BLOB >> 8);
+            t[23] = (uint8_t)(FE_PER_BLOB & 0xff);
+            for (int k = 0; k < 8; k++) t[24 + k] = (uint8_t)((uint64_t)n_total >> (56 - 8 * k));
+            for (size_t b = b0; b < b1; b++) {
+                memcpy(t.data() + 32, all_records + 160 * n_total * b, 160 * n_total);
+                uint8_t dg[32];
+                hostsha::digest(dg, t.data(), t.size());
+                while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r: at most two subtractions (2^256 < 3r)
+                reverse32(w.h_buf + w.off_r + 32 * b, dg);  // pinned staging for the async H2D copy
+            }
+        };
+        static const size_t host_threads = [] {
+            const char* e = getenv("KZG_HOST_THREADS");
+            long v = e ? atol(e) : 16;
+            return (size_t)(v < 1 ? 1 : v > 64 ? 64 : v);
+        }();
+        const size_t nthr = std::min(host_threads, std::min(B, (B * 160 * n_total) / (512 * 1024) + 1));
+        if (nthr <= 1) {
+            digest_range(0, B);
+        } else {
+            std::vector<std::thread> pool;
+            for (size_t k = 1; k < nthr; k++) pool.emplace_back(digest_range, B * k / nthr, B * (k + 1) / nthr);
+            digest_range(0, B / nthr);
+            for (auto& th : pool) th.join();
         }
         HIPCHK(hipMemcpyAsync(w.d_r, w.h_buf + w.off_r, 32 * B, hipMemcpyHostToDevice, s->s1));
         unsigned blocks = (unsigned)((n + 255) / 256);
