@@ -35,6 +35,7 @@ ALG_BYTES = {
     "k_msm": 3 * 128,                               # three (point, scalar) terms per blob, 96 + 32 B each
     "k_slp_run(pairing)": 0,
 }
+PMC_FILE = "r1f_pmc.json"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
 
 
@@ -100,6 +101,11 @@ def main():
     d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).to(dev)
     d_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
+    if os.environ.get("KZG_PMC_CALIBRATE") == "1":  # a 128 MiB device-to-device copy: the known-size dispatch that
+        cal = torch.empty_like(d_blobs)              # checks the FETCH_SIZE / WRITE_SIZE scaling in a PMC run
+        cal.copy_(d_blobs)
+        torch.cuda.synchronize()
+        del cal
     backend0 = HipBackend(settings)
 
     # ---- pipeline: depth (d1, d2, d3) groups between the phases; one handle (2 HIP streams + workspace) per group in flight
@@ -186,15 +192,27 @@ def main():
     dom = max(kernels, key=kernels.get)
     units = n * g0
     achieved = ALG_BYTES[dom] * units / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
-    # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc cannot run inside
-    # this process): bytes per launch, scaled to this launch's unit count
-    traffic = None
+    # HBM traffic of that kernel and the VALU instruction counts of all kernels, from the PMC passes committed under
+    # profiles/ (tools/prof/collect_round.sh; rocprofv3 --pmc cannot run inside this process): per launch of
+    # `blobs_per_launch` blobs, scaled to this launch's unit count
+    PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge", "k_blob_evaluate": "kzg::k_blob_evaluate",
+                "k_g1_decode_multiples": "kzg::k_g1_decode_multiples", "k_msm": "kzg::k_msm_window", "k_slp_run(pairing)": "kzg::k_slp_run<false>"}
+    traffic, valu = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"].get(dom)
-        if pmc:
-            traffic = round(pmc["hbm_bytes_corrected"] * units / pmc["units"])
+        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+        pk = pmc["kernels"].get(PMC_NAME[dom])
+        if pk and "hbm_bytes_corrected" in pk:
+            traffic = round(pk["hbm_bytes_corrected"] * units / pmc["blobs_per_launch"])
+        path = list(PMC_NAME.values()) + ["kzg::k_msm_combine", "kzg::k_batch_scalars", "kzg::k_glv_split"]
+        insts = sum(pmc["kernels"][k].get("SQ_INSTS_VALU", 0) for k in path if k in pmc["kernels"])
+        per_blob = insts / pmc["blobs_per_launch"]  # wave-instructions per blob, all kernels of the path
+        simds, clock = 1024, 2.4e9
+        valu = {"wave_insts_per_blob": round(per_blob), "insts_per_cycle_per_simd": round(per_blob * (n * K / elapsed) / (simds * clock), 4),
+                "note": "VALU wave-instructions issued per SIMD cycle at the measured throughput (SQ_INSTS_VALU of every kernel of the path, "
+                        + PMC_FILE + "); gfx950 issues the path's instruction mix at 2.4-4.3 cycles per wave-instruction "
+                        "(profiles/r1_issuebench_valu_issue_cost.txt), i.e. 0.23-0.42 is the ceiling"}
     except Exception:
-        traffic = None
+        pass
     out = {
         "metric": "blobs/sec verify_blob_kzg_proof_batch",
         "value": round(n * world * K / elapsed, 2),
@@ -215,9 +233,10 @@ def main():
                    "batches_per_launch_group": G, "groups_in_flight": F},
         "roofline": {"bound": "hbm", "kernel": dom, "units_per_launch": units, "launch_ms": round(kernels[dom], 4),
                      "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                     "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH x2 gfx950 correction)",
+                     "traffic": traffic, "traffic_source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH x2 gfx950 correction)",
                      "algorithmic_bytes_per_launch": ALG_BYTES[dom] * units,
                      "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 5)"},
+        "valu": valu,
         "kernel_ms_per_launch_group": {k: round(v, 4) for k, v in kernels.items()},
         "single_batch": {"value": round(n * world * KS / seq_elapsed, 2), "unit": "blobs/s", "ms_per_step": round(seq_elapsed / KS * 1e3, 4),
                          "steps": KS, "kernel_ms": {"k_blob_challenge": round(seq_tm[5], 4), "k_blob_evaluate": round(seq_tm[4], 4),

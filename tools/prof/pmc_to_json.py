@@ -1,0 +1,53 @@
+"""Merge the PMC passes of tools/prof/collect_round.sh into one JSON: per kernel, the counters of its largest dispatch
+(one launch group), HBM bytes corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 on gfx950: 128-byte requests
+are tallied at 64 bytes; WRITE_SIZE exact), with the correction checked in the same run on a 128 MiB device copy
+(bench.py under KZG_PMC_CALIBRATE=1)."""
+import csv, glob, json, sys
+
+prefix, group = sys.argv[1], int(sys.argv[2])
+kern = {}
+calib = {}
+for d in sorted(glob.glob(prefix + "_*")):
+    if not d[-1].isdigit():
+        continue
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    t = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
+    if not f:
+        continue
+    dur = {}
+    for r in csv.DictReader(open(t[0])):
+        dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    per = {}
+    for r in csv.DictReader(open(f[0])):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        e = per.setdefault(name, {}).setdefault(r["Dispatch_Id"], {"grid": int(r["Grid_Size"]), "ms": dur.get(r["Dispatch_Id"])})
+        e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    for name, disp in per.items():
+        did, v = max(disp.items(), key=lambda kv: (kv[1]["grid"], kv[1]["ms"] or 0))
+        if "copyBuffer" in name:
+            # calibration: the 128 MiB copy is the largest copy
+            for k, x in v.items():
+                if k in ("FETCH_SIZE", "WRITE_SIZE"):
+                    calib[k + "_KB_for_128MiB_copy"] = x
+            continue
+        if not name.startswith("kzg::") and not name.startswith("k_"):
+            continue
+        o = kern.setdefault(name, {"grid_threads": v["grid"]})
+        for k, x in v.items():
+            if k == "grid":
+                continue
+            if k == "ms":
+                o.setdefault("ms_single_stream", []).append(round(x, 4))
+            else:
+                o[k] = x
+for name, o in kern.items():
+    if "ms_single_stream" in o:
+        o["ms_single_stream"] = round(sum(o["ms_single_stream"]) / len(o["ms_single_stream"]), 4)
+    if "FETCH_SIZE" in o and "WRITE_SIZE" in o:
+        o["hbm_bytes_corrected"] = round(2 * o["FETCH_SIZE"] * 1024 + o["WRITE_SIZE"] * 1024)
+print(json.dumps({
+    "method": "rocprofv3 --pmc, one counter set per run, KZG_SINGLE_STREAM=1, bench.py --group %d --inflight 1 --steps %d: one "
+              "launch group of %d batches x 1024 blobs; values are per launch of the kernel (its largest dispatch). FETCH_SIZE / "
+              "WRITE_SIZE in KB as reported; hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
+              "MI355X_MICROARCH.md HBM section)." % (group, group, group),
+    "blobs_per_launch": 1024 * group, "calibration": calib, "kernels": kern}, indent=1))
