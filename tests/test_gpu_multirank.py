@@ -1,0 +1,128 @@
+"""The N > 1 product path on real hardware: 2 and 3 ranks (one process each, all on cuda:0 of the test box, gloo for
+the two small exchanges) run the HIP shard phases of include/kzg_rs_amd.h through kzg_rs_amd/distributed.py and must
+agree with the unsharded oracle - the same scenarios as the CPU choreography tests of test_distributed_cpu.py (which
+use a backend made of oracle primitives), here with HipBackend: power offsets r^offset per rank, the 288-byte Jacobian
+partials, the fold kernel and the pairing.  On the 8-GPU node the only difference is the transport (RCCL)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+G1_GEN = bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _device_shard(torch, blobs, cs, ps):
+    """-> (keepalive tensors, (d_blobs, d_commitments, d_proofs, n)); an empty shard still gets valid pointers"""
+    n = len(blobs)
+    t = [torch.frombuffer(bytearray(b"".join(x) or b"\0"), dtype=torch.uint8).cuda() for x in (blobs, cs, ps)]
+    torch.cuda.synchronize()
+    return t, (t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n)
+
+
+def _worker(rank, world, port, scenario, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import golden_data as G
+    import oracle_lib as O
+    from kzg_rs_amd import api
+    from kzg_rs_amd.distributed import HipBackend, PipelinedVerifier, verify_blob_kzg_proof_batch_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ost = O.Settings.mainnet()
+    st = api.KzgSettings.load_trusted_setup_file()
+    tuples = G.valid_blob_tuples()  # 7 valid mainnet (blob, C, pi)
+    blobs, cs, ps = [list(x) for x in zip(*tuples)]
+    if scenario == "bad_proof":
+        ps[5] = O.g1_add(ps[5], G1_GEN)
+    if scenario == "bad_blob":
+        b = bytearray(blobs[6])
+        b[64:96] = R.to_bytes(32, "big")
+        blobs[6] = bytes(b)
+    n = len(blobs)
+    if scenario == "pipelined":
+        # three launch groups (2, 1, 2 batches) of 6-blob batches, every rank holding 6 / world blobs of each batch
+        def batch(rot, corrupt=False):
+            t = (tuples[rot:] + tuples[:rot])[:6]
+            bl, c, p = [list(x) for x in zip(*t)]
+            if corrupt:
+                p[4] = O.g1_add(p[4], G1_GEN)
+            return bl, c, p
+        plan = [[batch(0), batch(1, True)], [batch(2)], [batch(3), batch(5)]]
+        per = 6 // world
+        keep, groups, want = [], [], []
+        for grp in plan:
+            gb, gc, gp = [], [], []
+            for bl, c, p in grp:
+                want.append(O.verify_blob_kzg_proof_batch(bl, c, p, ost))
+                sl = slice(rank * per, (rank + 1) * per)
+                gb += bl[sl]; gc += c[sl]; gp += p[sl]
+            t, (db, dc, dp, _) = _device_shard(torch, gb, gc, gp)
+            keep.append(t)
+            groups.append(((db, dc, dp, per), len(grp)))
+        handles = [st] + [api.KzgSettings.load_trusted_setup_file() for _ in range(2)]
+        pipe = PipelinedVerifier([HipBackend(h) for h in handles], dist, "cpu", (1, 0, 1))
+        got = [x for res in pipe.run(groups) for x in res]
+        q.put((rank, got, want))
+    else:
+        if scenario == "uneven":
+            bounds = [0, 1, n] if world == 2 else [0, 1, 1, n]  # an empty shard in the 3-rank case
+        else:
+            bounds = [n * k // world for k in range(world + 1)]
+        lo, hi = bounds[rank], bounds[rank + 1]
+        keep, shard = _device_shard(torch, blobs[lo:hi], cs[lo:hi], ps[lo:hi])
+        try:
+            got = verify_blob_kzg_proof_batch_sharded(shard, hi - lo, HipBackend(st), dist, "cpu")
+        except api.KzgError:
+            got = "error"
+        try:
+            want = O.verify_blob_kzg_proof_batch(blobs, cs, ps, ost)
+        except O.OracleError:
+            want = "error"
+        q.put((rank, got, want))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, scenario):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, scenario, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,scenario", [(2, "valid"), (2, "bad_proof"), (2, "bad_blob"), (2, "uneven"), (3, "uneven")])
+def test_sharded_hip_path_matches_oracle(world, scenario):
+    expected = {"valid": True, "uneven": True, "bad_proof": False, "bad_blob": "error"}[scenario]
+    for rank, got, want in _run(world, scenario):
+        assert got == want == expected, (rank, got, want)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_groups_hip_path(world):
+    for rank, got, want in _run(world, "pipelined"):
+        assert got == want == [True, False, True, True, True], (rank, got, want)
