@@ -396,6 +396,64 @@ def test_synthetic_batch_vs_oracle():
     assert KzgProof.verify_blob_kzg_proof_batch([], [], [], st) is True
 
 
+def test_mutation_fuzz_against_oracle(settings, osettings):
+    """Seeded differential fuzz of the three entry points: valid mainnet tuples with one random mutation each (bit
+    flips in the commitment / proof / blob, field elements at and around r, the identity encoding, wrong flag bits,
+    swapped tuples) in batches of 1..4 - result and error class must equal the oracle's, case by case."""
+    rng = random.Random(20260101)
+    tuples = G.valid_blob_tuples()
+    edge = [R, R - 1, R + 1, (1 << 256) - 1, 0, 1]
+
+    def mutate(blob, c, p):
+        kind = rng.randrange(9)
+        blob, c, p = bytearray(blob), bytearray(c), bytearray(p)
+        if kind == 0:
+            c[rng.randrange(48)] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            p[rng.randrange(48)] ^= 1 << rng.randrange(8)
+        elif kind == 2:
+            i = rng.randrange(4096)
+            blob[32 * i: 32 * i + 32] = rng.choice(edge).to_bytes(32, "big")
+        elif kind == 3:
+            blob[rng.randrange(131072)] ^= 1 << rng.randrange(8)
+        elif kind == 4:
+            c[:] = G1_INF
+        elif kind == 5:
+            p[:] = G1_INF
+        elif kind == 6:
+            (c if rng.randrange(2) else p)[0] ^= rng.choice([0x80, 0x40, 0x20])
+        elif kind == 7:
+            c, p = p, c
+        return bytes(blob), bytes(c), bytes(p)  # kind 8: unchanged
+
+    outcomes = {True: 0, False: 0, None: 0}
+    for case in range(120):
+        n = rng.randrange(1, 5)
+        batch = [list(rng.choice(tuples)) for _ in range(n)]
+        k = rng.randrange(n)
+        batch[k] = list(mutate(*batch[k]))
+        blobs, cs, ps = [list(x) for x in zip(*batch)]
+        try:
+            want = O.verify_blob_kzg_proof_batch(blobs, cs, ps, osettings)
+        except O.OracleError:
+            want = None
+        got = _result(lambda: KzgProof.verify_blob_kzg_proof_batch([Blob(b) for b in blobs], [Bytes48(c) for c in cs],
+                                                                   [Bytes48(p) for p in ps], settings))
+        assert got == want, (case, n, k)
+        outcomes[got] += 1
+        if n == 1:  # the other two entry points on the same tuple
+            got1 = _result(lambda: KzgProof.verify_blob_kzg_proof(Blob(blobs[0]), Bytes48(cs[0]), Bytes48(ps[0]), settings))
+            assert got1 == want
+            try:
+                z = O.compute_challenge(blobs[0], cs[0])
+                y = O.evaluate_polynomial_in_evaluation_form(blobs[0], z, osettings)
+                want2 = O.verify_kzg_proof(cs[0], z, y, ps[0], osettings)
+            except O.OracleError:
+                continue
+            assert _result(lambda: KzgProof.verify_kzg_proof(Bytes48(cs[0]), Bytes32(z), Bytes32(y), Bytes48(ps[0]), settings)) == want2
+    assert min(outcomes.values()) >= 5, outcomes  # the fuzz reaches all three outcomes
+
+
 def test_device_resident_batch_full_size():
     """BASELINE config 2 size (n = 1024), device-resident inputs, through size-independent properties:
     valid batch -> true; one corrupted proof -> false; result is independent of how the batch is split."""
