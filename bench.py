@@ -118,7 +118,7 @@ def main():
     n_handles = sum(depth) + 1
     handles = [settings] + [api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1]) for _ in range(n_handles - 1)]
     backends = [backend0] + [HipBackend(h) for h in handles[1:]]
-    pipe = PipelinedVerifier(backends, dist, dev, depth)
+    pipe = PipelinedVerifier(backends, dist, dev, depth, equal_shards=True)
     # every batch is a different permutation of the rank's shard (different transcript and r), at its own HBM address
     gen = torch.Generator(device="cpu").manual_seed(7 + rank)
     c_t, p_t = d_c.view(n, 48), d_p.view(n, 48)

@@ -116,14 +116,21 @@ KzgRet kzg_shard_finish(bool *ok, const uint8_t *partials, size_t world, const K
  * a latency-bound serial chain that occupies a sliver of the chip, so the batch dimension inside the kernels is
  * what fills the machine; several handles additionally let ONE host thread pipeline groups in a fixed,
  * collective-safe order (kzg_rs_amd/distributed.py).  A handle runs one group at a time: phase1 -> phase2 -> finish.
- *   records_out : [n_batches][n_local] x 160 B;  bad_out (optional): n_batches flags, 1 = batch holds an invalid
- *                 input (without bad_out such a group returns KZG_BADARGS)
- *   all_records : [n_batches][n_total] x 160 B, each batch's records of ALL ranks in global blob order
- *   partial_out : [n_batches] x 288 B;  partials: [world][n_batches] x 288 B (NULL: single rank, no fold) */
+ *   records_out : (optional) [n_batches][n_local] x 160 B;  bad_out (optional): n_batches flags, 1 = batch holds an
+ *                 invalid input (without bad_out such a group returns KZG_BADARGS).  The handle keeps its records.
+ *   all_records : [n_batches][n_total] x 160 B, each batch's records of ALL ranks in global blob order;
+ *                 NULL = the handle's own records (single rank: n_total = n_local, offset = 0)
+ *   partial_out : [n_batches] x 288 B;  partials: [world][n_batches] x 288 B (NULL: single rank, no fold)
+ * Bulk exchange without host copies (the multi-GPU throughput path): kzg_shard_records_device enqueues a copy of
+ * the group's records, [n_batches][n_local] x 160 B, into caller-provided DEVICE memory (e.g. the send buffer of an
+ * RCCL all-gather; complete once kzg_shard_phase1_wait has returned), and kzg_shard_phase2_launch_gathered takes
+ * the all-gathered result as it lands, [world][n_batches][n_local] x 160 B in (pinned) host memory, equal shards. */
 KzgRet kzg_shard_phase1_launch(const void *d_blobs, const void *d_commitments, const void *d_proofs, size_t n_local,
                                size_t n_batches, const KzgSettings *s);
 KzgRet kzg_shard_phase1_wait(uint8_t *records_out, uint8_t *bad_out, const KzgSettings *s);
+KzgRet kzg_shard_records_device(void *d_records_out, const KzgSettings *s);
 KzgRet kzg_shard_phase2_launch(const uint8_t *all_records, size_t n_total, size_t offset, const KzgSettings *s);
+KzgRet kzg_shard_phase2_launch_gathered(const uint8_t *gathered, size_t world, size_t rank, const KzgSettings *s);
 KzgRet kzg_shard_phase2_wait(uint8_t *partial_out, const KzgSettings *s);
 KzgRet kzg_shard_finish_launch(const uint8_t *partials, size_t world, size_t n_batches, const KzgSettings *s);
 KzgRet kzg_shard_finish_wait(bool *ok /* n_batches */, const KzgSettings *s);

@@ -113,6 +113,15 @@ __global__ void k_set_generator(G1Aff* __restrict__ points, uint32_t* __restrict
     pflag[idx] = 0;
 }
 
+// transcript records on the device: out[i] = C_i (48) | z_i (32, LE) | y_i (32, LE) | pi_i (48) as 40 little words
+__global__ void k_pack_records(const uint32_t* __restrict__ c, const uint32_t* __restrict__ p, const uint32_t* __restrict__ z,
+                               const uint32_t* __restrict__ y, uint32_t* __restrict__ out, int T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T * 40) return;
+    int i = t / 40, k = t % 40;
+    out[t] = k < 12 ? c[12 * i + k] : k < 20 ? z[8 * i + k - 12] : k < 28 ? y[8 * i + k - 20] : p[12 * i + k - 28];
+}
+
 // the generator and its precomputed multiples (gen_mult[4], made once per settings) as point `idx` of a workspace
 __global__ void k_set_generator_multiples(G1Aff* __restrict__ points, uint32_t* __restrict__ pflag, G1Jac* __restrict__ mult,
                                           const G1Jac* __restrict__ gen_mult, int idx, int stride) {
@@ -370,7 +379,7 @@ struct Workspace {
     G1Aff* d_points = nullptr;
     G1Jac *d_window = nullptr, *d_ab = nullptr, *d_mult = nullptr, *d_parts = nullptr;
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
-    uint8_t *d_stage_blobs = nullptr, *d_stage_cp = nullptr, *d_bytes = nullptr;
+    uint8_t *d_stage_blobs = nullptr, *d_stage_cp = nullptr, *d_bytes = nullptr, *d_records = nullptr;
     // pinned host mirrors
     uint8_t* h_buf = nullptr;
     size_t h_cap = 0;
@@ -540,7 +549,8 @@ extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_
 
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
-                    w.d_sorted, w.d_points, w.d_window, w.d_ab, w.d_mult, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes};
+                    w.d_sorted, w.d_points, w.d_window, w.d_ab, w.d_mult, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
+                    w.d_records};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w.h_buf) (void)hipHostFree(w.h_buf);
@@ -626,6 +636,7 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
         HIPCHK(hipMalloc(&w.d_slp_in, sizeof(Fp) * 6 * capB));
         HIPCHK(hipMalloc(&w.d_slp_out, sizeof(Fp) * 6 * capB));
         HIPCHK(hipMalloc(&w.d_bytes, 96 * np));
+        HIPCHK(hipMalloc(&w.d_records, 160 * capT));
         w.off_r = 256 * capT + 4096;                 // pinned layout: [per-blob area | r | own partials | out | gathered partials]
         w.off_part = w.off_r + 32 * capB;
         w.off_out = w.off_part + 288 * capB;
@@ -732,14 +743,14 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
     HIPCHK(hipEventRecord(s->ev[8], s->s1));
     HIPCHK(hipStreamWaitEvent(s->s1, s->ev[6], 0));
     HIPCHK(hipEventRecord(s->ev[1], s->s1));
+    // the transcript records, packed on the device; pinned host mirror: [records 160 T | status 4 T | point flags 8 T]
+    hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((40 * T + 255) / 256)), dim3(256), 0, s->s1, (const uint32_t*)d_commitments,
+                       (const uint32_t*)d_proofs, (const uint32_t*)w.d_z, (const uint32_t*)w.d_y, (uint32_t*)w.d_records, (int)T);
+    HIPCHK(hipGetLastError());
     uint8_t* h = w.h_buf;
-    uint8_t *h_z = h, *h_y = h + 32 * T, *h_c = h + 64 * T, *h_p = h + 112 * T;
     uint32_t* h_status = reinterpret_cast<uint32_t*>(h + 160 * T);
     uint32_t* h_pflag = h_status + T;
-    HIPCHK(hipMemcpyAsync(h_z, w.d_z, 32 * T, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipMemcpyAsync(h_y, w.d_y, 32 * T, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipMemcpyAsync(h_c, d_commitments, 48 * T, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipMemcpyAsync(h_p, d_proofs, 48 * T, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(h, w.d_records, 160 * T, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * T, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * T, hipMemcpyDeviceToHost, s->s1));
     w.pending_n = n;
@@ -747,8 +758,8 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
     return KZG_OK;
 }
 
-// records_out: [B][n] x 160 bytes  C(48) || z(32, LE) || y(32, LE) || pi(48) - exactly the per-blob slices of the
-// batch transcripts of src/kzg_proof.rs:314-334.  bad_out (optional, B bytes): 1 where a batch holds an invalid input
+// records_out (optional): [B][n] x 160 bytes  C(48) || z(32, LE) || y(32, LE) || pi(48) - exactly the per-blob slices
+// of the batch transcripts of src/kzg_proof.rs:314-334.  The handle keeps them (pinned host + device) for phase 2.  bad_out (optional, B bytes): 1 where a batch holds an invalid input
 // (then the call still returns KZG_OK); without bad_out any invalid input makes the whole call return KZG_BADARGS.
 static KzgRet phase1_wait_locked(uint8_t* records_out, uint8_t* bad_out, const KzgSettings* s) {
     Workspace& w = s->ws;
@@ -760,7 +771,6 @@ static KzgRet phase1_wait_locked(uint8_t* records_out, uint8_t* bad_out, const K
     elapsed(&s->timings[6], s->ev[5], s->ev[10]);
     elapsed(&s->timings[7], s->ev[10], s->ev[6]);
     uint8_t* h = w.h_buf;
-    uint8_t *h_z = h, *h_y = h + 32 * T, *h_c = h + 64 * T, *h_p = h + 112 * T;
     uint32_t* h_status = reinterpret_cast<uint32_t*>(h + 160 * T);
     uint32_t* h_pflag = h_status + T;
     // error order of the reference: commitments (:503), proofs (:508), then blobs (:263); all map to BadArgs
@@ -772,21 +782,24 @@ static KzgRet phase1_wait_locked(uint8_t* records_out, uint8_t* bad_out, const K
         any_bad |= bad;
     }
     if (any_bad && !bad_out) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");  // (sic) src/kzg_proof.rs:19-23,38-40
-    uint8_t* o = records_out;
-    for (size_t i = 0; i < T; i++, o += 160) {
-        memcpy(o, h_c + 48 * i, 48);
-        memcpy(o + 48, h_z + 32 * i, 32);  // the device limb arrays ARE Scalar::to_bytes() (little-endian), :321,:326
-        memcpy(o + 80, h_y + 32 * i, 32);
-        memcpy(o + 112, h_p + 48 * i, 48);
-    }
+    if (records_out) memcpy(records_out, h, 160 * T);  // the device limb arrays ARE Scalar::to_bytes() (little-endian), :321,:326
     return KZG_OK;
 }
 
-// Phase 2: per batch b, r_b from its FULL transcript (all_records = [B][n_total] records in global blob order), this
-// shard's scalars r_b^(offset+i) and its partial sums (A, B)_b.  Requires phase 1 of the same group on this handle.
-static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, size_t offset, const KzgSettings* s) {
+// Phase 2: per batch b, r_b from its FULL transcript, this shard's scalars r_b^(offset+i) and its partial sums (A, B)_b.
+// Requires phase 1 of the same group on this handle.  The records come in one of three layouts:
+//   all_records != NULL, world == 0 : [B][n_total]          every batch's records in global blob order
+//   all_records != NULL, world  > 0 : [world][B][n]         as an all-gather of equal shards leaves them (n_total = world n)
+//   all_records == NULL             : the handle's own records of phase 1 (single rank: n_total = n)
+static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, size_t offset, const KzgSettings* s, size_t world = 0) {
     Workspace& w = s->ws;
     const size_t n = w.pending_n, B = w.pending_b;
+    if (!all_records) {
+        if (n_total != n || offset != 0) return fail(KZG_BADARGS, "local phase 2 needs n_total == n_local");
+        all_records = w.h_buf;
+        world = 0;
+    }
+    if (world && n_total != world * n) return fail(KZG_BADARGS, "gathered phase 2 needs equal shards");
     if (n_total == 1) {
         // verify_blob_kzg_proof path (:482-489): r^0 = 1, no batch challenge
         hipLaunchKernelGGL(k_single_scalars, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_z, w.d_y, w.d_scalars);
@@ -802,7 +815,9 @@ static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, s
             t[23] = (uint8_t)(FE_PER_BLOB & 0xff);
             for (int k = 0; k < 8; k++) t[24 + k] = (uint8_t)((uint64_t)n_total >> (56 - 8 * k));
             for (size_t b = b0; b < b1; b++) {
-                memcpy(t.data() + 32, all_records + 160 * n_total * b, 160 * n_total);
+                if (world == 0) memcpy(t.data() + 32, all_records + 160 * n_total * b, 160 * n_total);
+                else
+                    for (size_t k = 0; k < world; k++) memcpy(t.data() + 32 + 160 * n * k, all_records + 160 * n * (k * B + b), 160 * n);
                 uint8_t dg[32];
                 hostsha::digest(dg, t.data(), t.size());
                 while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r: at most two subtractions (2^256 < 3r)
@@ -882,11 +897,10 @@ static KzgRet finish_wait_locked(bool* ok /* B */, const KzgSettings* s) {
 
 static KzgRet batch_device_locked(bool* ok, const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n,
                                   const KzgSettings* s) {
-    std::vector<uint8_t> records(160 * n);
     KzgRet rc;
     if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, 1, s)) != KZG_OK) return rc;
-    if ((rc = phase1_wait_locked(records.data(), nullptr, s)) != KZG_OK) return rc;
-    if ((rc = phase2_launch_locked(records.data(), n, 0, s)) != KZG_OK) return rc;
+    if ((rc = phase1_wait_locked(nullptr, nullptr, s)) != KZG_OK) return rc;
+    if ((rc = phase2_launch_locked(nullptr, n, 0, s)) != KZG_OK) return rc;
     if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;  // same stream: no host round trip needed
     return finish_wait_locked(ok, s);
 }
@@ -905,12 +919,21 @@ extern "C" KzgRet kzg_shard_phase1_launch(const void* d_blobs, const void* d_com
     return phase1_launch_locked(d_blobs, d_commitments, d_proofs, n_local, n_batches, s);
 }
 extern "C" KzgRet kzg_shard_phase1_wait(uint8_t* records_out, uint8_t* bad_out, const KzgSettings* s) {
-    KZG_ENTER(s && records_out && s->ws.pending_n);
+    KZG_ENTER(s && s->ws.pending_n);
     return phase1_wait_locked(records_out, bad_out, s);
 }
 extern "C" KzgRet kzg_shard_phase2_launch(const uint8_t* all_records, size_t n_total, size_t offset, const KzgSettings* s) {
-    KZG_ENTER(s && all_records && s->ws.pending_n && offset + s->ws.pending_n <= n_total);
+    KZG_ENTER(s && s->ws.pending_n && offset + s->ws.pending_n <= n_total);
     return phase2_launch_locked(all_records, n_total, offset, s);
+}
+extern "C" KzgRet kzg_shard_phase2_launch_gathered(const uint8_t* gathered, size_t world, size_t rank, const KzgSettings* s) {
+    KZG_ENTER(s && gathered && s->ws.pending_n && world && rank < world);
+    return phase2_launch_locked(gathered, world * s->ws.pending_n, rank * s->ws.pending_n, s, world);
+}
+extern "C" KzgRet kzg_shard_records_device(void* d_records_out, const KzgSettings* s) {
+    KZG_ENTER(s && d_records_out && s->ws.pending_n);
+    HIPCHK(hipMemcpyAsync(d_records_out, s->ws.d_records, 160 * s->ws.pending_n * s->ws.pending_b, hipMemcpyDeviceToDevice, s->s1));
+    return KZG_OK;
 }
 extern "C" KzgRet kzg_shard_phase2_wait(uint8_t* partial_out, const KzgSettings* s) {
     KZG_ENTER(s && partial_out);
@@ -950,10 +973,9 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batches_device(bool* ok_out, uint8_t
     KZG_ENTER(s && ok_out && d_blobs && d_commitments && d_proofs && n && n_batches);
     KzgRet rc = ws_reserve(s, n * n_batches, n_batches, false);
     if (rc != KZG_OK) return rc;
-    std::vector<uint8_t> records(160 * n * n_batches);
     if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, n_batches, s)) != KZG_OK) return rc;
-    if ((rc = phase1_wait_locked(records.data(), err_out, s)) != KZG_OK) return rc;
-    if ((rc = phase2_launch_locked(records.data(), n, 0, s)) != KZG_OK) return rc;
+    if ((rc = phase1_wait_locked(nullptr, err_out, s)) != KZG_OK) return rc;
+    if ((rc = phase2_launch_locked(nullptr, n, 0, s)) != KZG_OK) return rc;
     if ((rc = finish_launch_locked(nullptr, 1, n_batches, s)) != KZG_OK) return rc;
     if ((rc = finish_wait_locked(ok_out, s)) != KZG_OK) return rc;
     if (err_out)

@@ -36,6 +36,8 @@ class HipBackend:
         L.kzg_shard_phase1_launch.argtypes = [vp, vp, vp, sz, sz, vp]
         L.kzg_shard_phase1_wait.argtypes = [u8, u8, vp]
         L.kzg_shard_phase2_launch.argtypes = [u8, sz, sz, vp]
+        L.kzg_shard_phase2_launch_gathered.argtypes = [vp, sz, sz, vp]
+        L.kzg_shard_records_device.argtypes = [vp, vp]
         L.kzg_shard_phase2_wait.argtypes = [u8, vp]
         L.kzg_shard_finish_launch.argtypes = [u8, sz, sz, vp]
         L.kzg_shard_finish_wait.argtypes = [C.POINTER(C.c_bool), vp]
@@ -62,13 +64,25 @@ class HipBackend:
         self._n, self._b = n_local, n_batches
         api._chk(api.lib().kzg_shard_phase1_launch(d_blobs, d_commitments, d_proofs, n_local, n_batches, self.settings._h))
 
-    def phase1_wait(self):
+    def phase1_wait(self, want_records=True):
+        """want_records=False leaves the records inside the handle (phase2_launch(None, ...) or the device exchange)."""
+        if not want_records:
+            api._chk(api.lib().kzg_shard_phase1_wait(None, None, self.settings._h))
+            return None
         out = C.create_string_buffer(RECORD_BYTES * self._n * self._b)
         api._chk(api.lib().kzg_shard_phase1_wait(out, None, self.settings._h))
         return out.raw
 
     def phase2_launch(self, all_records, n_total, offset):
+        """all_records None: the handle's own records (single rank)."""
         api._chk(api.lib().kzg_shard_phase2_launch(all_records, n_total, offset, self.settings._h))
+
+    # bulk exchange without host copies (equal shards): records leave through device memory, come back gathered
+    def records_to_device(self, d_ptr):
+        api._chk(api.lib().kzg_shard_records_device(d_ptr, self.settings._h))
+
+    def phase2_launch_gathered(self, h_ptr, world, rank):
+        api._chk(api.lib().kzg_shard_phase2_launch_gathered(h_ptr, world, rank, self.settings._h))
 
     def phase2_wait(self):
         out = C.create_string_buffer(PARTIAL_BYTES * self._b)
@@ -148,8 +162,12 @@ class PipelinedVerifier:
     The order is the same on every rank, so the collectives of different groups never interleave differently
     on different ranks.  With one rank the exchanges and the phase-2 host round trip disappear."""
 
-    def __init__(self, backends, dist=None, device="cpu", depth=(1, 1, 1)):
+    def __init__(self, backends, dist=None, device="cpu", depth=(1, 1, 1), equal_shards=False):
+        """equal_shards: every rank holds the same number of blobs of every batch - enables the bulk exchange (records
+        go from the library's device buffer straight into the all-gather and come back through one pinned buffer)."""
         self.backends = backends
+        self.equal_shards = equal_shards
+        self._bufs = {}
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.device = device
         self.depth = depth if self.dist else (depth[0], 0, depth[2])
@@ -160,25 +178,60 @@ class PipelinedVerifier:
         per_rank = [[g[i * (len(g) // n_batches): (i + 1) * (len(g) // n_batches)] for i in range(n_batches)] for g in gathered]
         return b"".join(per_rank[r][b] for b in range(n_batches) for r in range(len(gathered)))
 
+    def _exchange_buffers(self, slot, nbytes):
+        """Per handle: device send buffer, gathered receive buffer and its pinned host mirror (cached by size)."""
+        import torch
+        world = self.dist.get_world_size()
+        key = (slot, nbytes)
+        if key not in self._bufs:
+            on_gpu = str(self.device) != "cpu"
+            send = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+            recv = torch.empty(world * nbytes, dtype=torch.uint8, device=self.device)
+            host = torch.empty(world * nbytes, dtype=torch.uint8, pin_memory=True) if on_gpu else recv
+            self._bufs[key] = (send, recv, host)
+        return self._bufs[key]
+
     def run(self, groups):
         """groups: list of ((d_blobs, d_commitments, d_proofs, n_local), n_batches): this rank's shard of every batch
         of the group, batches contiguous.  Returns the per-batch results of every group, in order."""
+        import torch
         K, S = len(groups), len(self.backends)
         d1, d2, d3 = self.depth
         results = [None] * K
+        # bulk path: equal shards on every rank and a backend that can hand its records over in device memory
+        bulk = bool(self.dist) and self.equal_shards and hasattr(self.backends[0], "records_to_device")
         for t in range(K + d1 + d2 + d3):
             if t < K:
-                self.backends[t % S].phase1_launch(groups[t][0], groups[t][1])
+                b = self.backends[t % S]
+                b.phase1_launch(groups[t][0], groups[t][1])
+                if bulk:
+                    send, _, _ = self._exchange_buffers(t % S, RECORD_BYTES * groups[t][0][3] * groups[t][1])
+                    b.records_to_device(send.data_ptr())
             i = t - d1
             if 0 <= i < K:
                 b, nb = self.backends[i % S], groups[i][1]
-                recs = b.phase1_wait()
-                if self.dist:
+                if bulk:
+                    world, rank = self.dist.get_world_size(), self.dist.get_rank()
+                    send, recv, host = self._exchange_buffers(i % S, RECORD_BYTES * groups[i][0][3] * nb)
+                    b.phase1_wait(want_records=False)  # the handle's stream is drained: `send` is complete
+                    src = send if recv.is_cuda else send.cpu()
+                    self.dist.all_gather(list(recv.chunk(world)), src)  # exchange 1, [world][batch][n_local] records
+                    if recv.is_cuda:
+                        host.copy_(recv, non_blocking=True)
+                        torch.cuda.current_stream().synchronize()
+                    b.phase2_launch_gathered(host.data_ptr(), world, rank)
+                elif self.dist:
+                    recs = b.phase1_wait()
                     gathered = _all_gather_bytes(self.dist, recs, self.device)
                     counts = [len(g) // RECORD_BYTES // nb for g in gathered]
                     b.phase2_launch(self._regroup(gathered, nb), sum(counts), sum(counts[: self.dist.get_rank()]))
                 else:
-                    b.phase2_launch(recs, len(recs) // RECORD_BYTES // nb, 0)
+                    if hasattr(b, "records_to_device"):  # the records never leave the handle
+                        b.phase1_wait(want_records=False)
+                        b.phase2_launch(None, groups[i][0][3], 0)
+                    else:
+                        recs = b.phase1_wait()
+                        b.phase2_launch(recs, len(recs) // RECORD_BYTES // nb, 0)
                     b.finish_launch(None, 1)
             j = t - d1 - d2
             if self.dist and 0 <= j < K:

@@ -57,7 +57,7 @@ def _worker(rank, world, port, scenario, q):
         b[64:96] = R.to_bytes(32, "big")
         blobs[6] = bytes(b)
     n = len(blobs)
-    if scenario == "pipelined":
+    if scenario.startswith("pipelined"):
         # three launch groups (2, 1, 2 batches) of 6-blob batches, every rank holding 6 / world blobs of each batch
         def batch(rot, corrupt=False):
             t = (tuples[rot:] + tuples[:rot])[:6]
@@ -78,7 +78,7 @@ def _worker(rank, world, port, scenario, q):
             keep.append(t)
             groups.append(((db, dc, dp, per), len(grp)))
         handles = [st] + [api.KzgSettings.load_trusted_setup_file() for _ in range(2)]
-        pipe = PipelinedVerifier([HipBackend(h) for h in handles], dist, "cpu", (1, 0, 1))
+        pipe = PipelinedVerifier([HipBackend(h) for h in handles], dist, "cpu", (1, 0, 1), equal_shards=scenario == "pipelined_bulk")
         got = [x for res in pipe.run(groups) for x in res]
         q.put((rank, got, want))
     else:
@@ -122,7 +122,9 @@ def test_sharded_hip_path_matches_oracle(world, scenario):
         assert got == want == expected, (rank, got, want)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_pipelined_groups_hip_path(world):
-    for rank, got, want in _run(world, "pipelined"):
+@pytest.mark.parametrize("world,scenario", [(2, "pipelined"), (3, "pipelined"), (2, "pipelined_bulk"), (3, "pipelined_bulk")])
+def test_pipelined_groups_hip_path(world, scenario):
+    """Launch groups through the fixed-order pipeline: the byte-string exchange (any shard sizes) and the bulk exchange
+    (equal shards: records leave the library in device memory, come back as one gathered buffer)."""
+    for rank, got, want in _run(world, scenario):
         assert got == want == [True, False, True, True, True], (rank, got, want)
