@@ -66,6 +66,14 @@ KzgRet kzg_settings_from_tau_g2(KzgSettings **out, const uint8_t tau_g2[96]);
 void kzg_settings_free(KzgSettings *s);
 /* roots_of_unity[i] as 32 big-endian bytes (i < 4096), for parity tests of the settings tables. */
 KzgRet kzg_settings_root_of_unity(const KzgSettings *s, size_t i, uint8_t out[32]);
+/* The rest of the trusted setup (handles made by kzg_settings_load_trusted_setup only; verification does not read it):
+ * g1_points[i] after the bit-reversal permutation of build.rs:79,89-105 (i < 4096, 48 compressed bytes) and
+ * g2_points[i] (i < the file's G2 count, 96 bytes), both re-compressed from the device-side decoded tables; and
+ * is_trusted_setup_in_lagrange_form (build.rs:107-129): e(g1[1], g2[0]) == e(g1[0], g2[1]) on the FILE order -
+ * false for the Lagrange-form file the crate ships (the reference computes and discards it). */
+KzgRet kzg_settings_g1_point(const KzgSettings *s, size_t i, uint8_t out[48]);
+KzgRet kzg_settings_g2_point(const KzgSettings *s, size_t i, uint8_t out[96]);
+KzgRet kzg_settings_is_monomial_form(bool *ok, const KzgSettings *s);
 /* g2_points[1] re-compressed from the device-side decompressed point (round-trip check). */
 KzgRet kzg_settings_tau_g2(const KzgSettings *s, uint8_t out[96]);
 
@@ -140,6 +148,11 @@ KzgRet kzg_shard_finish_wait(bool *ok /* n_batches */, const KzgSettings *s);
 KzgRet kzg_verify_blob_kzg_proof_batches_device(bool *ok_out, uint8_t *err_out, const void *d_blobs,
                                                 const void *d_commitments, const void *d_proofs, size_t n,
                                                 size_t n_batches, const KzgSettings *s);
+
+/* Prover side (not in the reference - c-kzg-4844's blob_to_kzg_commitment): C_b = sum_i blob_b[i] *
+ * g1_points[i], one 4096-term MSM per blob over the settings' Lagrange points.  blobs: n * 131072 bytes (host), out:
+ * n * 48 bytes.  KZG_BADARGS for a non-canonical field element, or settings without G1 points. */
+KzgRet kzg_blob_to_kzg_commitment(uint8_t *out48, const uint8_t *blobs, size_t n, const KzgSettings *s);
 
 /* ---- pieces of the path, exposed for parity tests and the per-kernel benchmarks ---- */
 /* compute_challenge (src/kzg_proof.rs:46-72) for n blobs: z_out = n * 32 bytes, big-endian canonical.

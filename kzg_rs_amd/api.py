@@ -73,6 +73,10 @@ def lib():
         L.kzg_settings_free.restype = None
         L.kzg_settings_root_of_unity.argtypes = [vp, sz, u8]
         L.kzg_settings_tau_g2.argtypes = [vp, u8]
+        L.kzg_settings_g1_point.argtypes = [vp, sz, u8]
+        L.kzg_settings_g2_point.argtypes = [vp, sz, u8]
+        L.kzg_settings_is_monomial_form.argtypes = [bp, vp]
+        L.kzg_blob_to_kzg_commitment.argtypes = [u8, u8, sz, vp]
         L.kzg_verify_kzg_proof.argtypes = [bp, u8, u8, u8, u8, vp]
         L.kzg_verify_kzg_proof_batch.argtypes = [bp, u8, u8, u8, u8, sz, vp]
         L.kzg_verify_blob_kzg_proof.argtypes = [bp, u8, u8, u8, vp]
@@ -146,6 +150,13 @@ class KzgSettings:
         return cls(h)
 
     @classmethod
+    def load_trusted_setup_text(cls, txt):
+        """The same parser on text held in memory (bytes)."""
+        h = C.c_void_p()
+        _chk(lib().kzg_settings_load_trusted_setup(C.byref(h), bytes(txt), len(txt)))
+        return cls(h)
+
+    @classmethod
     def from_tau_g2(cls, tau_g2):
         """EnvKzgSettings::Custom (src/trusted_setup.rs:52-57) from g2_points[1] alone."""
         h = C.c_void_p()
@@ -161,6 +172,23 @@ class KzgSettings:
         out = C.create_string_buffer(96)
         _chk(lib().kzg_settings_tau_g2(self._h, out))
         return out.raw
+
+    def g1_point(self, i):
+        """g1_points[i] (bit-reversal permuted, build.rs:79) as 48 compressed bytes."""
+        out = C.create_string_buffer(48)
+        _chk(lib().kzg_settings_g1_point(self._h, i, out))
+        return out.raw
+
+    def g2_point(self, i):
+        out = C.create_string_buffer(96)
+        _chk(lib().kzg_settings_g2_point(self._h, i, out))
+        return out.raw
+
+    def is_monomial_form(self):
+        """build.rs:107-129 (the reference computes this at load time and discards it)."""
+        ok = C.c_bool(False)
+        _chk(lib().kzg_settings_is_monomial_form(C.byref(ok), self._h))
+        return bool(ok.value)
 
     def last_timings(self):
         t = (C.c_float * 8)()
@@ -309,6 +337,15 @@ def pairing_check(a, b, kzg_settings):
     ok = C.c_bool(False)
     _chk(lib().kzg_pairing_check(C.byref(ok), a, b, kzg_settings._h))
     return bool(ok.value)
+
+
+def blob_to_kzg_commitment(blobs, kzg_settings):
+    """Prover side (not in the reference; c-kzg-4844's name): commitments of a list of blobs (bytes) under the
+    settings' Lagrange G1 points, as 48-byte strings."""
+    n = len(blobs)
+    out = C.create_string_buffer(48 * max(n, 1))
+    _chk(lib().kzg_blob_to_kzg_commitment(out, b"".join(blobs), n, kzg_settings._h))
+    return [out.raw[48 * i: 48 * i + 48] for i in range(n)]
 
 
 def g1_mul_generator(scalars, kzg_settings):

@@ -60,6 +60,55 @@ __global__ void k_g2_decompress(const uint8_t* __restrict__ bytes, Fp* __restric
     *flag = st;
 }
 
+// n G2 points, one per workgroup (trusted-setup load: build.rs:73, from_compressed_unchecked)
+__global__ void k_g2_decompress_n(const uint8_t* __restrict__ bytes, Fp* __restrict__ out4, uint32_t* __restrict__ flag) {
+    if (threadIdx.x) return;
+    const int i = blockIdx.x;
+    G2Aff q;
+    q.x.c0 = q.x.c1 = q.y.c0 = q.y.c1 = FpF::zero();
+    uint32_t st = g2_decompress(q, bytes + 96 * (size_t)i);
+    out4[4 * i] = q.x.c0;
+    out4[4 * i + 1] = q.x.c1;
+    out4[4 * i + 2] = q.y.c0;
+    out4[4 * i + 3] = q.y.c1;
+    flag[i] = st;
+}
+
+// affine points -> 48 compressed bytes (flag != 0: the identity encoding)
+__global__ void k_aff_compress(const G1Aff* __restrict__ pts, const uint32_t* __restrict__ flag, uint8_t* __restrict__ out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g1_compress(out + 48 * (size_t)i, pts[i], flag[i] != 0);
+}
+
+// blob bytes -> MSM scalars: element i of blob b (32 big-endian bytes) as plain little-endian limbs; status[b] |= 1
+// when an element is >= r (src/dtypes.rs:48-57)
+__global__ void k_blob_scalars(const uint8_t* __restrict__ blobs, Fr* __restrict__ scalars, uint32_t* __restrict__ status, int total) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const uint4* src = reinterpret_cast<const uint4*>(blobs) + 2 * (size_t)t;
+    Fr v = fr_from_be_words(src[0], src[1]);
+    if (FrF::geq_mod(v)) atomicOr(&status[t / FE_PER_BLOB], 1u);
+    scalars[t] = v;
+}
+
+// term tables of n_out independent MSMs over the same 4096 points: term t of output b = (point t, scalar b * 4096 + t)
+__global__ void k_commit_terms(uint32_t* __restrict__ term_point, uint32_t* __restrict__ term_scalar, int total) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    term_point[t] = t % FE_PER_BLOB;
+    term_scalar[t] = t;
+}
+
+// Jacobian -> compressed, one point per thread
+__global__ void k_jac_compress_n(const G1Jac* __restrict__ p, uint8_t* __restrict__ out, int count) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    G1Aff a;
+    bool finite = g1_to_affine(a, p[i]);
+    g1_compress(out + 48 * (size_t)i, a, !finite);
+}
+
 __global__ void k_g2_generator(Fp* __restrict__ out4) {
     if (threadIdx.x || blockIdx.x) return;
     out4[0] = fp_const(consts::G2_GEN_X0_MONT);
@@ -392,6 +441,14 @@ struct KzgSettings {
     Fp* d_tau4 = nullptr;   // [tau]G2 affine (x.c0 x.c1 y.c0 y.c1), Montgomery
     Fp* d_prep = nullptr;   // prepared lines: [tau]G2 then generator (2 * 408 Fp)
     G1Jac* d_gen_mult = nullptr;  // G, 2^64 G, -phi(G), -phi(2^64 G)
+    // full trusted setup (kzg_settings_load_trusted_setup only; not needed by verification):
+    G1Aff* d_g1 = nullptr;            // g1_points, bit-reversal permuted (build.rs:79,89-105), 4096 entries
+    uint32_t* d_g1_flag = nullptr;    // 0 finite / 1 identity (unchecked decode, build.rs:68)
+    G1Jac* d_g1_mult = nullptr;       // their MSM multiples (msm.hpp), valid iff g1_in_subgroup
+    bool g1_in_subgroup = false;      // every G1 point lies in the r-torsion (what the GLV multiples need)
+    Fp* d_g2 = nullptr;               // g2_points (monomial), n_g2 x 4 Fp
+    size_t n_g2 = 0;
+    uint8_t g1_first[2][48] = {};     // g1_points[0], [1] of the FILE order, for the monomial-form check (build.rs:107-129)
     DevProgram prep, verify;
     hipStream_t s1 = nullptr, s2 = nullptr;
     hipEvent_t ev[12] = {};
@@ -527,19 +584,82 @@ extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char*
     long n2 = strtol(std::string(lines[1].first, lines[1].second).c_str(), nullptr, 10);
     if (n1 != FE_PER_BLOB) return fail(KZG_BAD_SETUP, "trusted setup: expected 4096 G1 points");
     if (n2 < 2 || (long)lines.size() < 2 + n1 + n2) return fail(KZG_BAD_SETUP, "trusted setup: truncated file");
-    for (long i = 0; i < n1; i++)
-        if (lines[2 + i].second != 96) return fail(KZG_BAD_SETUP, "trusted setup: bad G1 line length");
-    uint8_t g2[2][96];
-    for (int k = 0; k < 2; k++) {
-        auto& ln = lines[2 + n1 + k];
-        if (ln.second != 192) return fail(KZG_BAD_SETUP, "trusted setup: bad G2 line length");
-        for (int i = 0; i < 96; i++) {
+    // hex -> bytes for every point line (hex_to_bytes, build.rs:15-21: KzgError::InvalidHexFormat)
+    auto unhex = [&](uint8_t* dst, const std::pair<const char*, size_t>& ln, size_t nbytes) {
+        if (ln.second != 2 * nbytes) return false;
+        for (size_t i = 0; i < nbytes; i++) {
             int a = hexnib(ln.first[2 * i]), b = hexnib(ln.first[2 * i + 1]);
-            if (a < 0 || b < 0) return fail(KZG_BAD_SETUP, "trusted setup: bad hex");  // KzgError::InvalidHexFormat
-            g2[k][i] = (uint8_t)(a << 4 | b);
+            if (a < 0 || b < 0) return false;
+            dst[i] = (uint8_t)(a << 4 | b);
         }
+        return true;
+    };
+    std::vector<uint8_t> g1b(48 * (size_t)n1), g2b(96 * (size_t)n2);
+    uint8_t first[2][48];
+    for (long i = 0; i < n1; i++) {
+        // stored bit-reversal permuted (build.rs:79,89-105): file line i -> slot brp(i)
+        uint8_t tmp[48];
+        if (!unhex(tmp, lines[2 + i], 48)) return fail(KZG_BAD_SETUP, "trusted setup: bad G1 line");
+        if (i < 2) memcpy(first[i], tmp, 48);
+        uint32_t r = 0;
+        for (int k = 0; k < 12; k++) r |= ((uint32_t)(i >> k) & 1u) << (11 - k);
+        memcpy(g1b.data() + 48 * (size_t)r, tmp, 48);
     }
-    return settings_common(out, g2[1]);
+    for (long i = 0; i < n2; i++)
+        if (!unhex(g2b.data() + 96 * (size_t)i, lines[2 + n1 + i], 96)) return fail(KZG_BAD_SETUP, "trusted setup: bad G2 line");
+    KzgRet rc = settings_common(out, g2b.data() + 96);
+    if (rc != KZG_OK) return rc;
+    KzgSettings* s = *out;
+    *out = nullptr;
+    auto bail = [&](KzgRet code, const char* msg) {
+        kzg_settings_free(s);
+        return fail(code, msg);
+    };
+    memcpy(s->g1_first, first, sizeof first);
+    // G1 Lagrange points: unchecked decode (build.rs:66-70) for the table, and the decode + subgroup test + multiples
+    // pass of the MSM (msm.hpp) so that commitments can be computed against them
+    uint8_t* d_bytes;
+    uint32_t *d_flag2, *d_gflag;
+    G1Aff* d_tmp;
+    const int N = (int)n1;
+    HIPCHK(hipMalloc(&d_bytes, std::max(g1b.size(), g2b.size())));
+    HIPCHK(hipMalloc(&d_flag2, 4 * (size_t)N));
+    HIPCHK(hipMalloc(&d_tmp, sizeof(G1Aff) * (size_t)N));
+    HIPCHK(hipMalloc(&s->d_g1, sizeof(G1Aff) * (size_t)N));
+    HIPCHK(hipMalloc(&s->d_g1_flag, 4 * (size_t)N));
+    HIPCHK(hipMalloc(&s->d_g1_mult, sizeof(G1Jac) * MSM_CHUNKS * (size_t)N));
+    HIPCHK(hipMemcpyAsync(d_bytes, g1b.data(), g1b.size(), hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, s->d_g1, s->d_g1_flag, N, 0);
+    hipLaunchKernelGGL(k_g1_decode_multiples, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp, d_flag2,
+                       s->d_g1_mult, N, N);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> f1((size_t)N), f2((size_t)N);
+    HIPCHK(hipMemcpyAsync(f1.data(), s->d_g1_flag, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(f2.data(), d_flag2, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    s->g1_in_subgroup = true;
+    for (int i = 0; i < N; i++) {
+        if (f1[i] == G1_INVALID) return bail(KZG_BAD_SETUP, "load_trusted_setup Invalid g1 bytes");
+        if (f2[i] == G1_INVALID) s->g1_in_subgroup = false;
+    }
+    // G2 monomial points: all of them decoded (build.rs:72-75); verification itself reads only [1]
+    s->n_g2 = (size_t)n2;
+    HIPCHK(hipMalloc(&s->d_g2, sizeof(Fp) * 4 * (size_t)n2));
+    HIPCHK(hipMalloc(&d_gflag, 4 * (size_t)n2));
+    HIPCHK(hipMemcpyAsync(d_bytes, g2b.data(), g2b.size(), hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_g2_decompress_n, dim3((unsigned)n2), dim3(64), 0, s->s1, d_bytes, s->d_g2, d_gflag);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> fg((size_t)n2);
+    HIPCHK(hipMemcpyAsync(fg.data(), d_gflag, 4 * (size_t)n2, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipFree(d_bytes));
+    HIPCHK(hipFree(d_flag2));
+    HIPCHK(hipFree(d_gflag));
+    HIPCHK(hipFree(d_tmp));
+    for (long i = 0; i < n2; i++)
+        if (fg[(size_t)i] == G1_INVALID) return bail(KZG_BAD_SETUP, "load_trusted_setup Invalid g2 bytes");
+    *out = s;
+    return KZG_OK;
 }
 
 extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_g2[96]) {
@@ -560,7 +680,7 @@ static void ws_free(Workspace& w) {
 extern "C" void kzg_settings_free(KzgSettings* s) {
     if (!s) return;
     ws_free(s->ws);
-    void* ptrs[] = {s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_tau4, s->d_prep, s->d_gen_mult, s->prep.blob, s->verify.blob};
+    void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_tau4, s->d_prep, s->d_gen_mult, s->prep.blob, s->verify.blob};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : s->ev)
@@ -1329,6 +1449,108 @@ extern "C" KzgRet kzg_settings_tau_g2(const KzgSettings* s, uint8_t out[96]) {
     HIPCHK(hipStreamSynchronize(s->s1));
     HIPCHK(hipFree(d));
     return KZG_OK;
+}
+
+extern "C" KzgRet kzg_settings_g1_point(const KzgSettings* s, size_t i, uint8_t out[48]) {
+    if (!s || !out || i >= FE_PER_BLOB) return fail(KZG_BADARGS, "bad argument");
+    if (!s->d_g1) return fail(KZG_BADARGS, "these settings were not loaded from a trusted-setup file");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    uint8_t* d;
+    HIPCHK(hipMalloc(&d, 48));
+    hipLaunchKernelGGL(k_aff_compress, dim3(1), dim3(64), 0, s->s1, s->d_g1 + i, s->d_g1_flag + i, d, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d, 48, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipFree(d));
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_settings_g2_point(const KzgSettings* s, size_t i, uint8_t out[96]) {
+    if (!s || !out) return fail(KZG_BADARGS, "bad argument");
+    if (!s->d_g2 || i >= s->n_g2) return fail(KZG_BADARGS, "no such G2 point in these settings");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    uint8_t* d;
+    HIPCHK(hipMalloc(&d, 96));
+    hipLaunchKernelGGL(k_g2_compress, dim3(1), dim3(64), 0, s->s1, s->d_g2 + 4 * i, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d, 96, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipFree(d));
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_pairing_check(bool* ok, const uint8_t a[48], const uint8_t b[48], const KzgSettings* s);
+// is_trusted_setup_in_lagrange_form (build.rs:107-129; its result is discarded by the reference's loader):
+// e(g1[1], g2[0]) == e(g1[0], g2[1]) on the points in FILE order - true for a monomial-form G1 section, false for the
+// Lagrange-form file the crate ships.
+extern "C" KzgRet kzg_settings_is_monomial_form(bool* ok, const KzgSettings* s) {
+    if (!s || !ok) return fail(KZG_BADARGS, "null argument");
+    if (!s->d_g1) return fail(KZG_BADARGS, "these settings were not loaded from a trusted-setup file");
+    return kzg_pairing_check(ok, s->g1_first[0], s->g1_first[1], s);  // e(g1[0], [tau]G2) == e(g1[1], G2)
+}
+
+// blob_to_kzg_commitment (prover side; c-kzg-4844's name - the reference has no prover):
+// C_b = sum_i blob_b[i] * g1_points[i], one 4096-term MSM per blob over the settings' Lagrange points, all blobs of the
+// call in one launch of the MSM kernels.  blobs: n * 131072 bytes, host memory; out: n * 48 bytes.
+extern "C" KzgRet kzg_blob_to_kzg_commitment(uint8_t* out48, const uint8_t* blobs, size_t n, const KzgSettings* s) {
+    if (!s || (n && (!out48 || !blobs))) return fail(KZG_BADARGS, "null argument");
+    if (!s->d_g1_mult) return fail(KZG_BADARGS, "these settings were not loaded from a trusted-setup file");
+    if (!s->g1_in_subgroup) return fail(KZG_BAD_SETUP, "a G1 setup point is outside the r-torsion subgroup");
+    if (n == 0) return KZG_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    const size_t CH = 64;  // blobs per launch
+    uint8_t *d_blobs, *d_out;
+    Fr* d_sc;
+    uint32_t *d_tp, *d_ts, *d_sorted, *d_status;
+    G1Jac *d_win, *d_res;
+    const size_t NT = (size_t)FE_PER_BLOB;
+    HIPCHK(hipMalloc(&d_blobs, (size_t)BLOB_BYTES * CH));
+    HIPCHK(hipMalloc(&d_sc, sizeof(Fr) * NT * CH));
+    HIPCHK(hipMalloc(&d_tp, 4 * NT * CH));
+    HIPCHK(hipMalloc(&d_ts, 4 * NT * CH));
+    HIPCHK(hipMalloc(&d_sorted, 4 * NT * CH * MSM_WINDOWS));
+    HIPCHK(hipMalloc(&d_status, 4 * CH));
+    HIPCHK(hipMalloc(&d_win, sizeof(G1Jac) * MSM_WINDOWS * CH));
+    HIPCHK(hipMalloc(&d_res, sizeof(G1Jac) * CH));
+    HIPCHK(hipMalloc(&d_out, 48 * CH));
+    KzgRet rc = KZG_OK;
+    for (size_t lo = 0; lo < n && rc == KZG_OK; lo += CH) {
+        const size_t m = std::min(CH, n - lo);
+        const int total = (int)(m * NT);
+        if (hipMemcpyAsync(d_blobs, blobs + (size_t)BLOB_BYTES * lo, (size_t)BLOB_BYTES * m, hipMemcpyHostToDevice, s->s1) != hipSuccess ||
+            hipMemsetAsync(d_status, 0, 4 * m, s->s1) != hipSuccess) { rc = fail(KZG_ERROR, "HIP copy failed"); break; }
+        hipLaunchKernelGGL(k_blob_scalars, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->s1, d_blobs, d_sc, d_status, total);
+        hipLaunchKernelGGL(k_commit_terms, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->s1, d_tp, d_ts, total);
+        hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->s1, d_sc, total);
+        MsmDesc d{};
+        d.mult = s->d_g1_mult;
+        d.pflag = s->d_g1_flag;
+        d.scalars = d_sc;
+        d.term_point = d_tp;
+        d.term_scalar = d_ts;
+        d.sorted = d_sorted;
+        d.window_sums = d_win;
+        d.nterms[0] = d.nterms[1] = (int)NT;
+        d.max_terms = (int)NT;
+        d.stride = (int)NT;
+        d.chunks_per_block = m >= 16 ? 4 : 1;
+        const unsigned slots = MSM_CHUNKS / d.chunks_per_block;
+        hipLaunchKernelGGL(k_msm_window, dim3(8, slots, (unsigned)m), dim3(256), 0, s->s1, d);
+        hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)m), dim3(64), 0, s->s1, d_win, d_res, (int)slots);
+        hipLaunchKernelGGL(k_jac_compress_n, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s->s1, d_res, d_out, (int)m);
+        std::vector<uint32_t> st(m);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out48 + 48 * lo, d_out, 48 * m, hipMemcpyDeviceToHost, s->s1) != hipSuccess ||
+            hipMemcpyAsync(st.data(), d_status, 4 * m, hipMemcpyDeviceToHost, s->s1) != hipSuccess ||
+            hipStreamSynchronize(s->s1) != hipSuccess) { rc = fail(KZG_ERROR, "HIP launch failed"); break; }
+        for (size_t i = 0; i < m; i++)
+            if (st[i]) rc = fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");  // (sic) Blob::as_polynomial, src/dtypes.rs:48-57
+    }
+    void* ptrs[] = {d_blobs, d_sc, d_tp, d_ts, d_sorted, d_status, d_win, d_res, d_out};
+    for (void* q : ptrs) (void)hipFree(q);
+    return rc;
 }
 
 // diagnostic / test hook: the host-side SHA-256 used for the batch transcript (force_portable skips SHA-NI)

@@ -45,6 +45,65 @@ def test_settings_tables(settings, osettings):
     assert settings.tau_g2() == osettings.g2(1)
 
 
+def test_trusted_setup_loader_full(settings):
+    """The whole file, not just what verification reads (build.rs:23-105): all 4096 G1 Lagrange points after the
+    bit-reversal permutation and all 65 G2 points survive decode -> re-compress; the Lagrange-form file is not in
+    monomial form (build.rs:107-129, computed and discarded by the reference)."""
+    ost = O.Settings.mainnet(load_g1=True)
+    ts = open(os.path.join(O.ROOT, "kzg_rs_amd", "data", "trusted_setup.txt")).read().split("\n")
+    brp = lambda i: int(format(i, "012b")[::-1], 2)
+    for i in list(range(0, 4096, 37)) + [1, 2, 4095, 2048]:
+        got = settings.g1_point(i)
+        assert got == ost.g1(i) == bytes.fromhex(ts[2 + brp(i)]), i
+    for i in range(65):
+        assert settings.g2_point(i).hex() == ts[2 + 4096 + i], i
+    assert settings.is_monomial_form() is False
+    with pytest.raises(KzgError):
+        settings.g2_point(65)
+
+
+def test_monomial_form_setup_detected():
+    """A monomial-form G1 section ([tau^i]G1) under the known-tau test setup: the same check returns true."""
+    from kzg_rs_amd import synth
+    tau, tau_g2 = synth.synthetic_setup()
+    st0 = KzgSettings.from_tau_g2(tau_g2)
+    with pytest.raises(KzgError):
+        st0.g1_point(0)  # custom handles carry no G1 section
+    pw, acc = [], 1
+    for _ in range(4096):
+        pw.append(acc.to_bytes(32, "big"))
+        acc = acc * tau % R
+    g1 = api.g1_mul_generator(pw, st0)
+    g2gen = open(os.path.join(O.ROOT, "kzg_rs_amd", "data", "trusted_setup.txt")).read().split("\n")[2 + 4096]
+    txt = "4096\n2\n" + "\n".join(p.hex() for p in g1) + "\n" + g2gen + "\n" + tau_g2.hex() + "\n"
+    st = KzgSettings.load_trusted_setup_text(txt.encode())
+    assert st.is_monomial_form() is True
+    assert st.g1_point(0) == G1_GEN and st.g1_point(2048) == g1[1]  # bit-reversal: file line 1 -> slot 2048
+
+
+def test_blob_to_kzg_commitment(settings):
+    """Prover-side MSM over the Lagrange points: must reproduce the commitment of every valid
+    mainnet vector, agree with the oracle's MSM on random blobs, and reject a non-canonical element."""
+    tuples = G.valid_blob_tuples()
+    assert api.blob_to_kzg_commitment([t[0] for t in tuples], settings) == [t[1] for t in tuples]
+    ost = O.Settings.mainnet(load_g1=True)
+    pts = b"".join(ost.g1(i) for i in range(4096))
+    rng = random.Random(12)
+    blobs = [_rand_blob(rng) for _ in range(3)] + [bytes(131072), _rand_blob(rng, "edge")]
+    got = api.blob_to_kzg_commitment(blobs, settings)
+    for b, c in zip(blobs, got):
+        assert c == O.g1_msm(pts, b, 4096)
+    assert got[3] == G1_INF
+    assert api.blob_to_kzg_commitment([], settings) == []
+    bad = bytearray(blobs[0])
+    bad[32 * 100: 32 * 101] = R.to_bytes(32, "big")
+    with pytest.raises(KzgError):
+        api.blob_to_kzg_commitment([blobs[1], bytes(bad)], settings)
+    # 70 blobs: more than one launch chunk, merged-chunk MSM blocks
+    many = [tuples[i % 7][0] for i in range(70)]
+    assert api.blob_to_kzg_commitment(many, settings) == [tuples[i % 7][1] for i in range(70)]
+
+
 # ------------------------------------------------------------------ the reference's three vector tests
 def test_verify_kzg_proof(settings):
     """src/kzg_proof.rs:604-631 over the 122 vectors; strict: null <=> Err."""
