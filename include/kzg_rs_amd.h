@@ -153,6 +153,14 @@ KzgRet kzg_verify_blob_kzg_proof_batches_device(bool *ok_out, uint8_t *err_out, 
  * g1_points[i], one 4096-term MSM per blob over the settings' Lagrange points.  blobs: n * 131072 bytes (host), out:
  * n * 48 bytes.  KZG_BADARGS for a non-canonical field element, or settings without G1 points. */
 KzgRet kzg_blob_to_kzg_commitment(uint8_t *out48, const uint8_t *blobs, size_t n, const KzgSettings *s);
+/* c-kzg-4844's compute_kzg_proof for n (blob, z) pairs: ys_out[i] = p_i(z_i) (32 bytes big-endian), proofs_out[i] =
+ * commitment to the quotient (p_i(X) - y_i) / (X - z_i) (48 bytes), z = a root of unity included.  zs: n * 32 bytes
+ * big-endian canonical.  And compute_blob_kzg_proof: the same at z = compute_challenge(blob, commitment)
+ * (src/kzg_proof.rs:46-72) - the proof verify_blob_kzg_proof accepts.  Host pointers. */
+KzgRet kzg_compute_kzg_proof(uint8_t *proofs_out, uint8_t *ys_out, const uint8_t *blobs, const uint8_t *zs, size_t n,
+                             const KzgSettings *s);
+KzgRet kzg_compute_blob_kzg_proof(uint8_t *proofs_out, const uint8_t *blobs, const uint8_t *commitments, size_t n,
+                                  const KzgSettings *s);
 
 /* ---- pieces of the path, exposed for parity tests and the per-kernel benchmarks ---- */
 /* compute_challenge (src/kzg_proof.rs:46-72) for n blobs: z_out = n * 32 bytes, big-endian canonical.

@@ -77,6 +77,8 @@ def lib():
         L.kzg_settings_g2_point.argtypes = [vp, sz, u8]
         L.kzg_settings_is_monomial_form.argtypes = [bp, vp]
         L.kzg_blob_to_kzg_commitment.argtypes = [u8, u8, sz, vp]
+        L.kzg_compute_kzg_proof.argtypes = [u8, u8, u8, u8, sz, vp]
+        L.kzg_compute_blob_kzg_proof.argtypes = [u8, u8, u8, sz, vp]
         L.kzg_verify_kzg_proof.argtypes = [bp, u8, u8, u8, u8, vp]
         L.kzg_verify_kzg_proof_batch.argtypes = [bp, u8, u8, u8, u8, sz, vp]
         L.kzg_verify_blob_kzg_proof.argtypes = [bp, u8, u8, u8, vp]
@@ -346,6 +348,22 @@ def blob_to_kzg_commitment(blobs, kzg_settings):
     out = C.create_string_buffer(48 * max(n, 1))
     _chk(lib().kzg_blob_to_kzg_commitment(out, b"".join(blobs), n, kzg_settings._h))
     return [out.raw[48 * i: 48 * i + 48] for i in range(n)]
+
+
+def compute_kzg_proof(blobs, zs, kzg_settings):
+    """c-kzg-4844's compute_kzg_proof for lists of blobs and 32-byte big-endian z: -> (proofs, ys)."""
+    n = len(blobs)
+    pr, ys = C.create_string_buffer(48 * max(n, 1)), C.create_string_buffer(32 * max(n, 1))
+    _chk(lib().kzg_compute_kzg_proof(pr, ys, b"".join(blobs), b"".join(zs), n, kzg_settings._h))
+    return [pr.raw[48 * i: 48 * i + 48] for i in range(n)], [ys.raw[32 * i: 32 * i + 32] for i in range(n)]
+
+
+def compute_blob_kzg_proof(blobs, commitments, kzg_settings):
+    """c-kzg-4844's compute_blob_kzg_proof: the proofs verify_blob_kzg_proof accepts."""
+    n = len(blobs)
+    pr = C.create_string_buffer(48 * max(n, 1))
+    _chk(lib().kzg_compute_blob_kzg_proof(pr, b"".join(blobs), b"".join(commitments), n, kzg_settings._h))
+    return [pr.raw[48 * i: 48 * i + 48] for i in range(n)]
 
 
 def g1_mul_generator(scalars, kzg_settings):

@@ -473,4 +473,82 @@ __global__ __launch_bounds__(64, 3) void k_blob_evaluate(const uint8_t* __restri
     }
 }
 
+// ---------------------------------------------------------------- quotient polynomial (prover side)
+// c-kzg-4844's compute_kzg_proof_impl: the proof of p(z) = y is pi = sum_i q_i * g1_points[i] with, in evaluation form,
+//     q_i = (p_i - y) / (w_i - z)   (i != m),      and if z is the root w_m:   q_m = sum_{i != m} (p_i - y) w_i / (z (z - w_i)).
+// One wavefront per (blob, z); lane t owns elements 64t..64t+63.  The 4096 inversions are one Montgomery batch
+// inversion: per-lane prefix products (parked in the output buffer), a product scan across the lanes, ONE Fermat
+// inversion per blob, and the backward sweep.  Not on the verification path: plain 8x32 arithmetic, no tuning.
+// z_in / y_in: plain little-endian limbs, canonical.  out: 4096 plain scalars per blob.  status |= 1: element >= r.
+__device__ __forceinline__ Fr fr_shfl(const Fr& a, int src) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = __shfl((int)a.l[i], src, 64);
+    return r;
+}
+__device__ inline Fr fr_inverse_mont(const Fr& a) {  // a != 0, Montgomery in and out
+    return pow_limbs<Fr, 8>(a, consts::FR_R_MINUS_2, FrF::one(), [](const Fr& x, const Fr& y) { return FrF::mul(x, y); });
+}
+__global__ __launch_bounds__(64) void k_blob_quotient(const uint8_t* __restrict__ blobs, const Fr* __restrict__ z_in,
+                                                      const Fr* __restrict__ y_in, const Fr* __restrict__ M, Fr* __restrict__ out,
+                                                      uint32_t* __restrict__ status) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const Fr zM = FrF::to_mont(z_in[b]), y = y_in[b];
+    const uint4* src = reinterpret_cast<const uint4*>(blobs + (size_t)b * BLOB_BYTES) + (size_t)lane * 128;
+    Fr* o = out + (size_t)b * FE_PER_BLOB + 64 * lane;
+    const Fr* Ml = M + 64 * lane;
+    // pass 1: prefix products of d_k = w_k - z within the lane (a zero factor, z = w_m, is replaced by one)
+    Fr acc = FrF::one();
+    int special = -1;
+    for (int k = 0; k < 64; k++) {
+        Fr d = FrF::sub(Ml[k], zM);
+        if (FrF::is_zero(d)) {
+            special = k;
+            d = FrF::one();
+        }
+        o[k] = acc;
+        acc = FrF::mul(acc, d);
+    }
+    // products across lanes: incl[l] = T_0 .. T_l (inclusive scan), then the exclusive prefix and the grand total
+    Fr incl = acc;
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        Fr up = fr_shfl(incl, lane >= sh ? lane - sh : lane);
+        if (lane >= sh) incl = FrF::mul(incl, up);
+    }
+    const Fr total = fr_shfl(incl, 63);
+    Fr excl = fr_shfl(incl, lane ? lane - 1 : 0);
+    if (lane == 0) excl = FrF::one();
+    const Fr inv_total = fr_inverse_mont(total);
+    // suffix products S_l = T_(l+1) .. T_63 by the same scan mirrored
+    Fr sfx = acc;
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        Fr dn = fr_shfl(sfx, lane + sh < 64 ? lane + sh : lane);
+        if (lane + sh < 64) sfx = FrF::mul(sfx, dn);
+    }
+    Fr sfx_excl = fr_shfl(sfx, lane < 63 ? lane + 1 : 63);
+    if (lane == 63) sfx_excl = FrF::one();
+    // running = 1 / (everything up to and including this lane's elements); walk the lane backwards
+    Fr running = FrF::mul(inv_total, sfx_excl);
+    bool bad = false;
+    Fr wsum = FrF::zero();  // sum_i q_i w_i (plain), only used when z is a root
+    for (int k = 63; k >= 0; k--) {
+        Fr d = FrF::sub(Ml[k], zM);
+        if (k == special) d = FrF::one();
+        const Fr inv_d = FrF::mul(running, FrF::mul(excl, o[k]));  // 1 / d_k
+        running = FrF::mul(running, d);
+        const Fr p = fr_from_be_words(src[2 * k], src[2 * k + 1]);
+        bad |= FrF::geq_mod(p);
+        Fr q = FrF::mul(FrF::sub(p, y), inv_d);  // plain * Montgomery = plain
+        if (k == special) q = FrF::zero();
+        o[k] = q;
+        wsum = FrF::add(wsum, FrF::mul(q, Ml[k]));
+    }
+    const unsigned long long any_special = __ballot(special >= 0);
+    if (any_special) {  // z = w_m: q_m = -(1/z) sum_{i != m} q_i w_i
+        for (int sh = 1; sh < 64; sh <<= 1) wsum = FrF::add(wsum, fr_shfl_xor(wsum, sh));
+        if (special >= 0) o[special] = FrF::neg(FrF::mul(wsum, fr_inverse_mont(zM)));
+    }
+    if (__ballot(bad) && lane == 0) atomicOr(&status[b], 1u);
+}
+
 }  // namespace kzg

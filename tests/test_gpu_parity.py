@@ -104,6 +104,30 @@ def test_blob_to_kzg_commitment(settings):
     assert api.blob_to_kzg_commitment(many, settings) == [tuples[i % 7][1] for i in range(70)]
 
 
+def test_compute_proofs(settings, osettings):
+    """Prover side: compute_blob_kzg_proof must reproduce the proof of every valid mainnet vector (the proof is a
+    deterministic function of blob and commitment); compute_kzg_proof at random z and AT ROOTS OF UNITY (the
+    q_m special case) must give y = p(z) as the oracle evaluates it and a proof that verify_kzg_proof accepts - and the
+    oracle too; a wrong y is then rejected."""
+    tuples = G.valid_blob_tuples()
+    blobs, cs, ps = [list(x) for x in zip(*tuples)]
+    assert api.compute_blob_kzg_proof(blobs, cs, settings) == ps
+    rng = random.Random(77)
+    zs = [rng.randrange(R).to_bytes(32, "big") for _ in range(4)] + [osettings.root(k) for k in (0, 1, 2047, 4095)] + [bytes(32)]
+    bl = [blobs[i % 7] for i in range(len(zs))]
+    proofs, ys = api.compute_kzg_proof(bl, zs, settings)
+    for b, c, z, y, p in zip(bl, [cs[i % 7] for i in range(len(zs))], zs, ys, proofs):
+        assert y == O.evaluate_polynomial_in_evaluation_form(b, z, osettings)
+        assert O.verify_kzg_proof(c, z, y, p, osettings) is True
+        assert KzgProof.verify_kzg_proof(Bytes48(c), Bytes32(z), Bytes32(y), Bytes48(p), settings) is True
+        y_bad = ((int.from_bytes(y, "big") + 1) % R).to_bytes(32, "big")
+        assert KzgProof.verify_kzg_proof(Bytes48(c), Bytes32(z), Bytes32(y_bad), Bytes48(p), settings) is False
+    with pytest.raises(KzgError):
+        api.compute_kzg_proof([blobs[0]], [R.to_bytes(32, "big")], settings)
+    with pytest.raises(KzgError):
+        api.compute_blob_kzg_proof([blobs[0]], [bytes([0x81]) + bytes(range(1, 48))], settings)
+
+
 # ------------------------------------------------------------------ the reference's three vector tests
 def test_verify_kzg_proof(settings):
     """src/kzg_proof.rs:604-631 over the 122 vectors; strict: null <=> Err."""
