@@ -537,6 +537,42 @@ def test_mutation_fuzz_against_oracle(settings, osettings):
     assert min(outcomes.values()) >= 5, outcomes  # the fuzz reaches all three outcomes
 
 
+def test_concurrent_host_threads(settings, osettings):
+    """SURVEY 8b threading: entry points must be callable concurrently from several host threads, with one shared
+    settings handle (calls serialise on the handle) and with one handle per thread (calls overlap on the device).
+    ctypes releases the GIL, so the calls really run in parallel."""
+    import threading
+    tuples = G.valid_blob_tuples()
+    bad = list(tuples[3])
+    bad[2] = O.g1_add(bad[2], G1_GEN)
+    jobs = []
+    for k in range(24):
+        t = [tuples[(k + j) % 7] for j in range(1 + k % 4)]
+        if k % 3 == 0:
+            t[-1] = tuple(bad)
+        blobs, cs, ps = [list(x) for x in zip(*t)]
+        jobs.append((blobs, cs, ps, O.verify_blob_kzg_proof_batch(blobs, cs, ps, osettings)))
+    own = [KzgSettings.load_trusted_setup_file() for _ in range(3)]
+    results, errors = {}, []
+
+    def work(tid, st):
+        try:
+            for k in range(tid, len(jobs), 6):
+                blobs, cs, ps, _ = jobs[k]
+                results[k] = KzgProof.verify_blob_kzg_proof_batch([Blob(b) for b in blobs], [Bytes48(c) for c in cs],
+                                                                  [Bytes48(p) for p in ps], st)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i, settings if i < 3 else own[i - 3])) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert [results[k] for k in range(len(jobs))] == [j[3] for j in jobs]
+
+
 def test_device_resident_batch_full_size():
     """BASELINE config 2 size (n = 1024), device-resident inputs, through size-independent properties:
     valid batch -> true; one corrupted proof -> false; result is independent of how the batch is split."""
