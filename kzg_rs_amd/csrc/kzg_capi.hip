@@ -450,7 +450,13 @@ struct KzgSettings {
     size_t n_g2 = 0;
     uint8_t g1_first[2][48] = {};     // g1_points[0], [1] of the FILE order, for the monomial-form check (build.rs:107-129)
     DevProgram prep, verify;
-    hipStream_t s1 = nullptr, s2 = nullptr;
+    // s1 / s2: the two streams the current launch uses (challenge chain | point decode).  They point at the plain pair,
+    // or - for a small launch (a single batch) - at a pair confined to disjoint halves of the CUs: the 16 two-wave
+    // workgroups of the challenge chain and the 32 decode waves otherwise land on the same first CUs of every XCD and,
+    // run to run, share SIMDs (the chain then takes 4.9 ms instead of 3.5 ms).  Measured: one 1 024-blob batch 9.1 ms on
+    // the split pair, 10.1-11.5 ms on the plain pair; KZG_CU_MASK=0 disables the split pair.
+    mutable hipStream_t s1 = nullptr, s2 = nullptr;
+    hipStream_t s_plain[2] = {nullptr, nullptr}, s_half[2] = {nullptr, nullptr};
     hipEvent_t ev[12] = {};
     mutable std::mutex mu;
     mutable Workspace ws;
@@ -499,11 +505,30 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
     }
     KzgSettings* s = new KzgSettings();
     HIPCHK(hipGetDevice(&s->device));
-    HIPCHK(hipStreamCreateWithFlags(&s->s1, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&s->s_plain[0], hipStreamNonBlocking));
+    s->s1 = s->s_plain[0];
     // KZG_SINGLE_STREAM=1 (profiling aid): run the point-decode chain on the same stream as the challenge chain, so
     // per-dispatch PMC counters are not polluted by a concurrent kernel
     if (getenv("KZG_SINGLE_STREAM") && getenv("KZG_SINGLE_STREAM")[0] == '1') s->s2 = s->s1;
-    else HIPCHK(hipStreamCreateWithFlags(&s->s2, hipStreamNonBlocking));
+    else {
+        HIPCHK(hipStreamCreateWithFlags(&s->s_plain[1], hipStreamNonBlocking));
+        s->s2 = s->s_plain[1];
+        const char* e = getenv("KZG_CU_MASK");
+        if (!(e && e[0] == '0')) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount >= 64) {
+                const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+                std::vector<uint32_t> lo(words, 0), hi(words, 0);
+                for (int i = 0; i < ncu; i++) ((i < ncu / 2) ? lo : hi)[i / 32] |= 1u << (i % 32);
+                if (hipExtStreamCreateWithCUMask(&s->s_half[0], words, lo.data()) != hipSuccess ||
+                    hipExtStreamCreateWithCUMask(&s->s_half[1], words, hi.data()) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (s->s_half[0]) (void)hipStreamDestroy(s->s_half[0]);
+                    s->s_half[0] = s->s_half[1] = nullptr;
+                }
+            }
+        }
+    }
     for (auto& e : s->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipMalloc(&s->d_M, sizeof(Fr) * FE_PER_BLOB));
     HIPCHK(hipMalloc(&s->d_DM, sizeof(Fr) * FE_PER_BLOB));
@@ -685,8 +710,8 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
         if (p) (void)hipFree(p);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
-    if (s->s1) (void)hipStreamDestroy(s->s1);
-    if (s->s2 && s->s2 != s->s1) (void)hipStreamDestroy(s->s2);
+    for (hipStream_t st : {s->s_plain[0], s->s_plain[1], s->s_half[0], s->s_half[1]})
+        if (st) (void)hipStreamDestroy(st);
     delete s;
 }
 
@@ -850,6 +875,11 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
     Workspace& w = s->ws;
     const size_t T = n * B;
     KzgRet rc;
+    if (s->s_half[0] && s->s_plain[1]) {  // every earlier launch of this handle has been waited for: safe to switch pairs
+        const bool small = T <= 4096;
+        s->s1 = small ? s->s_half[0] : s->s_plain[0];
+        s->s2 = small ? s->s_half[1] : s->s_plain[1];
+    }
     HIPCHK(hipEventRecord(s->ev[0], s->s1));
     HIPCHK(hipStreamWaitEvent(s->s2, s->ev[0], 0));
     HIPCHK(hipEventRecord(s->ev[5], s->s2));
