@@ -35,7 +35,7 @@ ALG_BYTES = {
     "k_msm": 3 * 128,                               # three (point, scalar) terms per blob, 96 + 32 B each
     "k_slp_run(pairing)": 0,
 }
-PMC_FILE = "r1f_pmc.json"
+PMC_FILE = "r1g_pmc.json"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
 
 
