@@ -67,11 +67,11 @@ def cpu_baseline(blobs, cs, ps, tau_g2, max_blobs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=6144)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--blobs", type=int, default=1024, help="blobs per GPU per step (batch)")
-    ap.add_argument("--group", type=int, default=128, help="independent batches per launch group (batch dimension inside the kernels)")
-    ap.add_argument("--inflight", type=int, default=4, help="launch groups kept in flight by the fixed-order software pipeline")
+    ap.add_argument("--group", type=int, default=256, help="independent batches per launch group (batch dimension inside the kernels)")
+    ap.add_argument("--inflight", type=int, default=3, help="launch groups kept in flight by the fixed-order software pipeline")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
