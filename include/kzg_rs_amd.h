@@ -197,7 +197,7 @@ KzgRet kzg_pairing_check(bool *ok, const uint8_t a[48], const uint8_t b[48], con
 /* Timing of the last batch call on this handle, in milliseconds, measured with HIP events on the
  * library's own stream: [0] whole call (device work), [1] per-blob phase (challenge + evaluate +
  * point decode), [2] MSM (split + window + combine), [3] pairing, [4] evaluate kernel, [5] challenge kernel,
- * [6] point-decode kernel, [7] multiples kernel. */
+ * [6] point decode + subgroup test + MSM multiples (one kernel), [7] the generator's table copy. */
 KzgRet kzg_last_timings(const KzgSettings *s, float out_ms[8]);
 
 const char *kzg_last_error(void);

@@ -85,7 +85,9 @@ __global__ void k_finish_g(const Fr* __restrict__ partial, int nparts, Fr* __res
 //     k = k1 + k2 * L,  L = x^2 (GLV: on G1, phi(P) = (beta x, y) = -[x^2]P, so [L]P = -phi(P)),  k1, k2 < 2^128
 //     k P = k1_lo P + k1_hi (2^64 P) + k2_lo (-phi P) + k2_hi (-phi(2^64 P)).
 // mult[0..3][p] = P, 2^64 P, -phi(P), -phi(2^64 P) (Jacobian): 64 doublings + 2 multiplications per point, which
-// depend only on the INPUT points, so k_g1_multiples runs beside the SHA-256 challenge chain, off the critical path.
+// depend only on the INPUT points.  On the verification path they come out of the decode pass for free
+// (k_g1_decode_multiples below shares the doubling chain with the subgroup test, beside the SHA-256 challenge chain);
+// k_g1_multiples is the stand-alone form for points that are already decoded (the generator, kzg_g1_msm).
 // Points must lie in G1 (all callers decode with the subgroup check).
 constexpr int MSM_CHUNKS = 4;
 __device__ __forceinline__ G1Jac g1_neg_phi(const G1Jac& p) {
