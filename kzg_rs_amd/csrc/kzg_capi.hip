@@ -456,7 +456,9 @@ struct KzgSettings {
     // run to run, share SIMDs (the chain then takes 4.9 ms instead of 3.5 ms).  Measured: one 1 024-blob batch 9.1 ms on
     // the split pair, 10.1-11.5 ms on the plain pair; KZG_CU_MASK=0 disables the split pair.
     mutable hipStream_t s1 = nullptr, s2 = nullptr;
-    hipStream_t s_plain[2] = {nullptr, nullptr}, s_half[2] = {nullptr, nullptr};
+    hipStream_t s_plain[2] = {nullptr, nullptr};
+    mutable hipStream_t s_half[2] = {nullptr, nullptr};
+    mutable bool s_half_tried = false;
     hipEvent_t ev[12] = {};
     mutable std::mutex mu;
     mutable Workspace ws;
@@ -513,21 +515,6 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
     else {
         HIPCHK(hipStreamCreateWithFlags(&s->s_plain[1], hipStreamNonBlocking));
         s->s2 = s->s_plain[1];
-        const char* e = getenv("KZG_CU_MASK");
-        if (!(e && e[0] == '0')) {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount >= 64) {
-                const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
-                std::vector<uint32_t> lo(words, 0), hi(words, 0);
-                for (int i = 0; i < ncu; i++) ((i < ncu / 2) ? lo : hi)[i / 32] |= 1u << (i % 32);
-                if (hipExtStreamCreateWithCUMask(&s->s_half[0], words, lo.data()) != hipSuccess ||
-                    hipExtStreamCreateWithCUMask(&s->s_half[1], words, hi.data()) != hipSuccess) {
-                    (void)hipGetLastError();
-                    if (s->s_half[0]) (void)hipStreamDestroy(s->s_half[0]);
-                    s->s_half[0] = s->s_half[1] = nullptr;
-                }
-            }
-        }
     }
     for (auto& e : s->ev) HIPCHK(hipEventCreate(&e));
     HIPCHK(hipMalloc(&s->d_M, sizeof(Fr) * FE_PER_BLOB));
@@ -869,17 +856,39 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
 // n = 1024 every phase is a latency-bound serial chain that uses a sliver of the chip, so the batch dimension
 // inside the kernels is what fills the machine.
 
+// The stream pair of a launch of T blobs (KzgSettings::s1/s2): the split pair, made on first use, for a small launch.
+// Every earlier launch of the handle has been waited for by then, so switching pairs is safe.
+static void select_streams(const KzgSettings* s, size_t T) {
+    if (!s->s_plain[1]) return;  // KZG_SINGLE_STREAM
+    const bool small = T <= 4096;
+    if (small && !s->s_half_tried) {
+        s->s_half_tried = true;
+        const char* e = getenv("KZG_CU_MASK");
+        hipDeviceProp_t prop;
+        if (!(e && e[0] == '0') && hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount >= 64) {
+            const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+            std::vector<uint32_t> lo(words, 0), hi(words, 0);
+            for (int i = 0; i < ncu; i++) ((i < ncu / 2) ? lo : hi)[i / 32] |= 1u << (i % 32);
+            if (hipExtStreamCreateWithCUMask(&s->s_half[0], words, lo.data()) != hipSuccess ||
+                hipExtStreamCreateWithCUMask(&s->s_half[1], words, hi.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                if (s->s_half[0]) (void)hipStreamDestroy(s->s_half[0]);
+                s->s_half[0] = s->s_half[1] = nullptr;
+            }
+        }
+    }
+    const bool use_half = small && s->s_half[0];
+    s->s1 = use_half ? s->s_half[0] : s->s_plain[0];
+    s->s2 = use_half ? s->s_half[1] : s->s_plain[1];
+}
+
 // Phase 1 (no communication): point decode + multiples || (challenge -> evaluate) for all T = B n blobs.
 static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n, size_t B,
                                    const KzgSettings* s) {
     Workspace& w = s->ws;
     const size_t T = n * B;
     KzgRet rc;
-    if (s->s_half[0] && s->s_plain[1]) {  // every earlier launch of this handle has been waited for: safe to switch pairs
-        const bool small = T <= 4096;
-        s->s1 = small ? s->s_half[0] : s->s_plain[0];
-        s->s2 = small ? s->s_half[1] : s->s_plain[1];
-    }
+    select_streams(s, T);
     HIPCHK(hipEventRecord(s->ev[0], s->s1));
     HIPCHK(hipStreamWaitEvent(s->s2, s->ev[0], 0));
     HIPCHK(hipEventRecord(s->ev[5], s->s2));
