@@ -228,17 +228,26 @@ __device__ inline bool g1_in_subgroup(const G1Aff& p) {
     return FpF::eq(q.x, fp_mul(bx, zz)) && FpF::eq(q.y, fp_neg(fp_mul(p.y, zzz)));
 }
 
-// The same test with its first [|x|] taken right-to-left, so that the doubling chain P, 2P, 4P, ... it walks ends in
-// [2^64]P - the multiple the MSM needs anyway (msm.hpp).  64 doublings + 5 additions, then [|x|] of the result
-// left-to-right as above.  p2_64 is valid whether or not the test passes.
-__device__ inline bool g1_in_subgroup_with_multiple(const G1Aff& p, G1Jac& p2_64) {
+// The same test with its first [|x|] taken right-to-left, so that the doubling chain P, 2P, 4P, ... it walks passes
+// through the multiples 2^(STEP k) P the MSM needs anyway (msm.hpp): STEP = 64 -> the chain ends in 2^64 P (64 doublings
+// + 5 additions, nothing extra); STEP = 16 -> 2^16 P .. 2^112 P, the chain extended by 48 doublings past the test's
+// 64.  `emit(k, point)` is called for k = 1 .. 128 / STEP - 1.  Then [|x|] of the result left-to-right as above.
+// The multiples are valid whether or not the test passes.
+template <int STEP, class Emit>
+__device__ inline bool g1_in_subgroup_with_multiples(const G1Aff& p, Emit emit) {
     G1Jac r = g1_from_affine(p), q = r;  // q is overwritten at bit 16, the lowest set bit of |x|
 #pragma unroll 1
     for (int i = 0; i < 64; i++) {
+        if (i && i % STEP == 0) emit(i / STEP, r);
         if ((BLS_X_ABS >> i) & 1) q = (i == 16) ? r : g1_add(q, r);
         r = g1_dbl(r);
     }
-    p2_64 = r;
+#pragma unroll 1
+    for (int i = 64; i < 128; i++) {
+        if (i % STEP == 0) emit(i / STEP, r);
+        if (i + STEP >= 128) break;  // the last multiple is out: no further doublings
+        r = g1_dbl(r);
+    }
     q = g1_mul_xabs(q);
     if (g1_is_identity(q)) return false;
     Fp zz = fp_sqr(q.z), zzz = fp_mul(zz, q.z);

@@ -173,14 +173,14 @@ __global__ void k_pack_records(const uint32_t* __restrict__ c, const uint32_t* _
 
 // the generator and its precomputed multiples (gen_mult[4], made once per settings) as point `idx` of a workspace
 __global__ void k_set_generator_multiples(G1Aff* __restrict__ points, uint32_t* __restrict__ pflag, G1Jac* __restrict__ mult,
-                                          const G1Jac* __restrict__ gen_mult, int idx, int stride) {
+                                          const G1Jac* __restrict__ gen_mult, int idx, int stride, int chunks) {
     if (threadIdx.x || blockIdx.x) return;
     G1Aff g;
     g.x = fp_const(consts::G1_GEN_X_MONT);
     g.y = fp_const(consts::G1_GEN_Y_MONT);
     points[idx] = g;
     pflag[idx] = 0;
-    for (int j = 0; j < MSM_CHUNKS; j++) mult[(size_t)j * stride + idx] = gen_mult[j];
+    for (int j = 0; j < chunks; j++) mult[(size_t)j * stride + idx] = gen_mult[j];
 }
 
 // plain msm: output 0 over terms (point t, scalar t)
@@ -417,10 +417,12 @@ struct DevProgram {
 };
 
 constexpr size_t MAX_WORLD = 64;
+constexpr size_t LATENCY_MAX_BLOBS = 4096;  // launches up to this size: CU-split stream pair + the latency MSM layout
 struct Workspace {
     size_t cap_n = 0;       // batch capacity
     size_t cap_b = 0;       // batches-per-group capacity
     size_t pending_n = 0, pending_b = 0, finish_b = 0;  // group currently in flight on this handle
+    int chunks = MSM_CHUNKS;                              // MSM layout of the group in flight (msm.hpp)
     size_t off_r = 0, off_part = 0, off_out = 0, off_parts = 0;  // pinned-buffer layout
     size_t cap_stage = 0;   // staged host-input capacity (blobs)
     Fr *d_z = nullptr, *d_y = nullptr, *d_scalars = nullptr, *d_partial = nullptr, *d_r = nullptr;
@@ -440,7 +442,7 @@ struct KzgSettings {
     Fr29Mem *d_M29 = nullptr, *d_DM29 = nullptr;   // the same in radix 2^29 (fr29.hpp), what k_blob_evaluate reads
     Fp* d_tau4 = nullptr;   // [tau]G2 affine (x.c0 x.c1 y.c0 y.c1), Montgomery
     Fp* d_prep = nullptr;   // prepared lines: [tau]G2 then generator (2 * 408 Fp)
-    G1Jac* d_gen_mult = nullptr;  // G, 2^64 G, -phi(G), -phi(2^64 G)
+    G1Jac* d_gen_mult = nullptr;  // the generator's MSM tables: [0, 4) the default layout, [4, 20) the latency layout (msm.hpp)
     // full trusted setup (kzg_settings_load_trusted_setup only; not needed by verification):
     G1Aff* d_g1 = nullptr;            // g1_points, bit-reversal permuted (build.rs:79,89-105), 4096 entries
     uint32_t* d_g1_flag = nullptr;    // 0 finite / 1 identity (unchecked decode, build.rs:68)
@@ -549,9 +551,10 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
         uint32_t* d_gf;
         HIPCHK(hipMalloc(&d_g, sizeof(G1Aff)));
         HIPCHK(hipMalloc(&d_gf, 4));
-        HIPCHK(hipMalloc(&s->d_gen_mult, sizeof(G1Jac) * MSM_CHUNKS));
+        HIPCHK(hipMalloc(&s->d_gen_mult, sizeof(G1Jac) * (MSM_CHUNKS + MSM_CHUNKS_LATENCY)));
         hipLaunchKernelGGL(k_set_generator, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, 0);
-        hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, s->d_gen_mult, 1, 1);
+        hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, s->d_gen_mult, 1, 1, MSM_CHUNKS);
+        hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, s->d_gen_mult + MSM_CHUNKS, 1, 1, MSM_CHUNKS_LATENCY);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s->s1));
         HIPCHK(hipFree(d_g));
@@ -642,8 +645,8 @@ extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char*
     HIPCHK(hipMalloc(&s->d_g1_mult, sizeof(G1Jac) * MSM_CHUNKS * (size_t)N));
     HIPCHK(hipMemcpyAsync(d_bytes, g1b.data(), g1b.size(), hipMemcpyHostToDevice, s->s1));
     hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, s->d_g1, s->d_g1_flag, N, 0);
-    hipLaunchKernelGGL(k_g1_decode_multiples, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp, d_flag2,
-                       s->d_g1_mult, N, N);
+    hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
+                       d_flag2, s->d_g1_mult, N, N);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> f1((size_t)N), f2((size_t)N);
     HIPCHK(hipMemcpyAsync(f1.data(), s->d_g1_flag, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
@@ -762,7 +765,7 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
         HIPCHK(hipMalloc(&w.d_sorted, 4 * MSM_WINDOWS * nterm));
         HIPCHK(hipMalloc(&w.d_points, sizeof(G1Aff) * np));
         HIPCHK(hipMalloc(&w.d_window, sizeof(G1Jac) * 2 * MSM_WINDOWS * capB));
-        HIPCHK(hipMalloc(&w.d_mult, sizeof(G1Jac) * MSM_CHUNKS * np));
+        HIPCHK(hipMalloc(&w.d_mult, sizeof(G1Jac) * std::max((size_t)MSM_CHUNKS * np, (size_t)MSM_CHUNKS_LATENCY * std::min(np, (size_t)(2 * LATENCY_MAX_BLOBS + 1)))));
         HIPCHK(hipMalloc(&w.d_ab, sizeof(G1Jac) * 2 * capB));
         HIPCHK(hipMalloc(&w.d_parts, sizeof(G1Jac) * 2 * capB * MAX_WORLD));
         HIPCHK(hipMalloc(&w.d_slp_in, sizeof(Fp) * 6 * capB));
@@ -822,13 +825,14 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     d.nterms[1] = (int)(2 * n + 1);
     d.max_terms = mt;
     d.stride = 2 * T + 1;
-    d.chunks_per_block = msm_chunks_per_block(B);
-    const unsigned slots = MSM_CHUNKS / d.chunks_per_block;
+    d.chunks = w.chunks;
+    d.chunks_per_block = w.chunks == MSM_CHUNKS ? msm_chunks_per_block(B) : 1;
+    const unsigned slots = d.chunks / d.chunks_per_block, W = MSM_WINDOWS / d.chunks;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     const int nsc = (int)(B * (2 * n + 1));
     hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc);
-    hipLaunchKernelGGL(k_msm_window, dim3(8, slots, (unsigned)(2 * B)), dim3(256), 0, s->s1, d);
-    hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(2 * B)), dim3(64), 0, s->s1, w.d_window, w.d_ab, (int)slots);
+    hipLaunchKernelGGL(k_msm_window, dim3(W, slots, (unsigned)(2 * B)), dim3(256), 0, s->s1, d);
+    hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(2 * B)), dim3(64), 0, s->s1, w.d_window, w.d_ab, (int)slots, (int)W);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
     return KZG_OK;
@@ -840,10 +844,18 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
     Workspace& w = s->ws;
     const int np = (int)(2 * T + 1);
     unsigned blocks = (unsigned)((2 * T + 63) / 64);
-    hipLaunchKernelGGL(k_g1_decode_multiples, dim3(blocks), dim3(64), 0, s->s2, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs,
-                       (int)T, w.d_points, w.d_pflag, w.d_mult, (int)(2 * T), np);
+    static const bool no_latency_layout = getenv("KZG_MSM_LATENCY_LAYOUT") && getenv("KZG_MSM_LATENCY_LAYOUT")[0] == '0';
+    w.chunks = (T <= LATENCY_MAX_BLOBS && !no_latency_layout) ? MSM_CHUNKS_LATENCY : MSM_CHUNKS;
+    const uint8_t *c = (const uint8_t*)d_commitments, *p = (const uint8_t*)d_proofs;
+    if (w.chunks == MSM_CHUNKS_LATENCY)
+        hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag,
+                           w.d_mult, (int)(2 * T), np);
+    else
+        hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult,
+                           (int)(2 * T), np);
     HIPCHK(hipEventRecord(s->ev[10], s->s2));
-    hipLaunchKernelGGL(k_set_generator_multiples, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, w.d_mult, s->d_gen_mult, (int)(2 * T), np);
+    hipLaunchKernelGGL(k_set_generator_multiples, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, w.d_mult,
+                       s->d_gen_mult + (w.chunks == MSM_CHUNKS ? 0 : MSM_CHUNKS), (int)(2 * T), np, w.chunks);
     HIPCHK(hipGetLastError());
     return KZG_OK;
 }
@@ -860,7 +872,7 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
 // Every earlier launch of the handle has been waited for by then, so switching pairs is safe.
 static void select_streams(const KzgSettings* s, size_t T) {
     if (!s->s_plain[1]) return;  // KZG_SINGLE_STREAM
-    const bool small = T <= 4096;
+    const bool small = T <= LATENCY_MAX_BLOBS;
     if (small && !s->s_half_tried) {
         s->s_half_tried = true;
         const char* e = getenv("KZG_CU_MASK");
@@ -1364,7 +1376,7 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
         for (size_t i = 0; i < n; i++)
             if (st[i] == G1_INVALID) return fail(KZG_BADARGS, "invalid G1 point");
     }
-    if (n) hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_points, w.d_pflag, w.d_mult, (int)n, mt);
+    if (n) hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_points, w.d_pflag, w.d_mult, (int)n, mt, MSM_CHUNKS);
     MsmDesc d{};
     d.mult = w.d_mult;
     d.pflag = w.d_pflag;
@@ -1377,10 +1389,11 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     d.nterms[1] = 0;
     d.max_terms = mt;
     d.stride = mt;
+    d.chunks = MSM_CHUNKS;
     d.chunks_per_block = 1;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, 1), dim3(256), 0, s->s1, d);
-    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, w.d_window, w.d_ab, MSM_CHUNKS);
+    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, w.d_window, w.d_ab, MSM_CHUNKS, 8);
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
     hipLaunchKernelGGL(k_jac_compress, dim3(1), dim3(64), 0, s->s1, w.d_ab, w.d_bytes, 1);
     HIPCHK(hipGetLastError());
@@ -1586,10 +1599,11 @@ static KzgRet setup_msm(const KzgSettings* s, ProverBufs& b, size_t m) {
     d.nterms[0] = d.nterms[1] = (int)NT;
     d.max_terms = (int)NT;
     d.stride = (int)NT;
+    d.chunks = MSM_CHUNKS;
     d.chunks_per_block = m >= 16 ? 4 : 1;
     const unsigned slots = MSM_CHUNKS / d.chunks_per_block;
     hipLaunchKernelGGL(k_msm_window, dim3(8, slots, (unsigned)m), dim3(256), 0, s->s1, d);
-    hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)m), dim3(64), 0, s->s1, b.d_win, b.d_res, (int)slots);
+    hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)m), dim3(64), 0, s->s1, b.d_win, b.d_res, (int)slots, 8);
     hipLaunchKernelGGL(k_jac_compress_n, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s->s1, b.d_res, b.d_out, (int)m);
     HIPCHK(hipGetLastError());
     return KZG_OK;

@@ -24,7 +24,7 @@
 namespace kzg {
 
 constexpr int MSM_C = 8;
-constexpr int MSM_WINDOWS = 32;  // 4 chunks x 8 windows
+constexpr int MSM_WINDOWS = 32;  // windows per output: chunks x windows per chunk (4 x 8 or 16 x 2)
 constexpr int MSM_BUCKETS = 256;
 
 struct MsmTerm {
@@ -89,7 +89,14 @@ __global__ void k_finish_g(const Fr* __restrict__ partial, int nparts, Fr* __res
 // (k_g1_decode_multiples below shares the doubling chain with the subgroup test, beside the SHA-256 challenge chain);
 // k_g1_multiples is the stand-alone form for points that are already decoded (the generator, kzg_g1_msm).
 // Points must lie in G1 (all callers decode with the subgroup check).
+//
+// Two layouts.  CHUNKS = 4 (64-bit chunks, 8 windows each) is the default: the 2^64 multiple falls out of the decode
+// pass for free and the window combine is 56 doublings.  CHUNKS = 16 (16-bit chunks, 2 windows each: multiples
+// 2^16 P .. 2^112 P and their -phi images) costs 48 more doublings per point in the decode pass - which runs beside the
+// longer SHA-256 chain when a single batch is verified - and cuts the serial combine to 8 doublings: the LATENCY
+// layout, used for small launches only (it would add a fifth to the decode work of a throughput launch).
 constexpr int MSM_CHUNKS = 4;
+constexpr int MSM_CHUNKS_LATENCY = 16;
 __device__ __forceinline__ G1Jac g1_neg_phi(const G1Jac& p) {
     G1Jac r;
     r.x = fp_mul(p.x, fp_const(consts::FP_BETA_MONT));
@@ -97,45 +104,52 @@ __device__ __forceinline__ G1Jac g1_neg_phi(const G1Jac& p) {
     r.z = p.z;
     return r;
 }
+// table j of `chunks` tables: j < chunks/2 -> 2^(step j) P, j >= chunks/2 -> -phi of table j - chunks/2; step = 256 / chunks
 __global__ __launch_bounds__(64, 4) void k_g1_multiples(const G1Aff* __restrict__ points, const uint32_t* __restrict__ pflag,
-                                                     G1Jac* __restrict__ mult, int n, int stride) {
+                                                     G1Jac* __restrict__ mult, int n, int stride, int chunks) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const int half = chunks / 2, step = 256 / chunks;
     G1Jac acc = pflag[i] ? g1_identity() : g1_from_affine(points[i]);
-    mult[i] = acc;
-    mult[(size_t)2 * stride + i] = g1_neg_phi(acc);
-    for (int k = 0; k < 64; k++) acc = g1_dbl(acc);
-    mult[(size_t)stride + i] = acc;
-    mult[(size_t)3 * stride + i] = g1_neg_phi(acc);
+    for (int j = 0; j < half; j++) {
+        mult[(size_t)j * stride + i] = acc;
+        mult[(size_t)(half + j) * stride + i] = g1_neg_phi(acc);
+        if (j + 1 < half)
+            for (int k = 0; k < step; k++) acc = g1_dbl(acc);
+    }
 }
 
 // Decode + subgroup check + multiples in one pass: the subgroup test's first scalar multiplication walks the same
 // doubling chain that produces 2^64 P (g1.hpp g1_in_subgroup_with_multiple), which saves the 64 doublings of a
 // separate k_g1_multiples pass.  bytes0 holds points [0, n0), bytes1 points [n0, n).
+template <int CHUNKS>
 __global__ __launch_bounds__(64, 2) void k_g1_decode_multiples(const uint8_t* __restrict__ bytes0, const uint8_t* __restrict__ bytes1,
-                                                            int n0, G1Aff* __restrict__ points, uint32_t* __restrict__ pflag,
-                                                            G1Jac* __restrict__ mult, int n, int stride) {
+                                                               int n0, G1Aff* __restrict__ points, uint32_t* __restrict__ pflag,
+                                                               G1Jac* __restrict__ mult, int n, int stride) {
+    constexpr int HALF = CHUNKS / 2, STEP = 256 / CHUNKS;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t* src = i < n0 ? bytes0 + (size_t)i * 48 : bytes1 + (size_t)(i - n0) * 48;
     G1Aff a;
     uint32_t st = g1_decompress(a, src, false);
-    G1Jac p = g1_identity(), m = p;
     if (st == G1_OK) {
-        p = g1_from_affine(a);
-        if (!g1_in_subgroup_with_multiple(a, m)) st = G1_INVALID;
+        const G1Jac p = g1_from_affine(a);
+        mult[i] = p;
+        mult[(size_t)HALF * stride + i] = g1_neg_phi(p);
+        const bool in = g1_in_subgroup_with_multiples<STEP>(a, [&](int k, const G1Jac& m) {
+            mult[(size_t)k * stride + i] = m;
+            mult[(size_t)(HALF + k) * stride + i] = g1_neg_phi(m);
+        });
+        if (!in) st = G1_INVALID;
     }
     if (st != G1_OK) {
         a.x = FpF::zero();
         a.y = FpF::zero();
-        p = m = g1_identity();
+        const G1Jac id = g1_identity();
+        for (int k = 0; k < CHUNKS; k++) mult[(size_t)k * stride + i] = id;
     }
     points[i] = a;
     pflag[i] = st;
-    mult[i] = p;
-    mult[(size_t)2 * stride + i] = g1_neg_phi(p);
-    mult[(size_t)stride + i] = m;
-    mult[(size_t)3 * stride + i] = g1_neg_phi(m);
 }
 
 // in place: canonical k (< r) -> k1 (limbs 0..3) | k2 (limbs 4..7) with k = k1 + k2 * x^2.
@@ -209,9 +223,10 @@ struct MsmDesc {
     int nterms[2];
     int max_terms;
     int stride;
+    int chunks;                   // MSM_CHUNKS or MSM_CHUNKS_LATENCY; windows per chunk = 32 / chunks = gridDim.x
     int chunks_per_block;         // 1: a block per (window, chunk) - most parallel, lowest latency;  4: a block per window
                                   // sums the four chunks' terms into ONE bucket set - a quarter of the reductions and
-                                  // fuller, better balanced buckets (throughput mode).  gridDim.y = 4 / chunks_per_block
+                                  // fuller, better balanced buckets (throughput mode).  gridDim.y = chunks / chunks_per_block
 };
 
 __device__ __forceinline__ void lds_store_jac(uint32_t* base, int slot, const G1Jac& p) {
@@ -235,8 +250,8 @@ __device__ __forceinline__ G1Jac lds_load_jac(const uint32_t* base, int slot) {
     return p;
 }
 
-// grid (8 windows, 4 / chunks_per_block, 2 outputs x batches), 256 threads: block (w, g, o) handles digit byte 8j + w
-// of every scalar of output o for its chunks j, against the multiples 2^(64j) P.
+// grid (W windows per chunk, chunks / chunks_per_block, 2 outputs x batches), 256 threads: block (w, g, o) handles digit
+// byte W j + w of every scalar of output o for its chunks j, against the table of chunk j (W = 32 / chunks).
 #ifndef KZG_MSM_OCC
 #define KZG_MSM_OCC 3
 #endif
@@ -245,7 +260,8 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     const int w = blockIdx.x, bo = blockIdx.z, o = bo & 1, tid = threadIdx.x;
     const int cpb = d.chunks_per_block, j0 = blockIdx.y * cpb;
     const int nt = d.nterms[o];
-    const int wi = (bo * gridDim.y + blockIdx.y) * 8 + w;  // window slot
+    const int W = gridDim.x;                                // windows (digit bytes) per chunk
+    const int wi = (bo * gridDim.y + blockIdx.y) * W + w;  // window slot
     const uint32_t* tp = d.term_point + (size_t)bo * d.max_terms;
     const uint32_t* tsc = d.term_scalar + (size_t)bo * d.max_terms;
     uint32_t* sorted = d.sorted + (size_t)wi * cpb * d.max_terms;
@@ -255,9 +271,9 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     cur[tid] = 0;
     __syncthreads();
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(d.scalars);
-    // 1. counting sort by digit of the cpb * nt (chunk, term) pairs; entry = chunk << 30 | point index
+    // 1. counting sort by digit of the cpb * nt (chunk, term) pairs; entry = chunk << 28 | point index
     for (int c = 0; c < cpb; c++) {
-        const int byte = 8 * (j0 + c) + w;
+        const int byte = W * (j0 + c) + w;
         for (int t = tid; t < nt; t += 256) {
             uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
             atomicAdd(&cnt[dig], 1u);
@@ -274,11 +290,11 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     }
     __syncthreads();
     for (int c = 0; c < cpb; c++) {
-        const int byte = 8 * (j0 + c) + w;
+        const int byte = W * (j0 + c) + w;
         for (int t = tid; t < nt; t += 256) {
             uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
             uint32_t pos = atomicAdd(&cur[dig], 1u);
-            sorted[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << 30;
+            sorted[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << 28;
         }
     }
     __threadfence_block();
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     if (bucket > 0) {
         for (uint32_t k = off[bucket]; k < off[bucket + 1]; k++) {
             const uint32_t e = sorted[k];
-            acc = g1_add(acc, d.mult[(size_t)(e >> 30) * d.stride + (e & 0x3FFFFFFFu)]);
+            acc = g1_add(acc, d.mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]);
         }
     }
     // 3. sum_b b*B_b with b = 16 hi + lo:   16 * sum_hi hi*R_hi + sum_lo lo*C_lo,
@@ -372,19 +388,20 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     }
 }
 
-// out[o] = sum_w 2^(8w) (sum_g W[o][g][w]): 8 threads fold the nslots chunk groups, then one Horner chain of 56 doublings
-__global__ __launch_bounds__(64) void k_msm_combine(const G1Jac* __restrict__ window_sums, G1Jac* __restrict__ out, int nslots) {
+// out[o] = sum_w 2^(8w) (sum_g S[o][g][w]), w < W: W threads fold the nslots chunk groups, then one Horner chain of
+// 8 (W - 1) doublings (56 for the default layout, 8 for the latency layout)
+__global__ __launch_bounds__(64) void k_msm_combine(const G1Jac* __restrict__ window_sums, G1Jac* __restrict__ out, int nslots, int W) {
     const int o = blockIdx.x, tid = threadIdx.x;
     __shared__ uint32_t pts[8 * 36];
-    if (tid < 8) {
-        G1Jac s = window_sums[(o * nslots + 0) * 8 + tid];
-        for (int j = 1; j < nslots; j++) s = g1_add(s, window_sums[(o * nslots + j) * 8 + tid]);
+    if (tid < W) {
+        G1Jac s = window_sums[(o * nslots + 0) * W + tid];
+        for (int j = 1; j < nslots; j++) s = g1_add(s, window_sums[(o * nslots + j) * W + tid]);
         lds_store_jac(pts, tid, s);
     }
     __syncthreads();
     if (tid) return;
-    G1Jac acc = lds_load_jac(pts, 7);
-    for (int w = 6; w >= 0; w--) {
+    G1Jac acc = lds_load_jac(pts, W - 1);
+    for (int w = W - 2; w >= 0; w--) {
         for (int k = 0; k < MSM_C; k++) acc = g1_dbl(acc);
         acc = g1_add(acc, lds_load_jac(pts, w));
     }
