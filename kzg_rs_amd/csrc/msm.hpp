@@ -388,17 +388,26 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     }
 }
 
-// out[o] = sum_w 2^(8w) (sum_g S[o][g][w]), w < W: W threads fold the nslots chunk groups, then one Horner chain of
-// 8 (W - 1) doublings (56 for the default layout, 8 for the latency layout)
+// out[o] = sum_w 2^(8w) (sum_g S[o][g][w]), w < W: the nslots chunk groups of every window are folded by a tree over
+// nslots * W (<= 32) threads, then one Horner chain of 8 (W - 1) doublings (56 for the default layout, 8 for the
+// latency layout).  nslots is a power of two.
 __global__ __launch_bounds__(64) void k_msm_combine(const G1Jac* __restrict__ window_sums, G1Jac* __restrict__ out, int nslots, int W) {
     const int o = blockIdx.x, tid = threadIdx.x;
-    __shared__ uint32_t pts[8 * 36];
-    if (tid < W) {
-        G1Jac s = window_sums[(o * nslots + 0) * W + tid];
-        for (int j = 1; j < nslots; j++) s = g1_add(s, window_sums[(o * nslots + j) * W + tid]);
-        lds_store_jac(pts, tid, s);
-    }
+    __shared__ uint32_t pts[32 * 36];
+    const int total = nslots * W;  // slot (g, w) at index g * W + w
+    if (tid < total) lds_store_jac(pts, tid, window_sums[o * total + tid]);
     __syncthreads();
+    for (int half = nslots >> 1; half >= 1; half >>= 1) {  // fold group g + half into g
+        const bool active = tid < half * W;
+        G1Jac x = g1_identity(), y = g1_identity();
+        if (active) {
+            x = lds_load_jac(pts, tid);
+            y = lds_load_jac(pts, tid + half * W);
+        }
+        __syncthreads();
+        if (active) lds_store_jac(pts, tid, g1_add(x, y));
+        __syncthreads();
+    }
     if (tid) return;
     G1Jac acc = lds_load_jac(pts, W - 1);
     for (int w = W - 2; w >= 0; w--) {
