@@ -417,6 +417,7 @@ struct DevProgram {
 };
 
 constexpr size_t MAX_WORLD = 64;
+constexpr unsigned MSM_MAX_SLICES = 32;
 constexpr size_t LATENCY_MAX_BLOBS = 4096;  // launches up to this size: CU-split stream pair + the latency MSM layout
 struct Workspace {
     size_t cap_n = 0;       // batch capacity
@@ -428,7 +429,7 @@ struct Workspace {
     Fr *d_z = nullptr, *d_y = nullptr, *d_scalars = nullptr, *d_partial = nullptr, *d_r = nullptr;
     uint32_t *d_status = nullptr, *d_pflag = nullptr, *d_term_point = nullptr, *d_term_scalar = nullptr, *d_sorted = nullptr;
     G1Aff* d_points = nullptr;
-    G1Jac *d_window = nullptr, *d_ab = nullptr, *d_mult = nullptr, *d_parts = nullptr;
+    G1Jac *d_window = nullptr, *d_window_sl = nullptr, *d_ab = nullptr, *d_mult = nullptr, *d_parts = nullptr;
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
     uint8_t *d_stage_blobs = nullptr, *d_stage_cp = nullptr, *d_bytes = nullptr, *d_records = nullptr;
     // pinned host mirrors
@@ -684,7 +685,7 @@ extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_
 
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
-                    w.d_sorted, w.d_points, w.d_window, w.d_ab, w.d_mult, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
+                    w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_mult, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
                     w.d_records};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -765,6 +766,7 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
         HIPCHK(hipMalloc(&w.d_sorted, 4 * MSM_WINDOWS * nterm));
         HIPCHK(hipMalloc(&w.d_points, sizeof(G1Aff) * np));
         HIPCHK(hipMalloc(&w.d_window, sizeof(G1Jac) * 2 * MSM_WINDOWS * capB));
+        HIPCHK(hipMalloc(&w.d_window_sl, sizeof(G1Jac) * 2 * MSM_WINDOWS * MSM_MAX_SLICES * 4));  // sliced launches have <= 4 batches
         HIPCHK(hipMalloc(&w.d_mult, sizeof(G1Jac) * std::max((size_t)MSM_CHUNKS * np, (size_t)MSM_CHUNKS_LATENCY * std::min(np, (size_t)(2 * LATENCY_MAX_BLOBS + 1)))));
         HIPCHK(hipMalloc(&w.d_ab, sizeof(G1Jac) * 2 * capB));
         HIPCHK(hipMalloc(&w.d_parts, sizeof(G1Jac) * 2 * capB * MAX_WORLD));
@@ -828,10 +830,18 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     d.chunks = w.chunks;
     d.chunks_per_block = w.chunks == MSM_CHUNKS ? msm_chunks_per_block(B) : 1;
     const unsigned slots = d.chunks / d.chunks_per_block, W = MSM_WINDOWS / d.chunks;
+    // one large batch: slice the terms of an output over several workgroups until the launch has ~1000 of them
+    // (each slice keeps >= 1024 terms of the smaller output)
+    unsigned S = 1;
+    while (S < MSM_MAX_SLICES && W * slots * 2 * B * S < 768 && n / (2 * S) >= 1024) S *= 2;
+    d.slices = (int)S;
+    d.window_sums = S > 1 ? w.d_window_sl : w.d_window;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     const int nsc = (int)(B * (2 * n + 1));
     hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc);
-    hipLaunchKernelGGL(k_msm_window, dim3(W, slots, (unsigned)(2 * B)), dim3(256), 0, s->s1, d);
+    hipLaunchKernelGGL(k_msm_window, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
+    if (S > 1)
+        hipLaunchKernelGGL(k_msm_fold_slices, dim3((unsigned)(2 * B * slots * W)), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, (int)W);
     hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(2 * B)), dim3(64), 0, s->s1, w.d_window, w.d_ab, (int)slots, (int)W);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
@@ -1389,6 +1399,7 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     d.nterms[1] = 0;
     d.max_terms = mt;
     d.stride = mt;
+    d.slices = 1;
     d.chunks = MSM_CHUNKS;
     d.chunks_per_block = 1;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
@@ -1599,6 +1610,7 @@ static KzgRet setup_msm(const KzgSettings* s, ProverBufs& b, size_t m) {
     d.nterms[0] = d.nterms[1] = (int)NT;
     d.max_terms = (int)NT;
     d.stride = (int)NT;
+    d.slices = 1;
     d.chunks = MSM_CHUNKS;
     d.chunks_per_block = m >= 16 ? 4 : 1;
     const unsigned slots = MSM_CHUNKS / d.chunks_per_block;

@@ -223,6 +223,10 @@ struct MsmDesc {
     int nterms[2];
     int max_terms;
     int stride;
+    int slices;                   // term slices per output (power of two, >= 1): blockIdx.z = (2 batch + output) * slices +
+                                  // slice; slice k sums terms [k nt / slices, (k + 1) nt / slices) into its own window sums
+                                  // [2B][slots][slices][W], folded by k_msm_fold_slices - what keeps ONE large batch
+                                  // (tens of thousands of terms per output) from running on a few dozen workgroups
     int chunks;                   // MSM_CHUNKS or MSM_CHUNKS_LATENCY; windows per chunk = 32 / chunks = gridDim.x
     int chunks_per_block;         // 1: a block per (window, chunk) - most parallel, lowest latency;  4: a block per window
                                   // sums the four chunks' terms into ONE bucket set - a quarter of the reductions and
@@ -256,15 +260,17 @@ __device__ __forceinline__ G1Jac lds_load_jac(const uint32_t* base, int slot) {
 #define KZG_MSM_OCC 3
 #endif
 __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
-    // blockIdx.z = 2*batch + output
-    const int w = blockIdx.x, bo = blockIdx.z, o = bo & 1, tid = threadIdx.x;
+    // blockIdx.z = (2*batch + output) * slices + slice
+    const int S = d.slices, bo = blockIdx.z / S, slice = blockIdx.z % S;
+    const int w = blockIdx.x, o = bo & 1, tid = threadIdx.x;
     const int cpb = d.chunks_per_block, j0 = blockIdx.y * cpb;
-    const int nt = d.nterms[o];
-    const int W = gridDim.x;                                // windows (digit bytes) per chunk
-    const int wi = (bo * gridDim.y + blockIdx.y) * W + w;  // window slot
-    const uint32_t* tp = d.term_point + (size_t)bo * d.max_terms;
-    const uint32_t* tsc = d.term_scalar + (size_t)bo * d.max_terms;
-    uint32_t* sorted = d.sorted + (size_t)wi * cpb * d.max_terms;
+    const int W = gridDim.x;                                              // windows (digit bytes) per chunk
+    const int wi = ((bo * gridDim.y + blockIdx.y) * S + slice) * W + w;  // window slot
+    const int t0 = (int)((long long)d.nterms[o] * slice / S), nt = (int)((long long)d.nterms[o] * (slice + 1) / S) - t0;
+    const uint32_t* tp = d.term_point + (size_t)bo * d.max_terms + t0;
+    const uint32_t* tsc = d.term_scalar + (size_t)bo * d.max_terms + t0;
+    // scratch of this block: the (window, chunk group) region of its output, then the slice's share of it
+    uint32_t* sorted = d.sorted + ((size_t)(bo * gridDim.y + blockIdx.y) * W + w) * cpb * d.max_terms + (size_t)cpb * t0;
     __shared__ uint32_t cnt[MSM_BUCKETS], off[MSM_BUCKETS + 1], cur[MSM_BUCKETS];
     __shared__ uint32_t pts[MSM_BUCKETS * 36];  // 36 KiB: one Jacobian point per thread
     cnt[tid] = 0;
@@ -386,6 +392,26 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
         for (int k = 0; k < 4; k++) r = g1_dbl(r);
         d.window_sums[wi] = g1_add(r, lds_load_jac(pts, 16));
     }
+}
+
+// sums[(g * slices + k) * W + w] over the slices k -> out[g * W + w]; one 64-thread workgroup per (g, w) of every output
+__global__ __launch_bounds__(64) void k_msm_fold_slices(const G1Jac* __restrict__ sums, G1Jac* __restrict__ out, int slices, int W) {
+    const int gw = blockIdx.x, g = gw / W, w = gw % W, tid = threadIdx.x;  // g runs over (2B x slots)
+    __shared__ uint32_t pts[64 * 36];
+    if (tid < slices) lds_store_jac(pts, tid, sums[((size_t)g * slices + tid) * W + w]);
+    __syncthreads();
+    for (int half = slices >> 1; half >= 1; half >>= 1) {
+        const bool active = tid < half;
+        G1Jac x = g1_identity(), y = g1_identity();
+        if (active) {
+            x = lds_load_jac(pts, tid);
+            y = lds_load_jac(pts, tid + half);
+        }
+        __syncthreads();
+        if (active) lds_store_jac(pts, tid, g1_add(x, y));
+        __syncthreads();
+    }
+    if (tid == 0) out[(size_t)g * W + w] = lds_load_jac(pts, 0);
 }
 
 // out[o] = sum_w 2^(8w) (sum_g S[o][g][w]), w < W: the nslots chunk groups of every window are folded by a tree over

@@ -101,3 +101,37 @@ def test_config4_msm_2_pow_20_points(settings):
         sums[i & 4095] += int.from_bytes(sc[i].tobytes(), "big")
     want = O.g1_msm(b"".join(base), b"".join((s % R).to_bytes(32, "big") for s in sums), 4096)
     assert got == want
+
+
+def test_config5_shard_size_single_batch():
+    """BASELINE config 5 is ONE batch of 262 144 blobs, 32 768 per GPU.  A single batch of 20 000 blobs (2.6 GB) on one
+    GPU runs every kernel at that kind of size - the one-lane-per-blob challenge kernel, MSM rows of 20 000 and
+    40 001 terms in one bucket set, a 3.2 MB transcript - through size-independent properties: valid -> true, one
+    corrupted proof anywhere -> false, one non-canonical element -> Err, and two uneven sub-batches -> true."""
+    import torch
+    from kzg_rs_amd import synth
+    from kzg_rs_amd.api import KzgError, KzgProof
+    n = 20000
+    blobs, cs, ps, st = synth.make_valid_batch(n, seed=55, chunk=2000)
+    d_blobs = torch.from_numpy(blobs).cuda()
+    d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).cuda()
+    d_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    run = lambda b, c, p, k: KzgProof.verify_blob_kzg_proof_batch_device(b, c, p, k, st)
+    assert run(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n) is True
+    t = st.last_timings()
+    print("config-5 shard size, one batch of %d blobs: %.1f ms device time (challenge %.1f, evaluate %.1f, decode %.1f, msm %.1f, pairing %.1f)"
+          % (n, t[0], t[5], t[4], t[6], t[2], t[3]))
+    lo = 7001
+    assert run(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), lo) is True
+    assert run(d_blobs.data_ptr() + lo * 131072, d_c.data_ptr() + 48 * lo, d_p.data_ptr() + 48 * lo, n - lo) is True
+    bad = list(ps)
+    bad[n - 3] = O.g1_add(ps[n - 3], bytes.fromhex(
+        "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"))
+    d_pb = torch.frombuffer(bytearray(b"".join(bad)), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    assert run(d_blobs.data_ptr(), d_c.data_ptr(), d_pb.data_ptr(), n) is False
+    d_blobs[12345, 32 * 4000: 32 * 4001] = torch.tensor(list(R.to_bytes(32, "big")), dtype=torch.uint8)
+    torch.cuda.synchronize()
+    with pytest.raises(KzgError):
+        run(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
