@@ -1399,11 +1399,15 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     d.nterms[1] = 0;
     d.max_terms = mt;
     d.stride = mt;
-    d.slices = 1;
+    unsigned S = 1;  // slice a large MSM over more workgroups (msm.hpp MsmDesc::slices)
+    while (S < MSM_MAX_SLICES && 8 * MSM_CHUNKS * S < 768 && n / (2 * S) >= 1024) S *= 2;
+    d.slices = (int)S;
+    d.window_sums = S > 1 ? w.d_window_sl : w.d_window;
     d.chunks = MSM_CHUNKS;
     d.chunks_per_block = 1;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
-    hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, 1), dim3(256), 0, s->s1, d);
+    hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, S), dim3(256), 0, s->s1, d);
+    if (S > 1) hipLaunchKernelGGL(k_msm_fold_slices, dim3(MSM_CHUNKS * 8), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, 8);
     hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, w.d_window, w.d_ab, MSM_CHUNKS, 8);
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
     hipLaunchKernelGGL(k_jac_compress, dim3(1), dim3(64), 0, s->s1, w.d_ab, w.d_bytes, 1);
