@@ -1229,6 +1229,7 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
         if (be_geq_r(zs + 32 * i) || be_geq_r(ys + 32 * i)) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    select_streams(s, n);
     KzgRet rc = ws_reserve(s, n, 1, true);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
@@ -1270,6 +1271,7 @@ extern "C" KzgRet kzg_compute_challenges(uint8_t* z_out, const uint8_t* blobs, c
     if (n == 0) return KZG_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
     KzgRet rc = ws_reserve(s, n, 1, true);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
@@ -1304,6 +1306,7 @@ extern "C" KzgRet kzg_evaluate_polynomials_device(void* d_y, const void* d_blobs
     if (n == 0) return KZG_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
     KzgRet rc = ws_reserve(s, n, 1, false);
     if (rc != KZG_OK) return rc;
     bool bad = false;
@@ -1316,6 +1319,7 @@ extern "C" KzgRet kzg_evaluate_polynomials(uint8_t* ys_out, const uint8_t* blobs
     if (n == 0) return KZG_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
     KzgRet rc = ws_reserve(s, n, 1, true);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
@@ -1336,6 +1340,7 @@ extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const 
     if (n == 0) return KZG_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
     KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, 1, false);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
@@ -1361,6 +1366,7 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     if (!s || !out || (n && (!points48 || !scalars))) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
     KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, 1, false);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
@@ -1423,6 +1429,7 @@ extern "C" KzgRet kzg_g1_mul_generator(uint8_t* out48, const uint8_t* scalars, s
     if (n == 0) return KZG_OK;
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
     std::vector<uint8_t> le(32 * n);
     for (size_t i = 0; i < n; i++) {
         uint8_t t[32];
@@ -1448,6 +1455,7 @@ extern "C" KzgRet kzg_pairing_check(bool* ok, const uint8_t a[48], const uint8_t
     if (!ok || !a || !b || !s) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
     KzgRet rc = ws_reserve(s, 2, 1, false);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
@@ -1632,6 +1640,7 @@ extern "C" KzgRet kzg_blob_to_kzg_commitment(uint8_t* out48, const uint8_t* blob
     if (rc != KZG_OK || n == 0) return rc;
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
     ProverBufs b;
     if ((rc = b.alloc()) != KZG_OK) return rc;
     for (size_t lo = 0; lo < n; lo += PROVER_CHUNK) {
@@ -1662,6 +1671,7 @@ static KzgRet compute_proofs(uint8_t* proofs48, uint8_t* ys32, const uint8_t* bl
             if (be_geq_r(zs + 32 * i)) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");  // (sic) :36-41
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);
     ProverBufs b;
     if ((rc = b.alloc()) != KZG_OK) return rc;
     std::vector<uint8_t> le(32 * PROVER_CHUNK);
