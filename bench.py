@@ -83,14 +83,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    # KZG_BENCH_SHARE_GPU=1 (test rig only): all ranks on cuda:0 with gloo for the exchanges - lets the N > 1 code
+    # path of this script run on a one-GPU box; the numbers it prints then mean nothing
+    share = os.environ.get("KZG_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = "cpu" if share else dev  # where the collectives' tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from kzg_rs_amd import api, synth
     from kzg_rs_amd.distributed import HipBackend, PipelinedVerifier, verify_blob_kzg_proof_batch_sharded
@@ -118,7 +127,7 @@ def main():
     n_handles = sum(depth) + 1
     handles = [settings] + [api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1]) for _ in range(n_handles - 1)]
     backends = [backend0] + [HipBackend(h) for h in handles[1:]]
-    pipe = PipelinedVerifier(backends, dist, dev, depth, equal_shards=True)
+    pipe = PipelinedVerifier(backends, dist, coll_dev, depth, equal_shards=True)
     # every batch is a different permutation of the rank's shard (different transcript and r), at its own HBM address
     gen = torch.Generator(device="cpu").manual_seed(7 + rank)
     c_t, p_t = d_c.view(n, 48), d_p.view(n, 48)
@@ -155,7 +164,7 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if dist:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el, out
@@ -177,7 +186,7 @@ def main():
             if world == 1:
                 ok = api.KzgProof.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, settings)
             else:
-                ok = verify_blob_kzg_proof_batch_sharded((d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n), n, backend0, dist, dev)
+                ok = verify_blob_kzg_proof_batch_sharded((d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n), n, backend0, dist, coll_dev)
             if not ok:
                 raise SystemExit("verification of a valid synthetic batch returned false")
 

@@ -128,3 +128,21 @@ def test_pipelined_groups_hip_path(world, scenario):
     (equal shards: records leave the library in device memory, come back as one gathered buffer)."""
     for rank, got, want in _run(world, scenario):
         assert got == want == [True, False, True, True, True], (rank, got, want)
+
+
+def test_bench_script_two_ranks_shared_gpu():
+    """bench.py's N > 1 code path (fixed-order pipeline, bulk exchange, sharded single-batch leg, max-over-ranks timing)
+    with two ranks sharing the test box's one GPU over gloo (KZG_BENCH_SHARE_GPU=1): must print one JSON line for
+    n_gpus = 2.  The driver's 8-GPU run differs only in the transport (RCCL) and in one GPU per rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, KZG_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "64", "--warmup", "1",
+           "--group", "16", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 64 and d["value"] > 0 and d["config"]["batch"] == 2048
