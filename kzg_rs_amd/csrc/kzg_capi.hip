@@ -502,6 +502,8 @@ static KzgRet run_program(const DevProgram& dp, const Fp* d_in, const Fp* d_set,
     return KZG_OK;
 }
 
+static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]);
+// a handle from g2_points[1]; on any failure everything allocated so far is released
 static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -509,6 +511,17 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
         return fail(KZG_ERROR, "no HIP device: this library has no CPU fallback");
     }
     KzgSettings* s = new KzgSettings();
+    KzgRet rc = settings_build(s, tau_g2);
+    if (rc != KZG_OK) {
+        const std::string msg = g_err;  // kzg_settings_free may run HIP calls; keep the first error
+        kzg_settings_free(s);
+        g_err = msg;
+        return rc;
+    }
+    *out = s;
+    return KZG_OK;
+}
+static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
     HIPCHK(hipGetDevice(&s->device));
     HIPCHK(hipStreamCreateWithFlags(&s->s_plain[0], hipStreamNonBlocking));
     s->s1 = s->s_plain[0];
@@ -565,13 +578,9 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
     HIPCHK(hipFree(d_bytes));
     HIPCHK(hipFree(d_flag));
     HIPCHK(hipFree(d_q));
-    if (flag != G1_OK) {
-        kzg_settings_free(s);
-        return fail(KZG_BAD_SETUP, "g2_points[1] is not a valid (finite) compressed G2 point");
-    }
+    if (flag != G1_OK) return fail(KZG_BAD_SETUP, "g2_points[1] is not a valid (finite) compressed G2 point");
     if (s->verify.p.n_set != 2 * s->prep.p.n_out || s->verify.p.n_in != 6 || s->prep.p.n_in != 4)
         return fail(KZG_ERROR, "embedded SLP programs do not fit together");
-    *out = s;
     return KZG_OK;
 }
 
