@@ -1202,6 +1202,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
     KzgRet rc = ws_reserve(s, n, 1, true);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
+    select_streams(s, n);  // before the staging copies: they must be on the stream the kernels of this launch run on
     HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
     HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
     HIPCHK(hipMemcpyAsync(w.d_stage_cp + 48 * n, proofs, 48 * n, hipMemcpyHostToDevice, s->s1));
@@ -1284,6 +1285,7 @@ extern "C" KzgRet kzg_compute_challenges(uint8_t* z_out, const uint8_t* blobs, c
     KzgRet rc = ws_reserve(s, n, 1, true);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
+    select_streams(s, n);  // before the staging copies: they must be on the stream the kernels of this launch run on
     HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
     HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
     if ((rc = launch_challenge(s, w.d_stage_blobs, w.d_stage_cp, w.d_z, n)) != KZG_OK) return rc;
