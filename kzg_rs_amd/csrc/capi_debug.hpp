@@ -1,0 +1,66 @@
+// capi_debug.hpp - diagnostic hooks and timings.
+// Part of the single translation unit kzg_capi.hip; not a stand-alone header.
+
+// diagnostic / test hook: the host-side SHA-256 used for the batch transcript (force_portable skips SHA-NI)
+extern "C" int kzg_debug_host_sha256(uint8_t out[32], const uint8_t* data, size_t len, int force_portable) {
+    if (force_portable) {
+        uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+        if (len % 64) return -1;
+        for (size_t i = 0; i < len / 64; i++) hostsha::block(st, data + 64 * i);
+        for (int i = 0; i < 8; i++) { out[4*i] = (uint8_t)(st[i] >> 24); out[4*i+1] = (uint8_t)(st[i] >> 16); out[4*i+2] = (uint8_t)(st[i] >> 8); out[4*i+3] = (uint8_t)st[i]; }
+        return 0;
+    }
+    hostsha::digest(out, data, len);
+    return hostsha::have_ni() ? 1 : 0;
+}
+
+// diagnostic: in-kernel shader clock (MHz) = delta s_memtime / delta s_memrealtime * 100 MHz
+__global__ void k_clock_probe(unsigned long long* out, int spin) {
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t x = threadIdx.x;
+    for (int i = 0; i < spin; i++) x = x * 1664525u + 1013904223u;
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = t1 - t0;
+        out[2 * blockIdx.x + 1] = r1 - r0 + (x == 12345u);
+    }
+}
+
+// diagnostic (tools/ only): run the VERIFY program on `instances` copies of zero inputs, `reps` times;
+// returns the average kernel time and the in-kernel shader clock seen by a 1-block probe launched alone.
+extern "C" KzgRet kzg_debug_slp_bench(float* ms_out, float* mhz_out, int instances, int reps, const KzgSettings* s) {
+    if (!s || !ms_out || instances < 1) return fail(KZG_BADARGS, "bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    Fp *d_in, *d_out;
+    unsigned long long* d_clk;
+    HIPCHK(hipMalloc(&d_in, sizeof(Fp) * 6 * instances));
+    HIPCHK(hipMalloc(&d_out, sizeof(Fp) * 6 * instances));
+    HIPCHK(hipMalloc(&d_clk, 16));
+    HIPCHK(hipMemset(d_in, 0, sizeof(Fp) * 6 * instances));
+    KzgRet rc = run_program(s->verify, d_in, s->d_prep, d_out, instances, s->s1);
+    if (rc != KZG_OK) return rc;
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipEventRecord(s->ev[2], s->s1));
+    for (int i = 0; i < reps; i++)
+        if ((rc = run_program(s->verify, d_in, s->d_prep, d_out, instances, s->s1)) != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[3], s->s1));
+    HIPCHK(hipEventSynchronize(s->ev[3]));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, s->ev[2], s->ev[3]));
+    *ms_out = ms / reps;
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, s->s1, d_clk, 200000);
+    unsigned long long h[2];
+    HIPCHK(hipMemcpyAsync(h, d_clk, 16, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    if (mhz_out) *mhz_out = h[1] ? (float)((double)h[0] / (double)h[1] * 100.0) : 0.f;
+    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_clk);
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_last_timings(const KzgSettings* s, float out_ms[8]) {
+    if (!s || !out_ms) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    memcpy(out_ms, s->timings, sizeof(float) * 8);
+    return KZG_OK;
+}

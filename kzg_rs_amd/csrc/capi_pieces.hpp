@@ -1,0 +1,305 @@
+// capi_pieces.hpp - pieces of the path exposed for parity tests and per-kernel benchmarks, settings accessors.
+// Part of the single translation unit kzg_capi.hip; not a stand-alone header.
+
+// ---------------------------------------------------------------- pieces
+extern "C" KzgRet kzg_compute_challenges(uint8_t* z_out, const uint8_t* blobs, const uint8_t* commitments, size_t n,
+                                         const KzgSettings* s) {
+    if (!s || !z_out || !blobs || !commitments) return fail(KZG_BADARGS, "null argument");
+    if (n == 0) return KZG_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
+    KzgRet rc = ws_reserve(s, n, 1, true);
+    if (rc != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    select_streams(s, n);  // before the staging copies: they must be on the stream the kernels of this launch run on
+    HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
+    if ((rc = launch_challenge(s, w.d_stage_blobs, w.d_stage_cp, w.d_z, n)) != KZG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(w.h_buf, w.d_z, 32 * n, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    for (size_t i = 0; i < n; i++) reverse32(z_out + 32 * i, w.h_buf + 32 * i);
+    return KZG_OK;
+}
+
+static KzgRet evaluate_device_locked(void* d_y, const void* d_blobs, const void* d_z, size_t n, const KzgSettings* s,
+                                     bool* any_bad) {
+    Workspace& w = s->ws;
+    HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * n, s->s1));
+    HIPCHK(hipEventRecord(s->ev[7], s->s1));
+    launch_evaluate(s, d_blobs, (const Fr*)d_z, (Fr*)d_y, w.d_status, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev[8], s->s1));
+    uint32_t* h_status = reinterpret_cast<uint32_t*>(w.h_buf + 64 * n);
+    HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * n, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    elapsed(&s->timings[4], s->ev[7], s->ev[8]);
+    *any_bad = false;
+    for (size_t i = 0; i < n; i++) *any_bad |= h_status[i] != 0;
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_evaluate_polynomials_device(void* d_y, const void* d_blobs, const void* d_z, size_t n, const KzgSettings* s) {
+    if (!s || !d_y || !d_blobs || !d_z) return fail(KZG_BADARGS, "null argument");
+    if (n == 0) return KZG_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
+    KzgRet rc = ws_reserve(s, n, 1, false);
+    if (rc != KZG_OK) return rc;
+    bool bad = false;
+    if ((rc = evaluate_device_locked(d_y, d_blobs, d_z, n, s, &bad)) != KZG_OK) return rc;
+    return bad ? fail(KZG_BADARGS, "Failed to parse G1Affine from bytes") : KZG_OK;
+}
+
+extern "C" KzgRet kzg_evaluate_polynomials(uint8_t* ys_out, const uint8_t* blobs, const uint8_t* zs, size_t n, const KzgSettings* s) {
+    if (!s || !ys_out || !blobs || !zs) return fail(KZG_BADARGS, "null argument");
+    if (n == 0) return KZG_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
+    KzgRet rc = ws_reserve(s, n, 1, true);
+    if (rc != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    for (size_t i = 0; i < n; i++) reverse32(w.h_buf + 32 * i, zs + 32 * i);
+    HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(w.d_z, w.h_buf, 32 * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    bool bad = false;
+    if ((rc = evaluate_device_locked(w.d_y, w.d_stage_blobs, w.d_z, n, s, &bad)) != KZG_OK) return rc;
+    if (bad) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    HIPCHK(hipMemcpy(w.h_buf, w.d_y, 32 * n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) reverse32(ys_out + 32 * i, w.h_buf + 32 * i);
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const uint8_t* points48, size_t n, const KzgSettings* s) {
+    if (!s || !status_out || !points48) return fail(KZG_BADARGS, "null argument");
+    if (n == 0) return KZG_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
+    KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, 1, false);
+    if (rc != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    HIPCHK(hipMemcpyAsync(w.d_bytes, points48, 48 * n, hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_bytes, w.d_bytes, (int)n, w.d_points, w.d_pflag, (int)n, 1);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> st(n);
+    HIPCHK(hipMemcpyAsync(st.data(), w.d_pflag, 4 * n, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    for (size_t i = 0; i < n; i++) status_out[i] = (uint8_t)st[i];
+    if (xy_out) {
+        uint8_t* d_xy;
+        HIPCHK(hipMalloc(&d_xy, 96 * n));
+        hipLaunchKernelGGL(k_aff_to_bytes, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_points, d_xy, (int)n);
+        HIPCHK(hipMemcpyAsync(xy_out, d_xy, 96 * n, hipMemcpyDeviceToHost, s->s1));
+        HIPCHK(hipStreamSynchronize(s->s1));
+        HIPCHK(hipFree(d_xy));
+    }
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uint8_t* scalars, size_t n, const KzgSettings* s) {
+    if (!s || !out || (n && (!points48 || !scalars))) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
+    KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, 1, false);
+    if (rc != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    int mt = (int)(n ? n : 1);
+    // scalars: big-endian, reduced mod r on the host (at most two subtractions), little-endian limbs on the device
+    std::vector<uint8_t> le(32 * (n ? n : 1));
+    for (size_t i = 0; i < n; i++) {
+        uint8_t t[32];
+        memcpy(t, scalars + 32 * i, 32);
+        while (be_geq_r(t)) be_sub_r(t);
+        reverse32(le.data() + 32 * i, t);
+    }
+    if (n) {
+        HIPCHK(hipMemcpyAsync(w.d_bytes, points48, 48 * n, hipMemcpyHostToDevice, s->s1));
+        HIPCHK(hipMemcpyAsync(w.d_scalars, le.data(), 32 * n, hipMemcpyHostToDevice, s->s1));
+        hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_bytes, w.d_bytes, (int)n, w.d_points, w.d_pflag, (int)n, 1);
+        hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, (int)n);
+        hipLaunchKernelGGL(k_plain_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar, (int)n);
+        HIPCHK(hipGetLastError());
+        std::vector<uint32_t> st(n);
+        HIPCHK(hipMemcpyAsync(st.data(), w.d_pflag, 4 * n, hipMemcpyDeviceToHost, s->s1));
+        HIPCHK(hipStreamSynchronize(s->s1));
+        for (size_t i = 0; i < n; i++)
+            if (st[i] == G1_INVALID) return fail(KZG_BADARGS, "invalid G1 point");
+    }
+    if (n) hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_points, w.d_pflag, w.d_mult, (int)n, mt, MSM_CHUNKS);
+    MsmDesc d{};
+    d.mult = w.d_mult;
+    d.pflag = w.d_pflag;
+    d.scalars = w.d_scalars;
+    d.term_point = w.d_term_point;
+    d.term_scalar = w.d_term_scalar;
+    d.sorted = w.d_sorted;
+    d.window_sums = w.d_window;
+    d.nterms[0] = (int)n;
+    d.nterms[1] = 0;
+    d.max_terms = mt;
+    d.stride = mt;
+    unsigned S = 1;  // slice a large MSM over more workgroups (msm.hpp MsmDesc::slices)
+    while (S < MSM_MAX_SLICES && 8 * MSM_CHUNKS * S < 768 && n / (2 * S) >= 1024) S *= 2;
+    d.slices = (int)S;
+    d.window_sums = S > 1 ? w.d_window_sl : w.d_window;
+    d.chunks = MSM_CHUNKS;
+    d.chunks_per_block = 1;
+    HIPCHK(hipEventRecord(s->ev[2], s->s1));
+    hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, S), dim3(256), 0, s->s1, d);
+    if (S > 1) hipLaunchKernelGGL(k_msm_fold_slices, dim3(MSM_CHUNKS * 8), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, 8);
+    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, w.d_window, w.d_ab, MSM_CHUNKS, 8);
+    HIPCHK(hipEventRecord(s->ev[3], s->s1));
+    hipLaunchKernelGGL(k_jac_compress, dim3(1), dim3(64), 0, s->s1, w.d_ab, w.d_bytes, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, w.d_bytes, 48, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    elapsed(&s->timings[2], s->ev[2], s->ev[3]);
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_g1_mul_generator(uint8_t* out48, const uint8_t* scalars, size_t n, const KzgSettings* s) {
+    if (!s || (n && (!out48 || !scalars))) return fail(KZG_BADARGS, "null argument");
+    if (n == 0) return KZG_OK;
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
+    std::vector<uint8_t> le(32 * n);
+    for (size_t i = 0; i < n; i++) {
+        uint8_t t[32];
+        memcpy(t, scalars + 32 * i, 32);
+        while (be_geq_r(t)) be_sub_r(t);
+        reverse32(le.data() + 32 * i, t);
+    }
+    Fr* d_s;
+    uint8_t* d_o;
+    HIPCHK(hipMalloc(&d_s, 32 * n));
+    HIPCHK(hipMalloc(&d_o, 48 * n));
+    HIPCHK(hipMemcpyAsync(d_s, le.data(), 32 * n, hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_g1_mul_generator, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, d_s, d_o, (int)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out48, d_o, 48 * n, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipFree(d_s));
+    HIPCHK(hipFree(d_o));
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_pairing_check(bool* ok, const uint8_t a[48], const uint8_t b[48], const KzgSettings* s) {
+    if (!ok || !a || !b || !s) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
+    KzgRet rc = ws_reserve(s, 2, 1, false);
+    if (rc != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    HIPCHK(hipMemcpyAsync(w.d_bytes, a, 48, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(w.d_bytes + 48, b, 48, hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_g1_decode, dim3(1), dim3(64), 0, s->s1, w.d_bytes, w.d_bytes, 2, w.d_points, w.d_pflag, 2, 0);
+    hipLaunchKernelGGL(k_aff_to_slp, dim3(1), dim3(64), 0, s->s1, w.d_points, w.d_pflag, w.d_slp_in);
+    HIPCHK(hipGetLastError());
+    uint32_t* h = reinterpret_cast<uint32_t*>(w.h_buf);
+    HIPCHK(hipMemcpyAsync(h, w.d_pflag, 8, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipEventRecord(s->ev[3], s->s1));
+    if ((rc = run_program(s->verify, w.d_slp_in, s->d_prep, w.d_slp_out, 1, s->s1)) != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[4], s->s1));
+    HIPCHK(hipMemcpyAsync(h + 2, w.d_slp_out, sizeof(Fp) * 6, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    elapsed(&s->timings[3], s->ev[3], s->ev[4]);
+    if (h[0] == G1_INVALID || h[1] == G1_INVALID) return fail(KZG_BADARGS, "invalid G1 point");
+    uint32_t any = 0;
+    for (int i = 0; i < 72; i++) any |= h[2 + i];
+    *ok = any == 0;
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_settings_root_of_unity(const KzgSettings* s, size_t i, uint8_t out[32]) {
+    if (!s || !out || i >= FE_PER_BLOB) return fail(KZG_BADARGS, "bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    // the table holds w*R mod r; strip the Montgomery factor with one host-side REDC (test/diagnostic path only)
+    Fr m;
+    HIPCHK(hipMemcpy(&m, s->d_M + i, sizeof(Fr), hipMemcpyDeviceToHost));
+    // host Montgomery reduction of one element: t = m * R^-1 mod r with 64-bit arithmetic
+    const uint32_t* MOD = consts::FR_MOD;
+    uint32_t t[9] = {0};
+    for (int k = 0; k < 8; k++) t[k] = m.l[k];
+    for (int k = 0; k < 8; k++) {
+        uint32_t q = t[0] * FR_INV32;
+        uint64_t c = ((uint64_t)q * MOD[0] + t[0]) >> 32;
+        for (int j = 1; j < 8; j++) {
+            uint64_t x = (uint64_t)q * MOD[j] + t[j] + c;
+            t[j - 1] = (uint32_t)x;
+            c = x >> 32;
+        }
+        uint64_t x = (uint64_t)t[8] + c;
+        t[7] = (uint32_t)x;
+        t[8] = (uint32_t)(x >> 32);
+    }
+    uint8_t be[32];
+    for (int k = 0; k < 8; k++) {
+        be[4 * (7 - k)] = (uint8_t)(t[k] >> 24); be[4 * (7 - k) + 1] = (uint8_t)(t[k] >> 16);
+        be[4 * (7 - k) + 2] = (uint8_t)(t[k] >> 8); be[4 * (7 - k) + 3] = (uint8_t)t[k];
+    }
+    if (t[8] || be_geq_r(be)) be_sub_r(be);
+    memcpy(out, be, 32);
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_settings_tau_g2(const KzgSettings* s, uint8_t out[96]) {
+    if (!s || !out) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    uint8_t* d;
+    HIPCHK(hipMalloc(&d, 96));
+    hipLaunchKernelGGL(k_g2_compress, dim3(1), dim3(64), 0, s->s1, s->d_tau4, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d, 96, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipFree(d));
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_settings_g1_point(const KzgSettings* s, size_t i, uint8_t out[48]) {
+    if (!s || !out || i >= FE_PER_BLOB) return fail(KZG_BADARGS, "bad argument");
+    if (!s->d_g1) return fail(KZG_BADARGS, "these settings were not loaded from a trusted-setup file");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    uint8_t* d;
+    HIPCHK(hipMalloc(&d, 48));
+    hipLaunchKernelGGL(k_aff_compress, dim3(1), dim3(64), 0, s->s1, s->d_g1 + i, s->d_g1_flag + i, d, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d, 48, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipFree(d));
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_settings_g2_point(const KzgSettings* s, size_t i, uint8_t out[96]) {
+    if (!s || !out) return fail(KZG_BADARGS, "bad argument");
+    if (!s->d_g2 || i >= s->n_g2) return fail(KZG_BADARGS, "no such G2 point in these settings");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    uint8_t* d;
+    HIPCHK(hipMalloc(&d, 96));
+    hipLaunchKernelGGL(k_g2_compress, dim3(1), dim3(64), 0, s->s1, s->d_g2 + 4 * i, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, d, 96, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipFree(d));
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_pairing_check(bool* ok, const uint8_t a[48], const uint8_t b[48], const KzgSettings* s);
+// is_trusted_setup_in_lagrange_form (build.rs:107-129; its result is discarded by the reference's loader):
+// e(g1[1], g2[0]) == e(g1[0], g2[1]) on the points in FILE order - true for a monomial-form G1 section, false for the
+// Lagrange-form file the crate ships.
+extern "C" KzgRet kzg_settings_is_monomial_form(bool* ok, const KzgSettings* s) {
+    if (!s || !ok) return fail(KZG_BADARGS, "null argument");
+    if (!s->d_g1) return fail(KZG_BADARGS, "these settings were not loaded from a trusted-setup file");
+    return kzg_pairing_check(ok, s->g1_first[0], s->g1_first[1], s);  // e(g1[0], [tau]G2) == e(g1[1], G2)
+}

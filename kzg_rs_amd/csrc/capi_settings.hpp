@@ -1,0 +1,307 @@
+// capi_settings.hpp - KzgSettings / Workspace and the construction of a handle (trusted-setup text parser, tables, prepared pairing lines).
+// Part of the single translation unit kzg_capi.hip; not a stand-alone header.
+
+// ---------------------------------------------------------------- settings
+struct DevProgram {
+    SlpProgram p{};
+    void* blob = nullptr;  // device copy of the whole program
+};
+
+constexpr size_t MAX_WORLD = 64;
+constexpr unsigned MSM_MAX_SLICES = 32;
+constexpr size_t LATENCY_MAX_BLOBS = 4096;  // launches up to this size: CU-split stream pair + the latency MSM layout
+struct Workspace {
+    size_t cap_n = 0;       // batch capacity
+    size_t cap_b = 0;       // batches-per-group capacity
+    size_t pending_n = 0, pending_b = 0, finish_b = 0;  // group currently in flight on this handle
+    int chunks = MSM_CHUNKS;                              // MSM layout of the group in flight (msm.hpp)
+    size_t off_r = 0, off_part = 0, off_out = 0, off_parts = 0;  // pinned-buffer layout
+    size_t cap_stage = 0;   // staged host-input capacity (blobs)
+    Fr *d_z = nullptr, *d_y = nullptr, *d_scalars = nullptr, *d_partial = nullptr, *d_r = nullptr;
+    uint32_t *d_status = nullptr, *d_pflag = nullptr, *d_term_point = nullptr, *d_term_scalar = nullptr, *d_sorted = nullptr;
+    G1Aff* d_points = nullptr;
+    G1Jac *d_window = nullptr, *d_window_sl = nullptr, *d_ab = nullptr, *d_mult = nullptr, *d_parts = nullptr;
+    Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
+    uint8_t *d_stage_blobs = nullptr, *d_stage_cp = nullptr, *d_bytes = nullptr, *d_records = nullptr;
+    // pinned host mirrors
+    uint8_t* h_buf = nullptr;
+    size_t h_cap = 0;
+};
+
+struct KzgSettings {
+    int device = 0;
+    Fr *d_M = nullptr, *d_DM = nullptr;            // roots of unity, 8x32 Montgomery (R, R^2 scalings)
+    Fr29Mem *d_M29 = nullptr, *d_DM29 = nullptr;   // the same in radix 2^29 (fr29.hpp), what k_blob_evaluate reads
+    Fp* d_tau4 = nullptr;   // [tau]G2 affine (x.c0 x.c1 y.c0 y.c1), Montgomery
+    Fp* d_prep = nullptr;   // prepared lines: [tau]G2 then generator (2 * 408 Fp)
+    G1Jac* d_gen_mult = nullptr;  // the generator's MSM tables: [0, 4) the default layout, [4, 20) the latency layout (msm.hpp)
+    // full trusted setup (kzg_settings_load_trusted_setup only; not needed by verification):
+    G1Aff* d_g1 = nullptr;            // g1_points, bit-reversal permuted (build.rs:79,89-105), 4096 entries
+    uint32_t* d_g1_flag = nullptr;    // 0 finite / 1 identity (unchecked decode, build.rs:68)
+    G1Jac* d_g1_mult = nullptr;       // their MSM multiples (msm.hpp), valid iff g1_in_subgroup
+    bool g1_in_subgroup = false;      // every G1 point lies in the r-torsion (what the GLV multiples need)
+    Fp* d_g2 = nullptr;               // g2_points (monomial), n_g2 x 4 Fp
+    size_t n_g2 = 0;
+    uint8_t g1_first[2][48] = {};     // g1_points[0], [1] of the FILE order, for the monomial-form check (build.rs:107-129)
+    DevProgram prep, verify;
+    // s1 / s2: the two streams the current launch uses (challenge chain | point decode).  They point at the plain pair,
+    // or - for a small launch (a single batch) - at a pair confined to disjoint halves of the CUs: the 16 two-wave
+    // workgroups of the challenge chain and the 32 decode waves otherwise land on the same first CUs of every XCD and,
+    // run to run, share SIMDs (the chain then takes 4.9 ms instead of 3.5 ms).  Measured: one 1 024-blob batch 9.1 ms on
+    // the split pair, 10.1-11.5 ms on the plain pair; KZG_CU_MASK=0 disables the split pair.
+    mutable hipStream_t s1 = nullptr, s2 = nullptr;
+    hipStream_t s_plain[2] = {nullptr, nullptr};
+    mutable hipStream_t s_half[2] = {nullptr, nullptr};
+    mutable bool s_half_tried = false;
+    hipEvent_t ev[12] = {};
+    mutable std::mutex mu;
+    mutable Workspace ws;
+    mutable float timings[8] = {};
+};
+
+static KzgRet upload_program(DevProgram& dp, const unsigned char* begin, const unsigned char* end) {
+    size_t len = (size_t)(end - begin);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(begin);
+    if (len < 64 || w[0] != SLP_MAGIC) return fail(KZG_ERROR, "embedded SLP program is corrupt");
+    HIPCHK(hipMalloc(&dp.blob, len));
+    HIPCHK(hipMemcpy(dp.blob, begin, len, hipMemcpyHostToDevice));
+    SlpProgram& p = dp.p;
+    p.lanes = w[1]; p.n_slots = w[2]; p.n_steps = w[3]; p.n_const = w[4]; p.n_in = w[5]; p.n_set = w[6]; p.n_out = w[7];
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(dp.blob);
+    size_t off = 16;
+    p.consts = reinterpret_cast<const Fp*>(d + off);
+    off += (size_t)12 * p.n_const;
+    p.out_slots = d + off;
+    off += p.n_out;
+    p.kinds = d + off;
+    off += p.n_steps;
+    p.desc = reinterpret_cast<const uint2*>(d + off);
+    if ((off + (size_t)2 * p.lanes * p.n_steps) * 4 != len) return fail(KZG_ERROR, "embedded SLP program has the wrong size");
+    return KZG_OK;
+}
+
+static KzgRet run_program(const DevProgram& dp, const Fp* d_in, const Fp* d_set, Fp* d_out, int instances, hipStream_t st) {
+    size_t lds = (size_t)dp.p.n_slots * 48 + (size_t)2 * SLP_GROUP * dp.p.lanes * sizeof(uint2);  // slots | descriptor ring
+    if (dp.p.lanes == 64) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp_run<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_slp_run<false>, dim3(instances), dim3(64), lds, st, dp.p, d_in, d_set, d_out);
+    } else {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp_run<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_slp_run<true>, dim3(instances), dim3(dp.p.lanes), lds, st, dp.p, d_in, d_set, d_out);
+    }
+    HIPCHK(hipGetLastError());
+    return KZG_OK;
+}
+
+static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]);
+// a handle from g2_points[1]; on any failure everything allocated so far is released
+static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return fail(KZG_ERROR, "no HIP device: this library has no CPU fallback");
+    }
+    KzgSettings* s = new KzgSettings();
+    KzgRet rc = settings_build(s, tau_g2);
+    if (rc != KZG_OK) {
+        const std::string msg = g_err;  // kzg_settings_free may run HIP calls; keep the first error
+        kzg_settings_free(s);
+        g_err = msg;
+        return rc;
+    }
+    *out = s;
+    return KZG_OK;
+}
+static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
+    HIPCHK(hipGetDevice(&s->device));
+    HIPCHK(hipStreamCreateWithFlags(&s->s_plain[0], hipStreamNonBlocking));
+    s->s1 = s->s_plain[0];
+    // KZG_SINGLE_STREAM=1 (profiling aid): run the point-decode chain on the same stream as the challenge chain, so
+    // per-dispatch PMC counters are not polluted by a concurrent kernel
+    if (getenv("KZG_SINGLE_STREAM") && getenv("KZG_SINGLE_STREAM")[0] == '1') s->s2 = s->s1;
+    else {
+        HIPCHK(hipStreamCreateWithFlags(&s->s_plain[1], hipStreamNonBlocking));
+        s->s2 = s->s_plain[1];
+    }
+    for (auto& e : s->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipMalloc(&s->d_M, sizeof(Fr) * FE_PER_BLOB));
+    HIPCHK(hipMalloc(&s->d_DM, sizeof(Fr) * FE_PER_BLOB));
+    HIPCHK(hipMalloc(&s->d_M29, sizeof(Fr29Mem) * FE_PER_BLOB));
+    HIPCHK(hipMalloc(&s->d_DM29, sizeof(Fr29Mem) * FE_PER_BLOB));
+    hipLaunchKernelGGL(k_roots_tables, dim3(FE_PER_BLOB / 64), dim3(64), 0, s->s1, s->d_M, s->d_DM);
+    hipLaunchKernelGGL(k_roots_tables29, dim3(FE_PER_BLOB / 64), dim3(64), 0, s->s1, s->d_M, s->d_M29, s->d_DM29);
+    HIPCHK(hipGetLastError());
+    KzgRet rc;
+    if ((rc = upload_program(s->prep, kzg_slp_prep_begin, kzg_slp_prep_end)) != KZG_OK) return rc;
+    if ((rc = upload_program(s->verify, kzg_slp_verify_begin, kzg_slp_verify_end)) != KZG_OK) return rc;
+    // decompress [tau]G2 on the device, then prepare the lines of [tau]G2 and of the generator
+    uint8_t* d_bytes;
+    uint32_t* d_flag;
+    Fp* d_q;  // 2 instances x 4 Fp
+    HIPCHK(hipMalloc(&d_bytes, 96));
+    HIPCHK(hipMalloc(&d_flag, 4));
+    HIPCHK(hipMalloc(&d_q, sizeof(Fp) * 8));
+    HIPCHK(hipMalloc(&s->d_tau4, sizeof(Fp) * 4));
+    HIPCHK(hipMalloc(&s->d_prep, sizeof(Fp) * 2 * s->prep.p.n_out));
+    HIPCHK(hipMemcpyAsync(d_bytes, tau_g2, 96, hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_g2_decompress, dim3(1), dim3(64), 0, s->s1, d_bytes, d_q, d_flag);
+    hipLaunchKernelGGL(k_g2_generator, dim3(1), dim3(64), 0, s->s1, d_q + 4);
+    HIPCHK(hipGetLastError());
+    uint32_t flag = 0;
+    HIPCHK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(s->d_tau4, d_q, sizeof(Fp) * 4, hipMemcpyDeviceToDevice, s->s1));
+    if ((rc = run_program(s->prep, d_q, nullptr, s->d_prep, 2, s->s1)) != KZG_OK) return rc;
+    {  // multiples of the generator (msm.hpp): the same for every batch
+        G1Aff* d_g;
+        uint32_t* d_gf;
+        HIPCHK(hipMalloc(&d_g, sizeof(G1Aff)));
+        HIPCHK(hipMalloc(&d_gf, 4));
+        HIPCHK(hipMalloc(&s->d_gen_mult, sizeof(G1Jac) * (MSM_CHUNKS + MSM_CHUNKS_LATENCY)));
+        hipLaunchKernelGGL(k_set_generator, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, 0);
+        hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, s->d_gen_mult, 1, 1, MSM_CHUNKS);
+        hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, s->d_gen_mult + MSM_CHUNKS, 1, 1, MSM_CHUNKS_LATENCY);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s->s1));
+        HIPCHK(hipFree(d_g));
+        HIPCHK(hipFree(d_gf));
+    }
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipFree(d_bytes));
+    HIPCHK(hipFree(d_flag));
+    HIPCHK(hipFree(d_q));
+    if (flag != G1_OK) return fail(KZG_BAD_SETUP, "g2_points[1] is not a valid (finite) compressed G2 point");
+    if (s->verify.p.n_set != 2 * s->prep.p.n_out || s->verify.p.n_in != 6 || s->prep.p.n_in != 4)
+        return fail(KZG_ERROR, "embedded SLP programs do not fit together");
+    return KZG_OK;
+}
+
+static int hexnib(int c) {
+    if (c >= '0' && c <= '9') return c - '0';
+    if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+    if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+    return -1;
+}
+
+extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char* txt, size_t len) {
+    if (!out || !txt) return fail(KZG_BADARGS, "null argument");
+    // line-oriented parse of build.rs:23-56
+    std::vector<std::pair<const char*, size_t>> lines;
+    const char *p = txt, *end = txt + len;
+    while (p < end) {
+        const char* q = (const char*)memchr(p, '\n', (size_t)(end - p));
+        if (!q) q = end;
+        size_t l = (size_t)(q - p);
+        if (l && p[l - 1] == '\r') l--;
+        lines.emplace_back(p, l);
+        p = q + 1;
+    }
+    if (lines.size() < 2) return fail(KZG_BAD_SETUP, "trusted setup: missing header lines");
+    long n1 = strtol(std::string(lines[0].first, lines[0].second).c_str(), nullptr, 10);
+    long n2 = strtol(std::string(lines[1].first, lines[1].second).c_str(), nullptr, 10);
+    if (n1 != FE_PER_BLOB) return fail(KZG_BAD_SETUP, "trusted setup: expected 4096 G1 points");
+    if (n2 < 2 || (long)lines.size() < 2 + n1 + n2) return fail(KZG_BAD_SETUP, "trusted setup: truncated file");
+    // hex -> bytes for every point line (hex_to_bytes, build.rs:15-21: KzgError::InvalidHexFormat)
+    auto unhex = [&](uint8_t* dst, const std::pair<const char*, size_t>& ln, size_t nbytes) {
+        if (ln.second != 2 * nbytes) return false;
+        for (size_t i = 0; i < nbytes; i++) {
+            int a = hexnib(ln.first[2 * i]), b = hexnib(ln.first[2 * i + 1]);
+            if (a < 0 || b < 0) return false;
+            dst[i] = (uint8_t)(a << 4 | b);
+        }
+        return true;
+    };
+    std::vector<uint8_t> g1b(48 * (size_t)n1), g2b(96 * (size_t)n2);
+    uint8_t first[2][48];
+    for (long i = 0; i < n1; i++) {
+        // stored bit-reversal permuted (build.rs:79,89-105): file line i -> slot brp(i)
+        uint8_t tmp[48];
+        if (!unhex(tmp, lines[2 + i], 48)) return fail(KZG_BAD_SETUP, "trusted setup: bad G1 line");
+        if (i < 2) memcpy(first[i], tmp, 48);
+        uint32_t r = 0;
+        for (int k = 0; k < 12; k++) r |= ((uint32_t)(i >> k) & 1u) << (11 - k);
+        memcpy(g1b.data() + 48 * (size_t)r, tmp, 48);
+    }
+    for (long i = 0; i < n2; i++)
+        if (!unhex(g2b.data() + 96 * (size_t)i, lines[2 + n1 + i], 96)) return fail(KZG_BAD_SETUP, "trusted setup: bad G2 line");
+    KzgRet rc = settings_common(out, g2b.data() + 96);
+    if (rc != KZG_OK) return rc;
+    KzgSettings* s = *out;
+    *out = nullptr;
+    auto bail = [&](KzgRet code, const char* msg) {
+        kzg_settings_free(s);
+        return fail(code, msg);
+    };
+    memcpy(s->g1_first, first, sizeof first);
+    // G1 Lagrange points: unchecked decode (build.rs:66-70) for the table, and the decode + subgroup test + multiples
+    // pass of the MSM (msm.hpp) so that commitments can be computed against them
+    uint8_t* d_bytes;
+    uint32_t *d_flag2, *d_gflag;
+    G1Aff* d_tmp;
+    const int N = (int)n1;
+    HIPCHK(hipMalloc(&d_bytes, std::max(g1b.size(), g2b.size())));
+    HIPCHK(hipMalloc(&d_flag2, 4 * (size_t)N));
+    HIPCHK(hipMalloc(&d_tmp, sizeof(G1Aff) * (size_t)N));
+    HIPCHK(hipMalloc(&s->d_g1, sizeof(G1Aff) * (size_t)N));
+    HIPCHK(hipMalloc(&s->d_g1_flag, 4 * (size_t)N));
+    HIPCHK(hipMalloc(&s->d_g1_mult, sizeof(G1Jac) * MSM_CHUNKS * (size_t)N));
+    HIPCHK(hipMemcpyAsync(d_bytes, g1b.data(), g1b.size(), hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, s->d_g1, s->d_g1_flag, N, 0);
+    hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
+                       d_flag2, s->d_g1_mult, N, N);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> f1((size_t)N), f2((size_t)N);
+    HIPCHK(hipMemcpyAsync(f1.data(), s->d_g1_flag, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(f2.data(), d_flag2, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    s->g1_in_subgroup = true;
+    for (int i = 0; i < N; i++) {
+        if (f1[i] == G1_INVALID) return bail(KZG_BAD_SETUP, "load_trusted_setup Invalid g1 bytes");
+        if (f2[i] == G1_INVALID) s->g1_in_subgroup = false;
+    }
+    // G2 monomial points: all of them decoded (build.rs:72-75); verification itself reads only [1]
+    s->n_g2 = (size_t)n2;
+    HIPCHK(hipMalloc(&s->d_g2, sizeof(Fp) * 4 * (size_t)n2));
+    HIPCHK(hipMalloc(&d_gflag, 4 * (size_t)n2));
+    HIPCHK(hipMemcpyAsync(d_bytes, g2b.data(), g2b.size(), hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_g2_decompress_n, dim3((unsigned)n2), dim3(64), 0, s->s1, d_bytes, s->d_g2, d_gflag);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> fg((size_t)n2);
+    HIPCHK(hipMemcpyAsync(fg.data(), d_gflag, 4 * (size_t)n2, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipFree(d_bytes));
+    HIPCHK(hipFree(d_flag2));
+    HIPCHK(hipFree(d_gflag));
+    HIPCHK(hipFree(d_tmp));
+    for (long i = 0; i < n2; i++)
+        if (fg[(size_t)i] == G1_INVALID) return bail(KZG_BAD_SETUP, "load_trusted_setup Invalid g2 bytes");
+    *out = s;
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_g2[96]) {
+    if (!out || !tau_g2) return fail(KZG_BADARGS, "null argument");
+    return settings_common(out, tau_g2);
+}
+
+static void ws_free(Workspace& w) {
+    void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
+                    w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_mult, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
+                    w.d_records};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (w.h_buf) (void)hipHostFree(w.h_buf);
+    w = Workspace();
+}
+
+extern "C" void kzg_settings_free(KzgSettings* s) {
+    if (!s) return;
+    ws_free(s->ws);
+    void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_tau4, s->d_prep, s->d_gen_mult, s->prep.blob, s->verify.blob};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto& e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {s->s_plain[0], s->s_plain[1], s->s_half[0], s->s_half[1]})
+        if (st) (void)hipStreamDestroy(st);
+    delete s;
+}

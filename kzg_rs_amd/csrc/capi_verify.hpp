@@ -1,0 +1,561 @@
+// capi_verify.hpp - the verification path: kernel selection, workspace, MSM tail, the three phases as launch + wait, and the entry points.
+// Part of the single translation unit kzg_capi.hip; not a stand-alone header.
+
+// The evaluation kernel over T blobs on stream s1 (radix-2^29 form; KZG_EVALUATE_KERNEL=32 selects the 8x32 form,
+// kept for A/B measurement and as a cross-check).
+static void launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr* d_z, Fr* d_y, uint32_t* d_status, size_t T) {
+    static const bool use32 = [] {
+        const char* e = getenv("KZG_EVALUATE_KERNEL");
+        return e && strcmp(e, "32") == 0;
+    }();
+    if (use32)
+        hipLaunchKernelGGL(k_blob_evaluate32, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, d_z, s->d_M, s->d_DM, d_y, d_status);
+    else
+        hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, d_z, s->d_M29, s->d_DM29, d_y, d_status);
+}
+
+// The challenge kernel over T blobs on stream s1: the producer/consumer form (half the serial chain, lowest latency)
+// while every pair of waves can have a CU to itself, the one-lane-per-blob form (highest throughput) beyond that.
+// KZG_CHALLENGE_KERNEL = lane | split forces one of them (A/B measurement, cross-check in the tests).
+static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const void* d_commitments, Fr* d_z, size_t T) {
+    static const int forced = [] {
+        const char* e = getenv("KZG_CHALLENGE_KERNEL");
+        return !e ? 0 : strcmp(e, "lane") == 0 ? 1 : strcmp(e, "split") == 0 ? 2 : 0;
+    }();
+    const uint8_t *bl = (const uint8_t*)d_blobs, *cm = (const uint8_t*)d_commitments;
+    const bool lane = forced ? forced == 1 : T > 64 * 256;
+    if (lane)
+        hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s->s1, bl, cm, d_z, (int)T);
+    else
+        hipLaunchKernelGGL(k_blob_challenge_split, dim3((unsigned)((T + 63) / 64)), dim3(128), 0, s->s1, bl, cm, d_z, (int)T);
+    HIPCHK(hipGetLastError());
+    return KZG_OK;
+}
+
+// Workspace for a launch group of B batches with T blobs in total (B = 1 for the single-call entry points).
+static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
+    Workspace& w = s->ws;
+    if (T > w.cap_n || B > w.cap_b) {
+        size_t keep_stage = w.cap_stage;
+        uint8_t *sb = w.d_stage_blobs, *sc = w.d_stage_cp;
+        w.d_stage_blobs = nullptr;
+        w.d_stage_cp = nullptr;
+        size_t capT = T > w.cap_n ? T : w.cap_n, capB = B > w.cap_b ? B : w.cap_b;
+        ws_free(w);
+        w.d_stage_blobs = sb;
+        w.d_stage_cp = sc;
+        w.cap_stage = keep_stage;
+        if (capT < 16) capT = 16;
+        const size_t np = 2 * capT + 1;            // points: C's, pi's, generator
+        const size_t nsc = 2 * capT + capB;        // scalars: (2n+1) per batch
+        const size_t nterm = 4 * capT + 2 * capB;  // term table rows: [2B][2n+1]
+        HIPCHK(hipMalloc(&w.d_z, sizeof(Fr) * capT));
+        HIPCHK(hipMalloc(&w.d_y, sizeof(Fr) * capT));
+        HIPCHK(hipMalloc(&w.d_scalars, sizeof(Fr) * nsc));
+        HIPCHK(hipMalloc(&w.d_partial, sizeof(Fr) * ((capT + 255) / 256 + capB)));
+        HIPCHK(hipMalloc(&w.d_r, sizeof(Fr) * capB));
+        HIPCHK(hipMalloc(&w.d_status, 4 * capT));
+        HIPCHK(hipMalloc(&w.d_pflag, 4 * np));
+        HIPCHK(hipMalloc(&w.d_term_point, 4 * nterm));
+        HIPCHK(hipMalloc(&w.d_term_scalar, 4 * nterm));
+        HIPCHK(hipMalloc(&w.d_sorted, 4 * MSM_WINDOWS * nterm));
+        HIPCHK(hipMalloc(&w.d_points, sizeof(G1Aff) * np));
+        HIPCHK(hipMalloc(&w.d_window, sizeof(G1Jac) * 2 * MSM_WINDOWS * capB));
+        HIPCHK(hipMalloc(&w.d_window_sl, sizeof(G1Jac) * 2 * MSM_WINDOWS * MSM_MAX_SLICES * 4));  // sliced launches have <= 4 batches
+        HIPCHK(hipMalloc(&w.d_mult, sizeof(G1Jac) * std::max((size_t)MSM_CHUNKS * np, (size_t)MSM_CHUNKS_LATENCY * std::min(np, (size_t)(2 * LATENCY_MAX_BLOBS + 1)))));
+        HIPCHK(hipMalloc(&w.d_ab, sizeof(G1Jac) * 2 * capB));
+        HIPCHK(hipMalloc(&w.d_parts, sizeof(G1Jac) * 2 * capB * MAX_WORLD));
+        HIPCHK(hipMalloc(&w.d_slp_in, sizeof(Fp) * 6 * capB));
+        HIPCHK(hipMalloc(&w.d_slp_out, sizeof(Fp) * 6 * capB));
+        HIPCHK(hipMalloc(&w.d_bytes, 96 * np));
+        HIPCHK(hipMalloc(&w.d_records, 160 * capT));
+        w.off_r = 256 * capT + 4096;                 // pinned layout: [per-blob area | r | own partials | out | gathered partials]
+        w.off_part = w.off_r + 32 * capB;
+        w.off_out = w.off_part + 288 * capB;
+        w.off_parts = w.off_out + 288 * capB;
+        w.h_cap = w.off_parts + 288 * capB * MAX_WORLD;
+        HIPCHK(hipHostMalloc(&w.h_buf, w.h_cap));
+        w.cap_n = capT;
+        w.cap_b = capB;
+    }
+    if (stage && T > w.cap_stage) {
+        if (w.d_stage_blobs) (void)hipFree(w.d_stage_blobs);
+        if (w.d_stage_cp) (void)hipFree(w.d_stage_cp);
+        w.d_stage_blobs = w.d_stage_cp = nullptr;
+        size_t cap = T < 4 ? 4 : T;
+        HIPCHK(hipMalloc(&w.d_stage_blobs, (size_t)BLOB_BYTES * cap));
+        HIPCHK(hipMalloc(&w.d_stage_cp, 96 * cap));
+        w.cap_stage = cap;
+    }
+    return KZG_OK;
+}
+
+// (window, chunk) blocks of the MSM: separate while the launch has few batches (latency), merged per window once the
+// batch dimension alone fills the chip (msm.hpp MsmDesc::chunks_per_block); KZG_MSM_CPB = 1 | 2 | 4 overrides.
+static int msm_chunks_per_block(size_t B) {
+    static const int forced = [] {
+        const char* e = getenv("KZG_MSM_CPB");
+        int v = e ? atoi(e) : 0;
+        return (v == 1 || v == 2 || v == 4) ? v : 0;
+    }();
+    if (forced) return forced;
+    return B >= 32 ? 4 : B >= 16 ? 2 : 1;
+}
+
+// ---------------------------------------------------------------- the tail: MSM + pairing
+// Group of B batches of n blobs (T = B n).  scalars of batch b at b(2n+1): a [0,n), b [n,2n), g at 2n;
+// points: C [0,T), pi [T,2T), G at 2T, multiples with stride 2T+1.  Leaves (A, B) of batch b in ws.d_ab[2b..].
+static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
+    Workspace& w = s->ws;
+    const int T = (int)(n * B), mt = (int)(2 * n + 1);
+    hipLaunchKernelGGL(k_batch_terms, dim3((unsigned)((n + 255) / 256), (unsigned)B), dim3(256), 0, s->s1, w.d_term_point,
+                       w.d_term_scalar, (int)n, T, mt);
+    MsmDesc d{};
+    d.mult = w.d_mult;
+    d.pflag = w.d_pflag;
+    d.scalars = w.d_scalars;
+    d.term_point = w.d_term_point;
+    d.term_scalar = w.d_term_scalar;
+    d.sorted = w.d_sorted;
+    d.window_sums = w.d_window;
+    d.nterms[0] = (int)n;
+    d.nterms[1] = (int)(2 * n + 1);
+    d.max_terms = mt;
+    d.stride = 2 * T + 1;
+    d.chunks = w.chunks;
+    d.chunks_per_block = w.chunks == MSM_CHUNKS ? msm_chunks_per_block(B) : 1;
+    const unsigned slots = d.chunks / d.chunks_per_block, W = MSM_WINDOWS / d.chunks;
+    // one large batch: slice the terms of an output over several workgroups until the launch has ~1000 of them
+    // (each slice keeps >= 1024 terms of the smaller output)
+    unsigned S = 1;
+    while (S < MSM_MAX_SLICES && W * slots * 2 * B * S < 768 && n / (2 * S) >= 1024) S *= 2;
+    d.slices = (int)S;
+    d.window_sums = S > 1 ? w.d_window_sl : w.d_window;
+    HIPCHK(hipEventRecord(s->ev[2], s->s1));
+    const int nsc = (int)(B * (2 * n + 1));
+    hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc);
+    hipLaunchKernelGGL(k_msm_window, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
+    if (S > 1)
+        hipLaunchKernelGGL(k_msm_fold_slices, dim3((unsigned)(2 * B * slots * W)), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, (int)W);
+    hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(2 * B)), dim3(64), 0, s->s1, w.d_window, w.d_ab, (int)slots, (int)W);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev[3], s->s1));
+    return KZG_OK;
+}
+
+// decode 2T points (all C then all pi) into ws.d_points / d_pflag together with their 2^(64j) multiples, generator
+// (precomputed multiples) as point 2T - all on stream s2, beside the SHA-256 chain
+static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, const void* d_proofs, size_t T) {
+    Workspace& w = s->ws;
+    const int np = (int)(2 * T + 1);
+    unsigned blocks = (unsigned)((2 * T + 63) / 64);
+    static const bool no_latency_layout = getenv("KZG_MSM_LATENCY_LAYOUT") && getenv("KZG_MSM_LATENCY_LAYOUT")[0] == '0';
+    w.chunks = (T <= LATENCY_MAX_BLOBS && !no_latency_layout) ? MSM_CHUNKS_LATENCY : MSM_CHUNKS;
+    const uint8_t *c = (const uint8_t*)d_commitments, *p = (const uint8_t*)d_proofs;
+    if (w.chunks == MSM_CHUNKS_LATENCY)
+        hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag,
+                           w.d_mult, (int)(2 * T), np);
+    else
+        hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult,
+                           (int)(2 * T), np);
+    HIPCHK(hipEventRecord(s->ev[10], s->s2));
+    hipLaunchKernelGGL(k_set_generator_multiples, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, w.d_mult,
+                       s->d_gen_mult + (w.chunks == MSM_CHUNKS ? 0 : MSM_CHUNKS), (int)(2 * T), np, w.chunks);
+    HIPCHK(hipGetLastError());
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------- the three phases, each as launch + wait
+// A handle is a small state machine: phase1_launch -> phase1_wait -> phase2_launch -> phase2_wait ->
+// finish_launch -> finish_wait.  Launch halves only enqueue work on the handle's streams (plus the host
+// transcript hashes in phase 2); wait halves block on this handle's stream only.  A call processes a launch
+// GROUP of B independent batches of n blobs each (own transcript, r, MSM and pairing instance per batch): at
+// n = 1024 every phase is a latency-bound serial chain that uses a sliver of the chip, so the batch dimension
+// inside the kernels is what fills the machine.
+
+// The stream pair of a launch of T blobs (KzgSettings::s1/s2): the split pair, made on first use, for a small launch.
+// Every earlier launch of the handle has been waited for by then, so switching pairs is safe.
+static void select_streams(const KzgSettings* s, size_t T) {
+    if (!s->s_plain[1]) return;  // KZG_SINGLE_STREAM
+    const bool small = T <= LATENCY_MAX_BLOBS;
+    if (small && !s->s_half_tried) {
+        s->s_half_tried = true;
+        const char* e = getenv("KZG_CU_MASK");
+        hipDeviceProp_t prop;
+        if (!(e && e[0] == '0') && hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount >= 64) {
+            const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+            std::vector<uint32_t> lo(words, 0), hi(words, 0);
+            for (int i = 0; i < ncu; i++) ((i < ncu / 2) ? lo : hi)[i / 32] |= 1u << (i % 32);
+            if (hipExtStreamCreateWithCUMask(&s->s_half[0], words, lo.data()) != hipSuccess ||
+                hipExtStreamCreateWithCUMask(&s->s_half[1], words, hi.data()) != hipSuccess) {
+                (void)hipGetLastError();
+                if (s->s_half[0]) (void)hipStreamDestroy(s->s_half[0]);
+                s->s_half[0] = s->s_half[1] = nullptr;
+            }
+        }
+    }
+    const bool use_half = small && s->s_half[0];
+    s->s1 = use_half ? s->s_half[0] : s->s_plain[0];
+    s->s2 = use_half ? s->s_half[1] : s->s_plain[1];
+}
+
+// Phase 1 (no communication): point decode + multiples || (challenge -> evaluate) for all T = B n blobs.
+static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n, size_t B,
+                                   const KzgSettings* s) {
+    Workspace& w = s->ws;
+    const size_t T = n * B;
+    KzgRet rc;
+    select_streams(s, T);
+    HIPCHK(hipEventRecord(s->ev[0], s->s1));
+    HIPCHK(hipStreamWaitEvent(s->s2, s->ev[0], 0));
+    HIPCHK(hipEventRecord(s->ev[5], s->s2));
+    if ((rc = launch_decode(s, d_commitments, d_proofs, T)) != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[6], s->s2));
+    HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * T, s->s1));
+    if ((rc = launch_challenge(s, d_blobs, d_commitments, w.d_z, T)) != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[7], s->s1));
+    launch_evaluate(s, d_blobs, w.d_z, w.d_y, w.d_status, T);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev[8], s->s1));
+    HIPCHK(hipStreamWaitEvent(s->s1, s->ev[6], 0));
+    HIPCHK(hipEventRecord(s->ev[1], s->s1));
+    // the transcript records, packed on the device; pinned host mirror: [records 160 T | status 4 T | point flags 8 T]
+    hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((40 * T + 255) / 256)), dim3(256), 0, s->s1, (const uint32_t*)d_commitments,
+                       (const uint32_t*)d_proofs, (const uint32_t*)w.d_z, (const uint32_t*)w.d_y, (uint32_t*)w.d_records, (int)T);
+    HIPCHK(hipGetLastError());
+    uint8_t* h = w.h_buf;
+    uint32_t* h_status = reinterpret_cast<uint32_t*>(h + 160 * T);
+    uint32_t* h_pflag = h_status + T;
+    HIPCHK(hipMemcpyAsync(h, w.d_records, 160 * T, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * T, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * T, hipMemcpyDeviceToHost, s->s1));
+    w.pending_n = n;
+    w.pending_b = B;
+    return KZG_OK;
+}
+
+// records_out (optional): [B][n] x 160 bytes  C(48) || z(32, LE) || y(32, LE) || pi(48) - exactly the per-blob slices
+// of the batch transcripts of src/kzg_proof.rs:314-334.  The handle keeps them (pinned host + device) for phase 2.  bad_out (optional, B bytes): 1 where a batch holds an invalid input
+// (then the call still returns KZG_OK); without bad_out any invalid input makes the whole call return KZG_BADARGS.
+static KzgRet phase1_wait_locked(uint8_t* records_out, uint8_t* bad_out, const KzgSettings* s) {
+    Workspace& w = s->ws;
+    const size_t n = w.pending_n, B = w.pending_b, T = n * B;
+    HIPCHK(hipStreamSynchronize(s->s1));
+    elapsed(&s->timings[1], s->ev[0], s->ev[1]);
+    elapsed(&s->timings[4], s->ev[7], s->ev[8]);
+    elapsed(&s->timings[5], s->ev[0], s->ev[7]);
+    elapsed(&s->timings[6], s->ev[5], s->ev[10]);
+    elapsed(&s->timings[7], s->ev[10], s->ev[6]);
+    uint8_t* h = w.h_buf;
+    uint32_t* h_status = reinterpret_cast<uint32_t*>(h + 160 * T);
+    uint32_t* h_pflag = h_status + T;
+    // error order of the reference: commitments (:503), proofs (:508), then blobs (:263); all map to BadArgs
+    bool any_bad = false;
+    for (size_t b = 0; b < B; b++) {
+        bool bad = false;
+        for (size_t i = b * n; i < (b + 1) * n; i++) bad |= h_pflag[i] == G1_INVALID || h_pflag[T + i] == G1_INVALID || h_status[i] != 0;
+        if (bad_out) bad_out[b] = bad;
+        any_bad |= bad;
+    }
+    if (any_bad && !bad_out) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");  // (sic) src/kzg_proof.rs:19-23,38-40
+    if (records_out) memcpy(records_out, h, 160 * T);  // the device limb arrays ARE Scalar::to_bytes() (little-endian), :321,:326
+    return KZG_OK;
+}
+
+// Phase 2: per batch b, r_b from its FULL transcript, this shard's scalars r_b^(offset+i) and its partial sums (A, B)_b.
+// Requires phase 1 of the same group on this handle.  The records come in one of three layouts:
+//   all_records != NULL, world == 0 : [B][n_total]          every batch's records in global blob order
+//   all_records != NULL, world  > 0 : [world][B][n]         as an all-gather of equal shards leaves them (n_total = world n)
+//   all_records == NULL             : the handle's own records of phase 1 (single rank: n_total = n)
+static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, size_t offset, const KzgSettings* s, size_t world = 0) {
+    Workspace& w = s->ws;
+    const size_t n = w.pending_n, B = w.pending_b;
+    if (!all_records) {
+        if (n_total != n || offset != 0) return fail(KZG_BADARGS, "local phase 2 needs n_total == n_local");
+        all_records = w.h_buf;
+        world = 0;
+    }
+    if (world && n_total != world * n) return fail(KZG_BADARGS, "gathered phase 2 needs equal shards");
+    if (n_total == 1) {
+        // verify_blob_kzg_proof path (:482-489): r^0 = 1, no batch challenge
+        hipLaunchKernelGGL(k_single_scalars, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_z, w.d_y, w.d_scalars);
+    } else {
+        // compute_r_powers :291-348, once per batch.  The transcripts are hashed on the host (SHA-NI): one serial chain
+        // of 160 n_total + 32 bytes per batch - hopeless on a GPU lane, ~2 GB/s on a CPU core - and the batches of a
+        // launch group are independent, so they are spread over a few host threads (KZG_HOST_THREADS, default 16).
+        auto digest_range = [&](size_t b0, size_t b1) {
+            std::vector<uint8_t> t(32 + 160 * n_total);
+            memcpy(t.data(), "RCKZGBATCH___V1_", 16);
+            memset(t.data() + 16, 0, 16);
+            t[22] = (uint8_t)(FE_PER_BLOB >> 8);
+            t[23] = (uint8_t)(FE_PER_BLOB & 0xff);
+            for (int k = 0; k < 8; k++) t[24 + k] = (uint8_t)((uint64_t)n_total >> (56 - 8 * k));
+            for (size_t b = b0; b < b1; b++) {
+                if (world == 0) memcpy(t.data() + 32, all_records + 160 * n_total * b, 160 * n_total);
+                else
+                    for (size_t k = 0; k < world; k++) memcpy(t.data() + 32 + 160 * n * k, all_records + 160 * n * (k * B + b), 160 * n);
+                uint8_t dg[32];
+                hostsha::digest(dg, t.data(), t.size());
+                while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r: at most two subtractions (2^256 < 3r)
+                reverse32(w.h_buf + w.off_r + 32 * b, dg);  // pinned staging for the async H2D copy
+            }
+        };
+        static const size_t host_threads = [] {
+            const char* e = getenv("KZG_HOST_THREADS");
+            long v = e ? atol(e) : 16;
+            return (size_t)(v < 1 ? 1 : v > 64 ? 64 : v);
+        }();
+        const size_t nthr = std::min(host_threads, std::min(B, (B * 160 * n_total) / (512 * 1024) + 1));
+        if (nthr <= 1) {
+            digest_range(0, B);
+        } else {
+            std::vector<std::thread> pool;
+            for (size_t k = 1; k < nthr; k++) pool.emplace_back(digest_range, B * k / nthr, B * (k + 1) / nthr);
+            digest_range(0, B / nthr);
+            for (auto& th : pool) th.join();
+        }
+        HIPCHK(hipMemcpyAsync(w.d_r, w.h_buf + w.off_r, 32 * B, hipMemcpyHostToDevice, s->s1));
+        unsigned blocks = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_batch_scalars, dim3(blocks, (unsigned)B), dim3(256), 0, s->s1, w.d_r, w.d_z, w.d_y, w.d_scalars,
+                           w.d_partial, (int)n, (unsigned long long)offset);
+        hipLaunchKernelGGL(k_finish_g, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_partial, (int)blocks, w.d_scalars, (int)n);
+    }
+    HIPCHK(hipGetLastError());
+    KzgRet rc = run_msm(s, n, B);
+    if (rc != KZG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(w.h_buf + w.off_part, w.d_ab, 288 * B, hipMemcpyDeviceToHost, s->s1));
+    return KZG_OK;
+}
+
+static KzgRet phase2_wait_locked(uint8_t* partial_out /* B x 288 */, const KzgSettings* s) {
+    Workspace& w = s->ws;
+    HIPCHK(hipStreamSynchronize(s->s1));
+    elapsed(&s->timings[2], s->ev[2], s->ev[3]);
+    if (partial_out) memcpy(partial_out, w.h_buf + w.off_part, 288 * w.pending_b);
+    return KZG_OK;
+}
+
+// Finish: fold `world` partial sets ([world][B] x 288 B), or take the handle's own (A, B)_b when partials == nullptr,
+// and run one pairing instance per batch.
+static KzgRet finish_launch_locked(const uint8_t* partials, size_t world, size_t B, const KzgSettings* s) {
+    Workspace& w = s->ws;
+    if (partials) {
+        if (world > MAX_WORLD) return fail(KZG_BADARGS, "world size above 64");
+        memcpy(w.h_buf + w.off_parts, partials, 288 * world * B);
+        HIPCHK(hipMemcpyAsync(w.d_parts, w.h_buf + w.off_parts, 288 * world * B, hipMemcpyHostToDevice, s->s1));
+        hipLaunchKernelGGL(k_fold_partials, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_parts, (int)world, (int)B, w.d_ab);
+    }
+    hipLaunchKernelGGL(k_jac_to_slp, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_ab, w.d_slp_in);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev[4], s->s1));
+    KzgRet rc = run_program(s->verify, w.d_slp_in, s->d_prep, w.d_slp_out, (int)B, s->s1);
+    if (rc != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[9], s->s1));
+    HIPCHK(hipMemcpyAsync(w.h_buf + w.off_out, w.d_slp_out, sizeof(Fp) * 6 * B, hipMemcpyDeviceToHost, s->s1));
+    w.finish_b = B;
+    return KZG_OK;
+}
+
+static KzgRet finish_wait_locked(bool* ok /* B */, const KzgSettings* s) {
+    Workspace& w = s->ws;
+    HIPCHK(hipStreamSynchronize(s->s1));
+    const uint32_t* h = reinterpret_cast<const uint32_t*>(w.h_buf + w.off_out);
+    for (size_t b = 0; b < w.finish_b; b++) {
+        uint32_t any = 0;
+        for (int i = 0; i < 72; i++) any |= h[72 * b + i];
+        ok[b] = any == 0;
+    }
+    elapsed(&s->timings[2], s->ev[2], s->ev[3]);
+    elapsed(&s->timings[3], s->ev[4], s->ev[9]);
+    elapsed(&s->timings[0], s->ev[0], s->ev[9]);
+    return KZG_OK;
+}
+
+static KzgRet batch_device_locked(bool* ok, const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n,
+                                  const KzgSettings* s) {
+    KzgRet rc;
+    if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, 1, s)) != KZG_OK) return rc;
+    if ((rc = phase1_wait_locked(nullptr, nullptr, s)) != KZG_OK) return rc;
+    if ((rc = phase2_launch_locked(nullptr, n, 0, s)) != KZG_OK) return rc;
+    if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;  // same stream: no host round trip needed
+    return finish_wait_locked(ok, s);
+}
+
+// ---- multi-GPU / grouped / pipelined entry points (include/kzg_rs_amd.h) ----
+#define KZG_ENTER(cond)                                          \
+    if (!(cond)) return fail(KZG_BADARGS, "bad argument");       \
+    std::lock_guard<std::mutex> lk(s->mu);                       \
+    HIPCHK(hipSetDevice(s->device));
+
+extern "C" KzgRet kzg_shard_phase1_launch(const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n_local,
+                                          size_t n_batches, const KzgSettings* s) {
+    KZG_ENTER(s && d_blobs && d_commitments && d_proofs && n_local && n_batches);
+    KzgRet rc = ws_reserve(s, n_local * n_batches, n_batches, false);
+    if (rc != KZG_OK) return rc;
+    return phase1_launch_locked(d_blobs, d_commitments, d_proofs, n_local, n_batches, s);
+}
+extern "C" KzgRet kzg_shard_phase1_wait(uint8_t* records_out, uint8_t* bad_out, const KzgSettings* s) {
+    KZG_ENTER(s && s->ws.pending_n);
+    return phase1_wait_locked(records_out, bad_out, s);
+}
+extern "C" KzgRet kzg_shard_phase2_launch(const uint8_t* all_records, size_t n_total, size_t offset, const KzgSettings* s) {
+    KZG_ENTER(s && s->ws.pending_n && offset + s->ws.pending_n <= n_total);
+    return phase2_launch_locked(all_records, n_total, offset, s);
+}
+extern "C" KzgRet kzg_shard_phase2_launch_gathered(const uint8_t* gathered, size_t world, size_t rank, const KzgSettings* s) {
+    KZG_ENTER(s && gathered && s->ws.pending_n && world && rank < world);
+    return phase2_launch_locked(gathered, world * s->ws.pending_n, rank * s->ws.pending_n, s, world);
+}
+extern "C" KzgRet kzg_shard_records_device(void* d_records_out, const KzgSettings* s) {
+    KZG_ENTER(s && d_records_out && s->ws.pending_n);
+    HIPCHK(hipMemcpyAsync(d_records_out, s->ws.d_records, 160 * s->ws.pending_n * s->ws.pending_b, hipMemcpyDeviceToDevice, s->s1));
+    return KZG_OK;
+}
+extern "C" KzgRet kzg_shard_phase2_wait(uint8_t* partial_out, const KzgSettings* s) {
+    KZG_ENTER(s && partial_out);
+    return phase2_wait_locked(partial_out, s);
+}
+extern "C" KzgRet kzg_shard_finish_launch(const uint8_t* partials, size_t world, size_t n_batches, const KzgSettings* s) {
+    KZG_ENTER(s && n_batches && (partials ? world > 0 : true));  // partials == NULL: pair this handle's own sums (single rank)
+    KzgRet rc = ws_reserve(s, 2 * n_batches, n_batches, false);
+    if (rc != KZG_OK) return rc;
+    return finish_launch_locked(partials, world, n_batches, s);
+}
+extern "C" KzgRet kzg_shard_finish_wait(bool* ok, const KzgSettings* s) {
+    KZG_ENTER(s && ok);
+    return finish_wait_locked(ok, s);
+}
+// blocking single-batch forms
+extern "C" KzgRet kzg_shard_phase1(uint8_t* records_out, const void* d_blobs, const void* d_commitments, const void* d_proofs,
+                                   size_t n_local, const KzgSettings* s) {
+    KzgRet rc = kzg_shard_phase1_launch(d_blobs, d_commitments, d_proofs, n_local, 1, s);
+    return rc != KZG_OK ? rc : kzg_shard_phase1_wait(records_out, nullptr, s);
+}
+extern "C" KzgRet kzg_shard_phase2(uint8_t partial_out[288], const uint8_t* all_records, size_t n_total, size_t offset,
+                                   size_t n_local, const KzgSettings* s) {
+    if (s && n_local != s->ws.pending_n) return fail(KZG_BADARGS, "kzg_shard_phase2 without a matching kzg_shard_phase1");
+    KzgRet rc = kzg_shard_phase2_launch(all_records, n_total, offset, s);
+    return rc != KZG_OK ? rc : kzg_shard_phase2_wait(partial_out, s);
+}
+extern "C" KzgRet kzg_shard_finish(bool* ok, const uint8_t* partials, size_t world, const KzgSettings* s) {
+    KzgRet rc = kzg_shard_finish_launch(partials, world, 1, s);
+    return rc != KZG_OK ? rc : kzg_shard_finish_wait(ok, s);
+}
+
+// B independent batches of n blobs each in ONE launch group: blobs / commitments / proofs are contiguous device
+// arrays of B*n entries, batch b = entries [b n, (b+1) n); ok_out[b] and (optional) err_out[b] per batch.
+extern "C" KzgRet kzg_verify_blob_kzg_proof_batches_device(bool* ok_out, uint8_t* err_out, const void* d_blobs, const void* d_commitments,
+                                                           const void* d_proofs, size_t n, size_t n_batches, const KzgSettings* s) {
+    KZG_ENTER(s && ok_out && d_blobs && d_commitments && d_proofs && n && n_batches);
+    KzgRet rc = ws_reserve(s, n * n_batches, n_batches, false);
+    if (rc != KZG_OK) return rc;
+    if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, n_batches, s)) != KZG_OK) return rc;
+    if ((rc = phase1_wait_locked(nullptr, err_out, s)) != KZG_OK) return rc;
+    if ((rc = phase2_launch_locked(nullptr, n, 0, s)) != KZG_OK) return rc;
+    if ((rc = finish_launch_locked(nullptr, 1, n_batches, s)) != KZG_OK) return rc;
+    if ((rc = finish_wait_locked(ok_out, s)) != KZG_OK) return rc;
+    if (err_out)
+        for (size_t b = 0; b < n_batches; b++)
+            if (err_out[b]) ok_out[b] = false;
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_device(bool* ok, const void* d_blobs, const void* d_commitments,
+                                                         const void* d_proofs, size_t n, const KzgSettings* s) {
+    if (!ok || !s) return fail(KZG_BADARGS, "null argument");
+    if (n == 0) {  // src/kzg_proof.rs:478-480
+        *ok = true;
+        return KZG_OK;
+    }
+    if (!d_blobs || !d_commitments || !d_proofs) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    KzgRet rc = ws_reserve(s, n, 1, false);
+    if (rc != KZG_OK) return rc;
+    return batch_device_locked(ok, d_blobs, d_commitments, d_proofs, n, s);
+}
+
+extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs, const uint8_t* commitments,
+                                                  const uint8_t* proofs, size_t n, const KzgSettings* s) {
+    if (!ok || !s) return fail(KZG_BADARGS, "null argument");
+    if (n == 0) {
+        *ok = true;
+        return KZG_OK;
+    }
+    if (!blobs || !commitments || !proofs) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    KzgRet rc = ws_reserve(s, n, 1, true);
+    if (rc != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    select_streams(s, n);  // before the staging copies: they must be on the stream the kernels of this launch run on
+    HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(w.d_stage_cp + 48 * n, proofs, 48 * n, hipMemcpyHostToDevice, s->s1));
+    return batch_device_locked(ok, w.d_stage_blobs, w.d_stage_cp, w.d_stage_cp + 48 * n, n, s);
+}
+
+extern "C" KzgRet kzg_verify_blob_kzg_proof(bool* ok, const uint8_t* blob, const uint8_t commitment[48], const uint8_t proof[48],
+                                            const KzgSettings* s) {
+    // src/kzg_proof.rs:446-470; the batch entry's n == 1 branch is this very function (:482-489)
+    return kzg_verify_blob_kzg_proof_batch(ok, blob, commitment, proof, 1, s);
+}
+
+extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitments, const uint8_t* zs, const uint8_t* ys,
+                                             const uint8_t* proofs, size_t n, const KzgSettings* s);
+extern "C" KzgRet kzg_verify_kzg_proof(bool* ok, const uint8_t commitment[48], const uint8_t z[32], const uint8_t y[32],
+                                       const uint8_t proof[48], const KzgSettings* s) {
+    // src/kzg_proof.rs:353-397: the same equation as the batch form with the single scalar r^0 = 1:
+    // e(pi, [tau]G2) == e(C - [y]G + [z]pi, G2)  <=>  e(pi, [tau - z]G2) == e(C - [y]G, G2)
+    if (!commitment || !z || !y || !proof) return fail(KZG_BADARGS, "null argument");
+    return kzg_verify_kzg_proof_batch(ok, commitment, z, y, proof, 1, s);
+}
+
+// KzgProof::verify_kzg_proof_batch (src/kzg_proof.rs:399-444) over byte inputs: n (commitment, z, y, proof) tuples checked
+// with ONE random linear combination and ONE pairing.  Same pipeline as the blob batch minus challenge + evaluation.
+extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitments, const uint8_t* zs, const uint8_t* ys,
+                                             const uint8_t* proofs, size_t n, const KzgSettings* s) {
+    if (!ok || !s) return fail(KZG_BADARGS, "null argument");
+    if (n == 0) {  // compute_r_powers on an empty batch: both MSMs are the identity, e(O, .) == e(O, .)
+        *ok = true;
+        return KZG_OK;
+    }
+    if (!commitments || !zs || !ys || !proofs) return fail(KZG_BADARGS, "null argument");
+    for (size_t i = 0; i < n; i++)
+        if (be_geq_r(zs + 32 * i) || be_geq_r(ys + 32 * i)) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    select_streams(s, n);
+    KzgRet rc = ws_reserve(s, n, 1, true);
+    if (rc != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    HIPCHK(hipEventRecord(s->ev[0], s->s1));
+    // z, y: big-endian -> the device's little-endian limb arrays (= the transcript's encoding)
+    std::vector<uint8_t> records(160 * n);
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* o = records.data() + 160 * i;
+        memcpy(o, commitments + 48 * i, 48);
+        reverse32(o + 48, zs + 32 * i);
+        reverse32(o + 80, ys + 32 * i);
+        memcpy(o + 112, proofs + 48 * i, 48);
+        memcpy(w.h_buf + 32 * i, o + 48, 32);
+        memcpy(w.h_buf + 32 * n + 32 * i, o + 80, 32);
+    }
+    HIPCHK(hipMemcpyAsync(w.d_z, w.h_buf, 32 * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(w.d_y, w.h_buf + 32 * n, 32 * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(w.d_stage_cp + 48 * n, proofs, 48 * n, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    if ((rc = launch_decode(s, w.d_stage_cp, w.d_stage_cp + 48 * n, n)) != KZG_OK) return rc;
+    uint32_t* h_pflag = reinterpret_cast<uint32_t*>(w.h_buf + 64 * n);
+    HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * n, hipMemcpyDeviceToHost, s->s2));
+    HIPCHK(hipStreamSynchronize(s->s2));
+    for (size_t i = 0; i < 2 * n; i++)
+        if (h_pflag[i] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    w.pending_n = n;
+    w.pending_b = 1;
+    // n == 1: r^0 = 1 whatever the transcript hashes to, which is phase 2's n_total == 1 branch (scalars 1, z, -y)
+    if ((rc = phase2_launch_locked(records.data(), n, 0, s)) != KZG_OK) return rc;
+    if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;
+    return finish_wait_locked(ok, s);
+}
