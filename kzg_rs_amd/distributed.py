@@ -116,13 +116,13 @@ def _all_gather_bytes(dist, payload, device):
     return [bytes(o[:l].cpu().numpy().tobytes()) for o, l in zip(outs, lens)]
 
 
-def verify_blob_kzg_proof_batch_sharded(shard, n_local, backend, dist=None, device="cpu"):
+def verify_blob_kzg_proof_batch_sharded(shard, n_local, backend, dist=None, device="cpu", force_collectives=False):
     """Every rank calls this with its own shard (rank order = global blob order).  Returns the batch
     result on every rank.  Raises KzgError on every rank if any shard holds an invalid input
     (first-error identity is not observable in the reference beyond "is Err")."""
     import torch
 
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collectives):
         if n_local == 0:
             return True
         recs = backend.phase1(shard)
@@ -162,13 +162,14 @@ class PipelinedVerifier:
     The order is the same on every rank, so the collectives of different groups never interleave differently
     on different ranks.  With one rank the exchanges and the phase-2 host round trip disappear."""
 
-    def __init__(self, backends, dist=None, device="cpu", depth=(1, 1, 1), equal_shards=False):
+    def __init__(self, backends, dist=None, device="cpu", depth=(1, 1, 1), equal_shards=False, force_collectives=False):
         """equal_shards: every rank holds the same number of blobs of every batch - enables the bulk exchange (records
         go from the library's device buffer straight into the all-gather and come back through one pinned buffer)."""
         self.backends = backends
         self.equal_shards = equal_shards
         self._bufs = {}
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        # force_collectives: run the exchanges even in a world of one (exercises the transport in tests)
+        self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives)) else None
         self.device = device
         self.depth = depth if self.dist else (depth[0], 0, depth[2])
         assert len(backends) >= sum(self.depth) + 1, "need depth+1 handles"

@@ -146,3 +146,53 @@ def test_bench_script_two_ranks_shared_gpu():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 64 and d["value"] > 0 and d["config"]["batch"] == 2048
+
+
+def _nccl_worker(port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import golden_data as G
+    import oracle_lib as O
+    from kzg_rs_amd import api
+    from kzg_rs_amd.distributed import HipBackend, PipelinedVerifier, verify_blob_kzg_proof_batch_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    ost = O.Settings.mainnet()
+    st = api.KzgSettings.load_trusted_setup_file()
+    tuples = G.valid_blob_tuples()
+    blobs, cs, ps = [list(x) for x in zip(*tuples)]
+    keep, shard = _device_shard(torch, blobs, cs, ps)
+    got = [verify_blob_kzg_proof_batch_sharded(shard, len(blobs), HipBackend(st), dist, dev, force_collectives=True)]
+    want = [O.verify_blob_kzg_proof_batch(blobs, cs, ps, ost)]
+    bad = list(ps)
+    bad[2] = O.g1_add(ps[2], G1_GEN)
+    keep2, shard2 = _device_shard(torch, blobs + blobs, cs + cs, ps + bad)  # a group of two batches: valid, corrupted
+    for bulk in (False, True):
+        handles = [st] + [api.KzgSettings.load_trusted_setup_file() for _ in range(3)]
+        pipe = PipelinedVerifier([HipBackend(h) for h in handles], dist, dev, (1, 1, 1), equal_shards=bulk, force_collectives=True)
+        res = pipe.run([((shard2[0], shard2[1], shard2[2], len(blobs)), 2), ((shard[0], shard[1], shard[2], len(blobs)), 1)])
+        got += [x for r in res for x in r]
+        want += [True, False, True]
+    q.put((got, want))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_transport_world_of_one():
+    """The exchanges over RCCL itself (backend "nccl"), forced in a world of one rank: all_reduce of the error flag,
+    all_gather of byte strings and of the bulk record buffer on device tensors, barrier.  What a one-GPU box can check of
+    the 8-GPU transport: the calls, dtypes and buffer handling - not the wire."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    got, want = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert got == want == [True, True, False, True, True, False, True]
