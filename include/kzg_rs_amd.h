@@ -199,6 +199,8 @@ KzgRet kzg_pairing_check(bool *ok, const uint8_t a[48], const uint8_t b[48], con
  * point decode), [2] MSM (split + window + combine), [3] pairing, [4] evaluate kernel, [5] challenge kernel,
  * [6] point decode + subgroup test + MSM multiples (one kernel), [7] the generator's table copy. */
 KzgRet kzg_last_timings(const KzgSettings *s, float out_ms[8]);
+/* The same intervals summed over every launch group finished on this handle since the last reset; *count = groups. */
+KzgRet kzg_timing_totals(const KzgSettings *s, double out_sum_ms[8], uint64_t *count, int reset);
 
 const char *kzg_last_error(void);
 

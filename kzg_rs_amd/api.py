@@ -93,6 +93,7 @@ def lib():
         L.kzg_pairing_check.argtypes = [bp, u8, u8, vp]
         L.kzg_g1_mul_generator.argtypes = [u8, u8, sz, vp]
         L.kzg_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
+        L.kzg_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.kzg_last_error.restype = C.c_char_p
         _lib = L
     return _lib
@@ -196,6 +197,12 @@ class KzgSettings:
         t = (C.c_float * 8)()
         _chk(lib().kzg_last_timings(self._h, t))
         return list(t)
+
+    def timing_totals(self, reset=False):
+        """(sums of the last_timings intervals over the groups finished since the last reset, number of groups)"""
+        t, c = (C.c_double * 8)(), C.c_uint64(0)
+        _chk(lib().kzg_timing_totals(self._h, t, C.byref(c), int(reset)))
+        return list(t), int(c.value)
 
     def close(self):
         if self._h:

@@ -64,3 +64,17 @@ extern "C" KzgRet kzg_last_timings(const KzgSettings* s, float out_ms[8]) {
     memcpy(out_ms, s->timings, sizeof(float) * 8);
     return KZG_OK;
 }
+
+// The same intervals summed over every launch group finished on this handle since the last reset (count = groups):
+// what bench.py averages over its timed region.  reset != 0 clears the sums after reading.
+extern "C" KzgRet kzg_timing_totals(const KzgSettings* s, double out_sum_ms[8], uint64_t* count, int reset) {
+    if (!s || !out_sum_ms || !count) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    memcpy(out_sum_ms, s->tsum, sizeof(double) * 8);
+    *count = s->tcount;
+    if (reset) {
+        memset(s->tsum, 0, sizeof s->tsum);
+        s->tcount = 0;
+    }
+    return KZG_OK;
+}

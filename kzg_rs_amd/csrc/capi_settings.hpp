@@ -57,6 +57,8 @@ struct KzgSettings {
     mutable std::mutex mu;
     mutable Workspace ws;
     mutable float timings[8] = {};
+    mutable double tsum[8] = {};   // the same, summed over every group finished on this handle since the last reset
+    mutable uint64_t tcount = 0;
 };
 
 static KzgRet upload_program(DevProgram& dp, const unsigned char* begin, const unsigned char* end) {

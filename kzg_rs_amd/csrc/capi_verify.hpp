@@ -368,6 +368,8 @@ static KzgRet finish_wait_locked(bool* ok /* B */, const KzgSettings* s) {
     elapsed(&s->timings[2], s->ev[2], s->ev[3]);
     elapsed(&s->timings[3], s->ev[4], s->ev[9]);
     elapsed(&s->timings[0], s->ev[0], s->ev[9]);
+    for (int i = 0; i < 8; i++) s->tsum[i] += s->timings[i];
+    s->tcount++;
     return KZG_OK;
 }
 
