@@ -413,7 +413,8 @@ __global__ __launch_bounds__(64, 3) void k_blob_evaluate(const uint8_t* __restri
     for (int q = 0; q < 32; q++) {
         uint4 a_hi = src[4 * q], a_lo = src[4 * q + 1], b_hi = src[4 * q + 2], b_lo = src[4 * q + 3];
         Fr wa = fr_from_be_words(a_hi, a_lo), wb = fr_from_be_words(b_hi, b_lo);
-        bad |= FrF::geq_mod(wa) | FrF::geq_mod(wb);
+        // canonical check (>= r -> BadArgs): the full 8-limb compare only when some lane's top word reaches r's
+        if (__any((wa.l[7] >= consts::FR_MOD[7]) | (wb.l[7] >= consts::FR_MOD[7]))) bad |= FrF::geq_mod(wa) | FrF::geq_mod(wb);
         const Fr29 pa = fr29_from_words(wa.l), pb = fr29_from_words(wb.l);
         const Fr29 s = fr29_add(pa, pb), u = fr29_sub_biased(pa, pb);
         int k = 32 * lane + q;  // level-1 node index

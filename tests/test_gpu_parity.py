@@ -510,7 +510,7 @@ def test_mutation_fuzz_against_oracle(settings, osettings):
         return bytes(blob), bytes(c), bytes(p)  # kind 8: unchanged
 
     outcomes = {True: 0, False: 0, None: 0}
-    for case in range(120):
+    for case in range(400):
         n = rng.randrange(1, 5)
         batch = [list(rng.choice(tuples)) for _ in range(n)]
         k = rng.randrange(n)
@@ -534,7 +534,7 @@ def test_mutation_fuzz_against_oracle(settings, osettings):
             except O.OracleError:
                 continue
             assert _result(lambda: KzgProof.verify_kzg_proof(Bytes48(cs[0]), Bytes32(z), Bytes32(y), Bytes48(ps[0]), settings)) == want2
-    assert min(outcomes.values()) >= 5, outcomes  # the fuzz reaches all three outcomes
+    assert min(outcomes.values()) >= 20, outcomes  # the fuzz reaches all three outcomes
 
 
 def test_concurrent_host_threads(settings, osettings):
