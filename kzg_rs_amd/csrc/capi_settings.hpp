@@ -8,6 +8,7 @@ struct DevProgram {
 };
 
 constexpr size_t MAX_WORLD = 64;
+constexpr size_t MAX_BATCHES_PER_LAUNCH = 16384;
 constexpr unsigned MSM_MAX_SLICES = 32;
 constexpr size_t LATENCY_MAX_BLOBS = 4096;  // launches up to this size: CU-split stream pair + the latency MSM layout
 struct Workspace {

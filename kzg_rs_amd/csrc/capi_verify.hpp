@@ -202,6 +202,7 @@ static void select_streams(const KzgSettings* s, size_t T) {
 // Phase 1 (no communication): point decode + multiples || (challenge -> evaluate) for all T = B n blobs.
 static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n, size_t B,
                                    const KzgSettings* s) {
+    if (B > MAX_BATCHES_PER_LAUNCH) return fail(KZG_BADARGS, "more than 16384 batches in one launch group");  // gridDim.z = 2 B
     Workspace& w = s->ws;
     const size_t T = n * B;
     KzgRet rc;

@@ -479,6 +479,26 @@ def test_synthetic_batch_vs_oracle():
     assert KzgProof.verify_blob_kzg_proof_batch([], [], [], st) is True
 
 
+def test_many_small_batches_in_one_launch():
+    """The batch dimension at its other extreme: 300 batches of 2 blobs in one launch group (merged-chunk MSM blocks
+    with 2 to 5 terms, 300 pairing instances); batches 7 and 250 carry a wrong proof."""
+    import torch
+    from kzg_rs_amd import synth
+    n, B = 2, 300
+    blobs, cs, ps, st = synth.make_valid_batch(n * B, seed=31)
+    ps = list(ps)
+    for b in (7, 250):
+        ps[b * n + 1] = O.g1_add(ps[b * n + 1], G1_GEN)
+    d_blobs = torch.from_numpy(blobs).cuda()
+    d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).cuda()
+    d_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    got = api.verify_blob_kzg_proof_batches_device(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, B, st)
+    assert got == [b not in (7, 250) for b in range(B)]
+    with pytest.raises(KzgError):
+        api.verify_blob_kzg_proof_batches_device(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 1, 20000, st)
+
+
 def test_mutation_fuzz_against_oracle(settings, osettings):
     """Seeded differential fuzz of the three entry points: valid mainnet tuples with one random mutation each (bit
     flips in the commitment / proof / blob, field elements at and around r, the identity encoding, wrong flag bits,
