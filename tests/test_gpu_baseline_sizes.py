@@ -135,3 +135,26 @@ def test_config5_shard_size_single_batch():
     torch.cuda.synchronize()
     with pytest.raises(KzgError):
         run(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
+
+
+@pytest.mark.parametrize("n,B", [(1024, 8), (512, 40), (3000, 3)])
+def test_mid_size_launch_groups(n, B):
+    """Launch groups between the single-batch latency path and the bench's large groups: the producer/consumer challenge
+    kernel beyond one batch, the default MSM layout with separate (B < 16), paired (B < 32) and merged chunk blocks, term
+    slicing at n = 3000.  One batch of each group carries a wrong proof."""
+    import torch
+    from kzg_rs_amd import synth
+    blobs, cs, ps, st = synth.make_valid_batch(n, seed=77 + n)
+    perm = lambda b: torch.roll(torch.arange(n), b * 17)
+    idx = torch.cat([perm(b) for b in range(B)])
+    d_blobs = torch.from_numpy(blobs).cuda()[idx.cuda()].contiguous()
+    c_all = [cs[i] for i in idx.tolist()]
+    p_all = [ps[i] for i in idx.tolist()]
+    wrong = B // 2
+    p_all[wrong * n + n - 1] = O.g1_add(p_all[wrong * n + n - 1], bytes.fromhex(
+        "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"))
+    d_c = torch.frombuffer(bytearray(b"".join(c_all)), dtype=torch.uint8).cuda()
+    d_p = torch.frombuffer(bytearray(b"".join(p_all)), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    got = api.verify_blob_kzg_proof_batches_device(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, B, st)
+    assert got == [b != wrong for b in range(B)]
