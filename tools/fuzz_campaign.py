@@ -1,0 +1,96 @@
+"""Open-ended differential fuzz of the entry points against the CPU oracle (a longer-running sibling of
+tests/test_gpu_parity.py::test_mutation_fuzz_against_oracle).   python tools/fuzz_campaign.py [seconds] [seed]"""
+import os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_data as G
+import oracle_lib as O
+from kzg_rs_amd.api import Blob, Bytes32, Bytes48, KzgError, KzgProof, KzgSettings
+
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+G1_INF = bytes([0xC0]) + bytes(47)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+rng = random.Random(seed)
+st, ost = KzgSettings.load_trusted_setup_file(), O.Settings.mainnet()
+tuples = G.valid_blob_tuples()
+edge_fr = [R, R - 1, R + 1, (1 << 256) - 1, 0, 1, 2 * R]
+edge_fp = [P, P - 1, P + 1, 0, 1]
+
+
+def rand_point():
+    k = rng.randrange(6)
+    if k == 0:
+        return G1_INF
+    if k == 1:  # x with random flags
+        return bytes([rng.randrange(256)]) + rng.randbytes(47)
+    if k == 2:  # edge x values with the compression flag set
+        v = rng.choice(edge_fp) % (1 << 381)
+        b = bytearray(v.to_bytes(48, "big")); b[0] |= 0x80 | (0x20 if rng.randrange(2) else 0)
+        return bytes(b)
+    if k == 3:  # a valid subgroup point: a multiple of a vector's commitment
+        return O.g1_mul(rng.choice(tuples)[1], rng.randrange(1, R).to_bytes(32, "big"))
+    if k == 4:  # on the curve, probably outside the subgroup: a random x that decodes unchecked
+        while True:
+            b = bytearray(rng.randrange(P).to_bytes(48, "big")); b[0] |= 0x80
+            try:
+                O.g1_decompress(bytes(b)); return bytes(b)   # oracle decode checks the subgroup: accept either way
+            except O.OracleError:
+                return bytes(b)
+    t = rng.choice(tuples); return t[rng.randrange(1, 3)]
+
+
+def mutate(blob, c, p):
+    kind = rng.randrange(12)
+    blob, c, p = bytearray(blob), bytearray(c), bytearray(p)
+    if kind == 0: c[rng.randrange(48)] ^= 1 << rng.randrange(8)
+    elif kind == 1: p[rng.randrange(48)] ^= 1 << rng.randrange(8)
+    elif kind == 2:
+        i = rng.randrange(4096); blob[32 * i: 32 * i + 32] = (rng.choice(edge_fr) % (1 << 256)).to_bytes(32, "big")
+    elif kind == 3: blob[rng.randrange(131072)] ^= 1 << rng.randrange(8)
+    elif kind == 4: c[:] = rand_point()
+    elif kind == 5: p[:] = rand_point()
+    elif kind == 6: c, p = p, c
+    elif kind == 7: blob[:] = bytes(131072)
+    elif kind == 8:
+        for _ in range(rng.randrange(1, 40)):
+            i = rng.randrange(4096); blob[32 * i: 32 * i + 32] = rng.randrange(R).to_bytes(32, "big")
+    return bytes(blob), bytes(c), bytes(p)
+
+
+def res(fn):
+    try:
+        return fn()
+    except (KzgError, O.OracleError):
+        return None
+
+
+t_end, cases, counts = time.time() + budget, 0, {True: 0, False: 0, None: 0}
+while time.time() < t_end:
+    n = rng.choice([1, 1, 2, 3, 4, 7, 12])
+    batch = [list(rng.choice(tuples)) for _ in range(n)]
+    for _ in range(rng.randrange(0, 3)):
+        k = rng.randrange(n); batch[k] = list(mutate(*batch[k]))
+    blobs, cs, ps = [list(x) for x in zip(*batch)]
+    want = res(lambda: O.verify_blob_kzg_proof_batch(blobs, cs, ps, ost))
+    got = res(lambda: KzgProof.verify_blob_kzg_proof_batch([Blob(b) for b in blobs], [Bytes48(c) for c in cs], [Bytes48(p) for p in ps], st))
+    if got != want:
+        print("MISMATCH batch seed=%d case=%d n=%d got=%r want=%r" % (seed, cases, n, got, want)); sys.exit(1)
+    counts[got] += 1
+    # proof-tuple entry points on (C, z, y, pi) with random / edge scalars
+    m = rng.choice([1, 2, 5])
+    tc = [rand_point() if rng.randrange(4) == 0 else rng.choice(tuples)[1] for _ in range(m)]
+    tp = [rand_point() if rng.randrange(4) == 0 else rng.choice(tuples)[2] for _ in range(m)]
+    tz = [(rng.choice(edge_fr) % (1 << 256) if rng.randrange(5) == 0 else rng.randrange(R)).to_bytes(32, "big") for _ in range(m)]
+    ty = [(rng.choice(edge_fr) % (1 << 256) if rng.randrange(5) == 0 else rng.randrange(R)).to_bytes(32, "big") for _ in range(m)]
+    want = res(lambda: O.verify_kzg_proof_batch(tc, tz, ty, tp, ost))
+    got = res(lambda: KzgProof.verify_kzg_proof_batch([Bytes48(x) for x in tc], [Bytes32(x) for x in tz], [Bytes32(x) for x in ty], [Bytes48(x) for x in tp], st))
+    if got != want:
+        print("MISMATCH proof batch seed=%d case=%d got=%r want=%r" % (seed, cases, got, want)); sys.exit(1)
+    want = res(lambda: O.verify_kzg_proof(tc[0], tz[0], ty[0], tp[0], ost))
+    got = res(lambda: KzgProof.verify_kzg_proof(Bytes48(tc[0]), Bytes32(tz[0]), Bytes32(ty[0]), Bytes48(tp[0]), st))
+    if got != want:
+        print("MISMATCH single proof seed=%d case=%d got=%r want=%r" % (seed, cases, got, want)); sys.exit(1)
+    cases += 1
+print("fuzz campaign seed=%d: %d cases x 3 entry points, no mismatch; blob-batch outcomes %s" % (seed, cases, counts))
