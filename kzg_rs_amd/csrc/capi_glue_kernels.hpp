@@ -137,8 +137,9 @@ __global__ void k_pack_records(const uint32_t* __restrict__ c, const uint32_t* _
 }
 
 // the generator and its precomputed multiples (gen_mult[4], made once per settings) as point `idx` of a workspace
-__global__ void k_set_generator_multiples(G1Aff* __restrict__ points, uint32_t* __restrict__ pflag, G1Jac* __restrict__ mult,
-                                          const G1Jac* __restrict__ gen_mult, int idx, int stride, int chunks) {
+template <class Mem>
+__global__ void k_set_generator_multiples(G1Aff* __restrict__ points, uint32_t* __restrict__ pflag, Mem* __restrict__ mult,
+                                          const Mem* __restrict__ gen_mult, int idx, int stride, int chunks) {
     if (threadIdx.x || blockIdx.x) return;
     G1Aff g;
     g.x = fp_const(consts::G1_GEN_X_MONT);

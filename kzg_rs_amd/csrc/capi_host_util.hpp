@@ -137,3 +137,14 @@ static void be_sub_r(uint8_t v[32]) {
 static void reverse32(uint8_t* dst, const uint8_t* src) {
     for (int i = 0; i < 32; i++) dst[i] = src[31 - i];
 }
+
+// Point arithmetic of the decode and MSM kernels: the radix-2^29 field (fp29.hpp) unless KZG_FP29=0 selects the 12x32
+// field (A/B measurement, cross-check).  Decides the table format (G1Jac29Mem / G1Jac) for the whole process.
+static bool fp29_enabled() {
+    static const bool v = [] {
+        const char* e = getenv("KZG_FP29");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+constexpr size_t MULT_ENTRY_BYTES = sizeof(G1Jac29Mem) > sizeof(G1Jac) ? sizeof(G1Jac29Mem) : sizeof(G1Jac);

@@ -130,7 +130,15 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
         for (size_t i = 0; i < n; i++)
             if (st[i] == G1_INVALID) return fail(KZG_BADARGS, "invalid G1 point");
     }
-    if (n) hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_points, w.d_pflag, w.d_mult, (int)n, mt, MSM_CHUNKS);
+    // the tables are made in the 12x32 form (the points are already decoded), then converted to the window kernel's format
+    G1Jac* d_std = nullptr;
+    if (n) {
+        if (fp29_enabled()) HIPCHK(hipMalloc(&d_std, sizeof(G1Jac) * MSM_CHUNKS * (size_t)mt));
+        G1Jac* tab = fp29_enabled() ? d_std : (G1Jac*)w.d_mult;
+        hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_points, w.d_pflag, tab, (int)n, mt, MSM_CHUNKS);
+        if (fp29_enabled())
+            hipLaunchKernelGGL(k_jac_to_jac29, dim3((unsigned)((MSM_CHUNKS * (size_t)mt + 255) / 256)), dim3(256), 0, s->s1, d_std, (G1Jac29Mem*)w.d_mult, (int)(MSM_CHUNKS * mt));
+    }
     MsmDesc d{};
     d.mult = w.d_mult;
     d.pflag = w.d_pflag;
@@ -150,7 +158,8 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     d.chunks = MSM_CHUNKS;
     d.chunks_per_block = 1;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
-    hipLaunchKernelGGL(k_msm_window, dim3(8, MSM_CHUNKS, S), dim3(256), 0, s->s1, d);
+    if (fp29_enabled()) hipLaunchKernelGGL(k_msm_window<Curve29>, dim3(8, MSM_CHUNKS, S), dim3(256), 0, s->s1, d);
+    else hipLaunchKernelGGL(k_msm_window<Curve32>, dim3(8, MSM_CHUNKS, S), dim3(256), 0, s->s1, d);
     if (S > 1) hipLaunchKernelGGL(k_msm_fold_slices, dim3(MSM_CHUNKS * 8), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, 8);
     hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, w.d_window, w.d_ab, MSM_CHUNKS, 8);
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
@@ -158,6 +167,7 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, w.d_bytes, 48, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
+    if (d_std) (void)hipFree(d_std);
     elapsed(&s->timings[2], s->ev[2], s->ev[3]);
     return KZG_OK;
 }

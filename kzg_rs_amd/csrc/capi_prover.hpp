@@ -61,7 +61,8 @@ static KzgRet setup_msm(const KzgSettings* s, ProverBufs& b, size_t m) {
     d.chunks = MSM_CHUNKS;
     d.chunks_per_block = m >= 16 ? 4 : 1;
     const unsigned slots = MSM_CHUNKS / d.chunks_per_block;
-    hipLaunchKernelGGL(k_msm_window, dim3(8, slots, (unsigned)m), dim3(256), 0, s->s1, d);
+    if (fp29_enabled()) hipLaunchKernelGGL(k_msm_window<Curve29>, dim3(8, slots, (unsigned)m), dim3(256), 0, s->s1, d);
+    else hipLaunchKernelGGL(k_msm_window<Curve32>, dim3(8, slots, (unsigned)m), dim3(256), 0, s->s1, d);
     hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)m), dim3(64), 0, s->s1, b.d_win, b.d_res, (int)slots, 8);
     hipLaunchKernelGGL(k_jac_compress_n, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s->s1, b.d_res, b.d_out, (int)m);
     HIPCHK(hipGetLastError());

@@ -21,7 +21,8 @@ struct Workspace {
     Fr *d_z = nullptr, *d_y = nullptr, *d_scalars = nullptr, *d_partial = nullptr, *d_r = nullptr;
     uint32_t *d_status = nullptr, *d_pflag = nullptr, *d_term_point = nullptr, *d_term_scalar = nullptr, *d_sorted = nullptr;
     G1Aff* d_points = nullptr;
-    G1Jac *d_window = nullptr, *d_window_sl = nullptr, *d_ab = nullptr, *d_mult = nullptr, *d_parts = nullptr;
+    G1Jac *d_window = nullptr, *d_window_sl = nullptr, *d_ab = nullptr, *d_parts = nullptr;
+    void* d_mult = nullptr;  // MSM tables: G1Jac29Mem or G1Jac entries (fp29_enabled())
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
     uint8_t *d_stage_blobs = nullptr, *d_stage_cp = nullptr, *d_bytes = nullptr, *d_records = nullptr;
     // pinned host mirrors
@@ -35,11 +36,11 @@ struct KzgSettings {
     Fr29Mem *d_M29 = nullptr, *d_DM29 = nullptr;   // the same in radix 2^29 (fr29.hpp), what k_blob_evaluate reads
     Fp* d_tau4 = nullptr;   // [tau]G2 affine (x.c0 x.c1 y.c0 y.c1), Montgomery
     Fp* d_prep = nullptr;   // prepared lines: [tau]G2 then generator (2 * 408 Fp)
-    G1Jac* d_gen_mult = nullptr;  // the generator's MSM tables: [0, 4) the default layout, [4, 20) the latency layout (msm.hpp)
+    void* d_gen_mult = nullptr;   // the generator's MSM tables: [0, 4) the default layout, [4, 20) the latency layout (msm.hpp)
     // full trusted setup (kzg_settings_load_trusted_setup only; not needed by verification):
     G1Aff* d_g1 = nullptr;            // g1_points, bit-reversal permuted (build.rs:79,89-105), 4096 entries
     uint32_t* d_g1_flag = nullptr;    // 0 finite / 1 identity (unchecked decode, build.rs:68)
-    G1Jac* d_g1_mult = nullptr;       // their MSM multiples (msm.hpp), valid iff g1_in_subgroup
+    void* d_g1_mult = nullptr;        // their MSM multiples (msm.hpp), valid iff g1_in_subgroup
     bool g1_in_subgroup = false;      // every G1 point lies in the r-torsion (what the GLV multiples need)
     Fp* d_g2 = nullptr;               // g2_points (monomial), n_g2 x 4 Fp
     size_t n_g2 = 0;
@@ -159,10 +160,20 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
         uint32_t* d_gf;
         HIPCHK(hipMalloc(&d_g, sizeof(G1Aff)));
         HIPCHK(hipMalloc(&d_gf, 4));
-        HIPCHK(hipMalloc(&s->d_gen_mult, sizeof(G1Jac) * (MSM_CHUNKS + MSM_CHUNKS_LATENCY)));
+        constexpr int NG = MSM_CHUNKS + MSM_CHUNKS_LATENCY;
+        G1Jac* d_gm;
+        HIPCHK(hipMalloc(&d_gm, sizeof(G1Jac) * NG));
         hipLaunchKernelGGL(k_set_generator, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, 0);
-        hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, s->d_gen_mult, 1, 1, MSM_CHUNKS);
-        hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, s->d_gen_mult + MSM_CHUNKS, 1, 1, MSM_CHUNKS_LATENCY);
+        hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, d_gm, 1, 1, MSM_CHUNKS);
+        hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, d_gm + MSM_CHUNKS, 1, 1, MSM_CHUNKS_LATENCY);
+        if (fp29_enabled()) {
+            HIPCHK(hipMalloc(&s->d_gen_mult, sizeof(G1Jac29Mem) * NG));
+            hipLaunchKernelGGL(k_jac_to_jac29, dim3(1), dim3(64), 0, s->s1, d_gm, (G1Jac29Mem*)s->d_gen_mult, NG);
+            HIPCHK(hipStreamSynchronize(s->s1));
+            HIPCHK(hipFree(d_gm));
+        } else {
+            s->d_gen_mult = d_gm;
+        }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s->s1));
         HIPCHK(hipFree(d_g));
@@ -246,11 +257,15 @@ extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char*
     HIPCHK(hipMalloc(&d_tmp, sizeof(G1Aff) * (size_t)N));
     HIPCHK(hipMalloc(&s->d_g1, sizeof(G1Aff) * (size_t)N));
     HIPCHK(hipMalloc(&s->d_g1_flag, 4 * (size_t)N));
-    HIPCHK(hipMalloc(&s->d_g1_mult, sizeof(G1Jac) * MSM_CHUNKS * (size_t)N));
+    HIPCHK(hipMalloc(&s->d_g1_mult, MULT_ENTRY_BYTES * MSM_CHUNKS * (size_t)N));
     HIPCHK(hipMemcpyAsync(d_bytes, g1b.data(), g1b.size(), hipMemcpyHostToDevice, s->s1));
     hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, s->d_g1, s->d_g1_flag, N, 0);
-    hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
-                       d_flag2, s->d_g1_mult, N, N);
+    if (fp29_enabled())
+        hipLaunchKernelGGL(k_g1_decode_multiples29<MSM_CHUNKS>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
+                           d_flag2, (G1Jac29Mem*)s->d_g1_mult, N, N);
+    else
+        hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
+                           d_flag2, (G1Jac*)s->d_g1_mult, N, N);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> f1((size_t)N), f2((size_t)N);
     HIPCHK(hipMemcpyAsync(f1.data(), s->d_g1_flag, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));

@@ -62,7 +62,7 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
         HIPCHK(hipMalloc(&w.d_points, sizeof(G1Aff) * np));
         HIPCHK(hipMalloc(&w.d_window, sizeof(G1Jac) * 2 * MSM_WINDOWS * capB));
         HIPCHK(hipMalloc(&w.d_window_sl, sizeof(G1Jac) * 2 * MSM_WINDOWS * MSM_MAX_SLICES * 4));  // sliced launches have <= 4 batches
-        HIPCHK(hipMalloc(&w.d_mult, sizeof(G1Jac) * std::max((size_t)MSM_CHUNKS * np, (size_t)MSM_CHUNKS_LATENCY * std::min(np, (size_t)(2 * LATENCY_MAX_BLOBS + 1)))));
+        HIPCHK(hipMalloc(&w.d_mult, MULT_ENTRY_BYTES * std::max((size_t)MSM_CHUNKS * np, (size_t)MSM_CHUNKS_LATENCY * std::min(np, (size_t)(2 * LATENCY_MAX_BLOBS + 1)))));
         HIPCHK(hipMalloc(&w.d_ab, sizeof(G1Jac) * 2 * capB));
         HIPCHK(hipMalloc(&w.d_parts, sizeof(G1Jac) * 2 * capB * MAX_WORLD));
         HIPCHK(hipMalloc(&w.d_slp_in, sizeof(Fp) * 6 * capB));
@@ -134,7 +134,8 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     const int nsc = (int)(B * (2 * n + 1));
     hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc);
-    hipLaunchKernelGGL(k_msm_window, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
+    if (fp29_enabled()) hipLaunchKernelGGL(k_msm_window<Curve29>, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
+    else hipLaunchKernelGGL(k_msm_window<Curve32>, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
     if (S > 1)
         hipLaunchKernelGGL(k_msm_fold_slices, dim3((unsigned)(2 * B * slots * W)), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, (int)W);
     hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(2 * B)), dim3(64), 0, s->s1, w.d_window, w.d_ab, (int)slots, (int)W);
@@ -152,15 +153,27 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
     static const bool no_latency_layout = getenv("KZG_MSM_LATENCY_LAYOUT") && getenv("KZG_MSM_LATENCY_LAYOUT")[0] == '0';
     w.chunks = (T <= LATENCY_MAX_BLOBS && !no_latency_layout) ? MSM_CHUNKS_LATENCY : MSM_CHUNKS;
     const uint8_t *c = (const uint8_t*)d_commitments, *p = (const uint8_t*)d_proofs;
-    if (w.chunks == MSM_CHUNKS_LATENCY)
-        hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag,
-                           w.d_mult, (int)(2 * T), np);
-    else
-        hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult,
-                           (int)(2 * T), np);
-    HIPCHK(hipEventRecord(s->ev[10], s->s2));
-    hipLaunchKernelGGL(k_set_generator_multiples, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, w.d_mult,
-                       s->d_gen_mult + (w.chunks == MSM_CHUNKS ? 0 : MSM_CHUNKS), (int)(2 * T), np, w.chunks);
+    const int n2 = (int)(2 * T);
+    const size_t gen_off = w.chunks == MSM_CHUNKS ? 0 : MSM_CHUNKS;
+    if (fp29_enabled()) {
+        G1Jac29Mem* mult = (G1Jac29Mem*)w.d_mult;
+        if (w.chunks == MSM_CHUNKS_LATENCY)
+            hipLaunchKernelGGL(k_g1_decode_multiples29<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
+        else
+            hipLaunchKernelGGL(k_g1_decode_multiples29<MSM_CHUNKS>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
+        HIPCHK(hipEventRecord(s->ev[10], s->s2));
+        hipLaunchKernelGGL(k_set_generator_multiples<G1Jac29Mem>, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, mult,
+                           (const G1Jac29Mem*)s->d_gen_mult + gen_off, n2, np, w.chunks);
+    } else {
+        G1Jac* mult = (G1Jac*)w.d_mult;
+        if (w.chunks == MSM_CHUNKS_LATENCY)
+            hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
+        else
+            hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
+        HIPCHK(hipEventRecord(s->ev[10], s->s2));
+        hipLaunchKernelGGL(k_set_generator_multiples<G1Jac>, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, mult,
+                           (const G1Jac*)s->d_gen_mult + gen_off, n2, np, w.chunks);
+    }
     HIPCHK(hipGetLastError());
     return KZG_OK;
 }

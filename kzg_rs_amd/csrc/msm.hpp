@@ -20,6 +20,7 @@
 // then k_msm_combine folds the chunk sums and the 8 windows (Horner, 8 doublings per window).
 #pragma once
 #include "g1.hpp"
+#include "g1_29.hpp"
 
 namespace kzg {
 
@@ -152,6 +153,54 @@ __global__ __launch_bounds__(64, 2) void k_g1_decode_multiples(const uint8_t* __
     pflag[i] = st;
 }
 
+// The same pass in the radix-2^29 field (fp29.hpp, g1_29.hpp): tables written as G1Jac29Mem (lazy values), the affine
+// point as a canonical 12x32 element like the kernel above.
+template <int CHUNKS>
+__global__ __launch_bounds__(64, 2) void k_g1_decode_multiples29(const uint8_t* __restrict__ bytes0, const uint8_t* __restrict__ bytes1,
+                                                                 int n0, G1Aff* __restrict__ points, uint32_t* __restrict__ pflag,
+                                                                 G1Jac29Mem* __restrict__ mult, int n, int stride) {
+    constexpr int HALF = CHUNKS / 2, STEP = 256 / CHUNKS;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t* src = i < n0 ? bytes0 + (size_t)i * 48 : bytes1 + (size_t)(i - n0) * 48;
+    Fp29 x, y;
+    uint32_t st = g1_decompress29(x, y, src);
+    G1Aff a;
+    a.x = FpF::zero();
+    a.y = FpF::zero();
+    if (st == G1_OK) {
+        G1Jac29 p;
+        p.x = x;
+        p.y = y;
+        p.z = fp29_const(cp29::FP29_ONE);
+        g1j29_store(mult[i], p);
+        g1j29_store(mult[(size_t)HALF * stride + i], g1j29_neg_phi(p));
+        const bool in = g1j29_in_subgroup_with_multiples<STEP>(x, y, [&](int k, const G1Jac29& m) {
+            g1j29_store(mult[(size_t)k * stride + i], m);
+            g1j29_store(mult[(size_t)(HALF + k) * stride + i], g1j29_neg_phi(m));
+        });
+        if (in) {
+            a.x = fp29_to_std(x);
+            a.y = fp29_to_std(y);
+        } else {
+            st = G1_INVALID;
+        }
+    }
+    if (st != G1_OK) {
+        const G1Jac29 id = g1j29_identity();
+        for (int k = 0; k < CHUNKS; k++) g1j29_store(mult[(size_t)k * stride + i], id);
+    }
+    points[i] = a;
+    pflag[i] = st;
+}
+
+// tables made in the 12x32 form (k_g1_multiples: the generator, kzg_g1_msm) -> the radix-2^29 table format
+__global__ void k_jac_to_jac29(const G1Jac* __restrict__ in, G1Jac29Mem* __restrict__ out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    g1j29_store(out[i], g1j29_from_std(in[i]));
+}
+
 // in place: canonical k (< r) -> k1 (limbs 0..3) | k2 (limbs 4..7) with k = k1 + k2 * x^2.
 // Barrett with M = floor(2^383 / x^2): the quotient estimate is low by at most 1 for k < 2^255.
 __global__ __launch_bounds__(256) void k_glv_split(Fr* __restrict__ scalars, int count) {
@@ -213,7 +262,7 @@ __global__ __launch_bounds__(256) void k_glv_split(Fr* __restrict__ scalars, int
 //   term_point[o][t], term_scalar[o][t]  (indices into points[] / scalars[]); nterms[o].
 // pflag[p] != 0 marks the identity / an invalid point (skipped).
 struct MsmDesc {
-    const G1Jac* mult;            // [4][stride] precomputed multiples
+    const void* mult;             // [chunks][stride] precomputed multiples: G1Jac (Curve32) or G1Jac29Mem (Curve29)
     const uint32_t* pflag;
     const Fr* scalars;            // plain little-endian limbs
     const uint32_t* term_point;   // [2][max_terms]
@@ -256,10 +305,60 @@ __device__ __forceinline__ G1Jac lds_load_jac(const uint32_t* base, int slot) {
 
 // grid (W windows per chunk, chunks / chunks_per_block, 2 outputs x batches), 256 threads: block (w, g, o) handles digit
 // byte W j + w of every scalar of output o for its chunks j, against the table of chunk j (W = 32 / chunks).
+__device__ __forceinline__ void lds_store_jac29(uint32_t* base, int slot, const G1Jac29& p) {
+    uint32_t* d = base + slot * 42;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        d[i] = p.x.l[i];
+        d[14 + i] = p.y.l[i];
+        d[28 + i] = p.z.l[i];
+    }
+}
+__device__ __forceinline__ G1Jac29 lds_load_jac29(const uint32_t* base, int slot) {
+    const uint32_t* d = base + slot * 42;
+    G1Jac29 p;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        p.x.l[i] = d[i];
+        p.y.l[i] = d[14 + i];
+        p.z.l[i] = d[28 + i];
+    }
+    return p;
+}
+
+// The window kernel is written once over a curve policy: Curve29 (radix-2^29 field, lazy reduction: the default) or
+// Curve32 (the 12x32 field of field.hpp; KZG_FP29=0, kept for A/B measurement and as a cross-check).
+struct Curve32 {
+    using Pt = G1Jac;
+    using Mem = G1Jac;
+    static constexpr int WORDS = 36;
+    __device__ static __forceinline__ Pt identity() { return g1_identity(); }
+    __device__ static __forceinline__ Pt add(const Pt& a, const Pt& b) { return g1_add(a, b); }
+    __device__ static __forceinline__ Pt dbl(const Pt& a) { return g1_dbl(a); }
+    __device__ static __forceinline__ Pt load(const Mem& m) { return m; }
+    __device__ static __forceinline__ void lds_store(uint32_t* b, int s, const Pt& p) { lds_store_jac(b, s, p); }
+    __device__ static __forceinline__ Pt lds_load(const uint32_t* b, int s) { return lds_load_jac(b, s); }
+    __device__ static __forceinline__ G1Jac to_std(const Pt& p) { return p; }
+};
+struct Curve29 {
+    using Pt = G1Jac29;
+    using Mem = G1Jac29Mem;
+    static constexpr int WORDS = 42;
+    __device__ static __forceinline__ Pt identity() { return g1j29_identity(); }
+    __device__ static __forceinline__ Pt add(const Pt& a, const Pt& b) { return g1j29_add(a, b); }
+    __device__ static __forceinline__ Pt dbl(const Pt& a) { return g1j29_dbl(a); }
+    __device__ static __forceinline__ Pt load(const Mem& m) { return g1j29_load(m); }
+    __device__ static __forceinline__ void lds_store(uint32_t* b, int s, const Pt& p) { lds_store_jac29(b, s, p); }
+    __device__ static __forceinline__ Pt lds_load(const uint32_t* b, int s) { return lds_load_jac29(b, s); }
+    __device__ static __forceinline__ G1Jac to_std(const Pt& p) { return g1j29_to_std(p); }
+};
+
 #ifndef KZG_MSM_OCC
 #define KZG_MSM_OCC 3
 #endif
+template <class CV>
 __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
+    using Pt = typename CV::Pt;
     // blockIdx.z = (2*batch + output) * slices + slice
     const int S = d.slices, bo = blockIdx.z / S, slice = blockIdx.z % S;
     const int w = blockIdx.x, o = bo & 1, tid = threadIdx.x;
@@ -272,7 +371,7 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     // scratch of this block: the (window, chunk group) region of its output, then the slice's share of it
     uint32_t* sorted = d.sorted + ((size_t)(bo * gridDim.y + blockIdx.y) * W + w) * cpb * d.max_terms + (size_t)cpb * t0;
     __shared__ uint32_t cnt[MSM_BUCKETS], off[MSM_BUCKETS + 1], cur[MSM_BUCKETS];
-    __shared__ uint32_t pts[MSM_BUCKETS * 36];  // 36 KiB: one Jacobian point per thread
+    __shared__ uint32_t pts[MSM_BUCKETS * CV::WORDS];  // 36 / 42 KiB: one Jacobian point per thread
     cnt[tid] = 0;
     cur[tid] = 0;
     __syncthreads();
@@ -319,11 +418,12 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     }
     __syncthreads();
     const int bucket = cur[tid];
-    G1Jac acc = g1_identity();
+    const typename CV::Mem* mult = static_cast<const typename CV::Mem*>(d.mult);
+    Pt acc = CV::identity();
     if (bucket > 0) {
         for (uint32_t k = off[bucket]; k < off[bucket + 1]; k++) {
             const uint32_t e = sorted[k];
-            acc = g1_add(acc, d.mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]);
+            acc = CV::add(acc, CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
         }
     }
     // 3. sum_b b*B_b with b = 16 hi + lo:   16 * sum_hi hi*R_hi + sum_lo lo*C_lo,
@@ -336,25 +436,25 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     //      kind 1 cols  : dst = 16 (2 s k) + lo, src = dst + 16 s     (ops = 128 / s)   on a fresh copy of the buckets
     //      kind 2 scan  : suffix scan over the two 16-element vectors R (slots 0..15) and C (slots 16..31)
     //      kind 3 tree  : tree sum of the two scanned vectors (slot 0 / 16 of each zeroed first)
-    lds_store_jac(pts, bucket, acc);
+    CV::lds_store(pts, bucket, acc);
     __syncthreads();
-    acc = lds_load_jac(pts, tid);  // from here on thread tid holds bucket tid again
-    G1Jac keep = g1_identity();  // threads 0..15: R_tid, threads 16..31: C_(tid-16)
+    acc = CV::lds_load(pts, tid);  // from here on thread tid holds bucket tid again
+    Pt keep = CV::identity();  // threads 0..15: R_tid, threads 16..31: C_(tid-16)
 #pragma unroll 1
     for (int lvl = 0; lvl < 16; lvl++) {
         const int kind = lvl >> 2, s = kind == 3 ? (8 >> (lvl & 3)) : (1 << (lvl & 3));
         if (lvl == 4) {  // rows done: save R, restore the buckets for the column trees
-            if (tid < 16) keep = lds_load_jac(pts, 16 * tid);
+            if (tid < 16) keep = CV::lds_load(pts, 16 * tid);
             __syncthreads();
-            lds_store_jac(pts, tid, acc);
+            CV::lds_store(pts, tid, acc);
             __syncthreads();
         } else if (lvl == 8) {  // columns done: lay out R | C for the scans
-            if (tid >= 16 && tid < 32) keep = lds_load_jac(pts, tid - 16);
+            if (tid >= 16 && tid < 32) keep = CV::lds_load(pts, tid - 16);
             __syncthreads();
-            if (tid < 32) lds_store_jac(pts, tid, keep);
+            if (tid < 32) CV::lds_store(pts, tid, keep);
             __syncthreads();
         } else if (lvl == 12) {  // scans done: S_0 is not part of sum_{k>=1} S_k
-            if (tid < 32 && (tid & 15) == 0) lds_store_jac(pts, tid, g1_identity());
+            if (tid < 32 && (tid & 15) == 0) CV::lds_store(pts, tid, CV::identity());
             __syncthreads();
         }
         bool active;
@@ -377,20 +477,20 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
             dst = tid;
             src = tid + s;
         }
-        G1Jac x = g1_identity(), y = g1_identity();
+        Pt x = CV::identity(), y = CV::identity();
         if (active) {
-            x = lds_load_jac(pts, dst);
-            y = lds_load_jac(pts, src);
+            x = CV::lds_load(pts, dst);
+            y = CV::lds_load(pts, src);
         }
         __syncthreads();  // scan levels read a slot that its owner rewrites in the same level
-        if (active) lds_store_jac(pts, dst, g1_add(x, y));
+        if (active) CV::lds_store(pts, dst, CV::add(x, y));
         __syncthreads();
     }
     if (tid == 0) {
-        G1Jac r = lds_load_jac(pts, 0);  // sum hi * R_hi
+        Pt r = CV::lds_load(pts, 0);  // sum hi * R_hi
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) r = g1_dbl(r);
-        d.window_sums[wi] = g1_add(r, lds_load_jac(pts, 16));
+        for (int k = 0; k < 4; k++) r = CV::dbl(r);
+        d.window_sums[wi] = CV::to_std(CV::add(r, CV::lds_load(pts, 16)));
     }
 }
 
