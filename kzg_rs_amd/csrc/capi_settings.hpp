@@ -33,7 +33,9 @@ struct Workspace {
 struct KzgSettings {
     int device = 0;
     Fr *d_M = nullptr, *d_DM = nullptr;            // roots of unity, 8x32 Montgomery (R, R^2 scalings)
-    Fr29Mem *d_M29 = nullptr, *d_DM29 = nullptr;   // the same in radix 2^29 (fr29.hpp), what k_blob_evaluate reads
+    Fr29Mem *d_M29 = nullptr, *d_DM29 = nullptr;   // the same in radix 2^29 (fr29.hpp)
+    uint4 *d_eval_a = nullptr, *d_eval_b = nullptr;  // ... in the order k_blob_evaluate reads them (k_eval_tables)
+    uint32_t* d_eval_c = nullptr;
     Fp* d_tau4 = nullptr;   // [tau]G2 affine (x.c0 x.c1 y.c0 y.c1), Montgomery
     Fp* d_prep = nullptr;   // prepared lines: [tau]G2 then generator (2 * 408 Fp)
     void* d_gen_mult = nullptr;   // the generator's MSM tables: [0, 4) the default layout, [4, 20) the latency layout (msm.hpp)
@@ -134,6 +136,10 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
     HIPCHK(hipMalloc(&s->d_DM29, sizeof(Fr29Mem) * FE_PER_BLOB));
     hipLaunchKernelGGL(k_roots_tables, dim3(FE_PER_BLOB / 64), dim3(64), 0, s->s1, s->d_M, s->d_DM);
     hipLaunchKernelGGL(k_roots_tables29, dim3(FE_PER_BLOB / 64), dim3(64), 0, s->s1, s->d_M, s->d_M29, s->d_DM29);
+    HIPCHK(hipMalloc(&s->d_eval_a, sizeof(uint4) * EVAL_SLOTS * 64));
+    HIPCHK(hipMalloc(&s->d_eval_b, sizeof(uint4) * EVAL_SLOTS * 64));
+    HIPCHK(hipMalloc(&s->d_eval_c, 4 * EVAL_SLOTS * 64));
+    hipLaunchKernelGGL(k_eval_tables, dim3(EVAL_SLOTS), dim3(64), 0, s->s1, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c);
     HIPCHK(hipGetLastError());
     KzgRet rc;
     if ((rc = upload_program(s->prep, kzg_slp_prep_begin, kzg_slp_prep_end)) != KZG_OK) return rc;
@@ -314,7 +320,7 @@ static void ws_free(Workspace& w) {
 extern "C" void kzg_settings_free(KzgSettings* s) {
     if (!s) return;
     ws_free(s->ws);
-    void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_tau4, s->d_prep, s->d_gen_mult, s->prep.blob, s->verify.blob};
+    void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_tau4, s->d_prep, s->d_gen_mult, s->prep.blob, s->verify.blob};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : s->ev)

@@ -11,7 +11,8 @@ static void launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr*
     if (use32)
         hipLaunchKernelGGL(k_blob_evaluate32, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, d_z, s->d_M, s->d_DM, d_y, d_status);
     else
-        hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, d_z, s->d_M29, s->d_DM29, d_y, d_status);
+        hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)((T + EVAL_BLOBS_PER_BLOCK - 1) / EVAL_BLOBS_PER_BLOCK)), dim3(64 * EVAL_BLOBS_PER_BLOCK), 0, s->s1,
+                           (const uint8_t*)d_blobs, d_z, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, d_y, d_status, (int)T);
 }
 
 // The challenge kernel over T blobs on stream s1: the producer/consumer form (half the serial chain, lowest latency)

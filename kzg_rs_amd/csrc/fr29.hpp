@@ -14,6 +14,8 @@
 //     value < (value(a) * value(b) / (70 r^2) + 1) r   because 2^261 > 70 r;  all call sites keep that below 3 r.
 //   fr29_add: limb-wise.   fr29_sub_biased(a, b) = a + 8r - b with 8r written so that no limb borrows while
 //     b's limbs 0..7 are <= 2^30 - 2 and b's top limb <= 2 * (2r >> 232)  (b = sum of two product outputs).
+//   fr29_mul2(a, b, c, d) = a b + c d under one reduction - the tree's merge step z^(2^L) (na + nb) + w (na - nb):
+//     sum limbs < 2^30, difference (fr29_sub_biased4: + 4r) limbs < 3 * 2^29, columns below 2^63.8; nodes stay below 1.2 r.
 // The file compiles for the host too (plain C++), which is how the bounds are unit-tested without a GPU.
 #pragma once
 #include <stdint.h>
@@ -73,6 +75,13 @@ FR29_FN Fr29 fr29_sub_biased(const Fr29& a, const Fr29& b) {
     for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + c29::FR29_BIAS8[i] - b.l[i];
     return r;
 }
+// a + 4r - b, for b a product output (limbs 0..7 < 2^29, value < 2r): result limbs below 2^29 + 2^30 when a's are below 2^29
+FR29_FN Fr29 fr29_sub_biased4(const Fr29& a, const Fr29& b) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + c29::FR29_BIAS4[i] - b.l[i];
+    return r;
+}
 // carry propagation: limbs 0..7 back below 2^29, the excess collects in the top limb (same value)
 FR29_FN Fr29 fr29_normalize(const Fr29& a) {
     Fr29 r = a;
@@ -126,6 +135,44 @@ FR29_FN Fr29 fr29_mul(const Fr29& a, const Fr29& b) {
 #pragma unroll
         for (int i = k - 8; i <= 8; i++) {
             acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)m[i] * mod[k - i];
+        }
+        out.l[k - 9] = (uint32_t)acc & FR29_MASK;
+        acc >>= 29;
+    }
+    out.l[8] = (uint32_t)acc;
+    return out;
+}
+
+// (a b + c d) 2^-261 mod r with ONE Montgomery reduction for the two products: 162 + 72 + 9 multiply-adds instead of
+// 2 x (81 + 72 + 9) and one set of shifts and masks instead of two.  b, d narrow (limbs < 2^29); a, c moderately wide:
+// (largest limb of a) + (largest limb of c) <= 5 * 2^29, which keeps every column below 9 * 5 * 2^58 + 9 * 2^58 + carry
+// < 2^63.8.  Output limbs < 2^29, value < ((value(a) value(b) + value(c) value(d)) / (70 r^2) + 1) r.
+FR29_FN Fr29 fr29_mul2(const Fr29& a, const Fr29& b, const Fr29& c, const Fr29& d) {
+    uint64_t acc = 0;
+    uint32_t m[9], mod[9];
+    Fr29 out;
+#pragma unroll
+    for (int i = 1; i < 9; i++) mod[i] = fr29_mod_limb(i);
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * mod[k - i];
+        m[k] = (0u - (uint32_t)acc) & FR29_MASK;
+        fr29_acc_add(acc, m[k]);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) {
+            acc += (uint64_t)a.l[i] * b.l[k - i];
+            acc += (uint64_t)c.l[i] * d.l[k - i];
             acc += (uint64_t)m[i] * mod[k - i];
         }
         out.l[k - 9] = (uint32_t)acc & FR29_MASK;

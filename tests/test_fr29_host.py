@@ -118,6 +118,65 @@ def test_tree_value_discipline(lib):
         assert val(t) < 2 * R and val(t) % R == val(d) * val(z) * pow(RP, -1, R) % R
 
 
+def column_sums2(a, b, c, d):
+    """The exact 64-bit accumulator values of fr29_mul2 (Python model of the same loop)."""
+    mod = limbs(R)
+    acc, m, peak = 0, [], 0
+    for k in range(9):
+        acc += sum(a[i] * b[k - i] + c[i] * d[k - i] for i in range(k + 1)) + sum(m[i] * mod[k - i] for i in range(k))
+        m.append((-acc) & MASK)
+        acc += m[k]
+        peak = max(peak, acc)
+        assert acc & MASK == 0
+        acc >>= 29
+    out = []
+    for k in range(9, 17):
+        acc += sum(a[i] * b[k - i] + c[i] * d[k - i] + m[i] * mod[k - i] for i in range(k - 8, 9))
+        peak = max(peak, acc)
+        out.append(acc & MASK)
+        acc >>= 29
+    out.append(acc)
+    return out, peak
+
+
+def mul2(lib, a, b, c, d):
+    o = arr([0] * 9)
+    lib.h_fr29_mul2(o, arr(a), arr(b), arr(c), arr(d))
+    return list(o)
+
+
+def test_mul2_worst_case_and_merge_discipline(lib):
+    """fr29_mul2 = a b + c d under one reduction: worst-case limbs of the merge step (sum of two nodes, 4r-biased
+    difference) keep the accumulator below 2^64; iterating the merge keeps node values below 1.2 r."""
+    rinv = pow(RP, -1, R)
+    a = [(1 << 30) - 2] * 8 + [1 << 26]
+    c = [(1 << 29) - 1 + (1 << 30) - 1] * 8 + [1 << 26]
+    narrow = [MASK] * 8 + [(2 * R) >> 232]
+    out, peak = column_sums2(a, narrow, c, narrow)
+    assert peak < (1 << 64), peak.bit_length()
+    assert mul2(lib, a, narrow, c, narrow) == out
+    assert val(out) % R == (val(a) + val(c)) * val(narrow) * rinv % R
+    rng = random.Random(11)
+    r2 = limbs(RP * RP % R)
+    nodes = [mul(lib, limbs(rng.randrange(R)), r2) for _ in range(64)]
+    for _ in range(400):
+        na, nb = rng.choice(nodes), rng.choice(nodes)
+        z, w = rng.choice(nodes), rng.choice(nodes)
+        o = arr([0] * 9)
+        lib.h_fr29_add(o, arr(na), arr(nb))
+        s = list(o)
+        lib.h_fr29_sub_biased4(o, arr(na), arr(nb))
+        d = list(o)
+        assert val(s) == val(na) + val(nb) and max(s[:8]) < (1 << 30)
+        assert val(d) == val(na) + 4 * R - val(nb) and max(d[:8]) < 3 * (1 << 29)
+        got = mul2(lib, s, z, d, w)
+        exp, peak = column_sums2(s, z, d, w)
+        assert got == exp and peak < (1 << 64)
+        assert all(x < (1 << 29) for x in got[:8]) and 10 * val(got) < 12 * R
+        assert val(got) % R == (val(s) * val(z) + val(d) * val(w)) * rinv % R
+        nodes[rng.randrange(64)] = got
+
+
 def test_words_round_trip_and_normalize(lib):
     rng = random.Random(3)
     for _ in range(500):
