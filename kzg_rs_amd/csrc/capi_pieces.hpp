@@ -27,7 +27,8 @@ static KzgRet evaluate_device_locked(void* d_y, const void* d_blobs, const void*
     Workspace& w = s->ws;
     HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * n, s->s1));
     HIPCHK(hipEventRecord(s->ev[7], s->s1));
-    launch_evaluate(s, d_blobs, (const Fr*)d_z, (Fr*)d_y, w.d_status, n);
+    KzgRet rc = launch_evaluate(s, d_blobs, (const Fr*)d_z, (Fr*)d_y, w.d_status, n);
+    if (rc != KZG_OK) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[8], s->s1));
     uint32_t* h_status = reinterpret_cast<uint32_t*>(w.h_buf + 64 * n);

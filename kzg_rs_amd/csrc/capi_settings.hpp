@@ -60,6 +60,8 @@ struct KzgSettings {
     hipEvent_t ev[12] = {};
     mutable std::mutex mu;
     mutable Workspace ws;
+    mutable uint32_t* d_eval_scratch = nullptr;  // between the three evaluation kernels (launch_evaluate)
+    mutable size_t eval_scratch_cap = 0;
     mutable float timings[8] = {};
     mutable double tsum[8] = {};   // the same, summed over every group finished on this handle since the last reset
     mutable uint64_t tcount = 0;
@@ -320,7 +322,7 @@ static void ws_free(Workspace& w) {
 extern "C" void kzg_settings_free(KzgSettings* s) {
     if (!s) return;
     ws_free(s->ws);
-    void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_tau4, s->d_prep, s->d_gen_mult, s->prep.blob, s->verify.blob};
+    void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_eval_scratch, s->d_tau4, s->d_prep, s->d_gen_mult, s->prep.blob, s->verify.blob};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : s->ev)

@@ -3,16 +3,29 @@
 
 // The evaluation kernel over T blobs on stream s1 (radix-2^29 form; KZG_EVALUATE_KERNEL=32 selects the 8x32 form,
 // kept for A/B measurement and as a cross-check).
-static void launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr* d_z, Fr* d_y, uint32_t* d_status, size_t T) {
+static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr* d_z, Fr* d_y, uint32_t* d_status, size_t T) {
     static const bool use32 = [] {
         const char* e = getenv("KZG_EVALUATE_KERNEL");
         return e && strcmp(e, "32") == 0;
     }();
-    if (use32)
+    if (use32) {
         hipLaunchKernelGGL(k_blob_evaluate32, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, d_z, s->d_M, s->d_DM, d_y, d_status);
-    else
-        hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)((T + EVAL_BLOBS_PER_BLOCK - 1) / EVAL_BLOBS_PER_BLOCK)), dim3(64 * EVAL_BLOBS_PER_BLOCK), 0, s->s1,
-                           (const uint8_t*)d_blobs, d_z, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, d_y, d_status, (int)T);
+        return KZG_OK;
+    }
+    if (T > s->eval_scratch_cap) {  // 576 bytes per blob between the three kernels (fr_kernels.hpp); callers hold the handle's lock
+        if (s->d_eval_scratch) HIPCHK(hipFree(s->d_eval_scratch));  // waits for the kernels that may still read it
+        s->d_eval_scratch = nullptr;
+        s->eval_scratch_cap = 0;
+        const size_t cap = T < 1024 ? 1024 : T;
+        HIPCHK(hipMalloc(&s->d_eval_scratch, 4 * (size_t)EVAL_SCRATCH_WORDS * cap));
+        s->eval_scratch_cap = cap;
+    }
+    const unsigned per_lane = (unsigned)((T + 63) / 64);
+    hipLaunchKernelGGL(k_eval_powers, dim3(per_lane), dim3(64), 0, s->s1, d_z, s->d_eval_scratch, (int)T);
+    hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)((T + EVAL_BLOBS_PER_BLOCK - 1) / EVAL_BLOBS_PER_BLOCK)), dim3(64 * EVAL_BLOBS_PER_BLOCK), 0, s->s1,
+                       (const uint8_t*)d_blobs, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, s->d_eval_scratch, d_status, (int)T);
+    hipLaunchKernelGGL(k_eval_finish, dim3(per_lane), dim3(64), 0, s->s1, s->d_eval_scratch, d_y, (int)T);
+    return KZG_OK;
 }
 
 // The challenge kernel over T blobs on stream s1: the producer/consumer form (half the serial chain, lowest latency)
@@ -229,7 +242,7 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
     HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * T, s->s1));
     if ((rc = launch_challenge(s, d_blobs, d_commitments, w.d_z, T)) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[7], s->s1));
-    launch_evaluate(s, d_blobs, w.d_z, w.d_y, w.d_status, T);
+    if ((rc = launch_evaluate(s, d_blobs, w.d_z, w.d_y, w.d_status, T)) != KZG_OK) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[8], s->s1));
     HIPCHK(hipStreamWaitEvent(s->s1, s->ev[6], 0));

@@ -420,14 +420,47 @@ __device__ __forceinline__ Fr29 eval_table_load(const EvalTables& t, int slot, i
     return r;
 }
 
+// Evaluation = k_eval_powers -> k_blob_evaluate -> k_eval_finish.  The serial parts of a blob's evaluation (13 squarings
+// of z before the tree, 4 products after it) would run on one lane of the blob's wavefront at the price of 64: they are
+// taken out into one-lane-per-blob kernels, with 576 bytes of scratch per blob in between:
+//     [ Z[0..12] = z^(2^L) R' ; Z[13] = z R'^2 (for plain operands) ; tail: N0 , S R' ]   16 x 9 words
 // z_in: plain little-endian limbs (any value < 2^256; reduced mod r here, like scalar_from_bytes_unchecked)
 // y_out: plain little-endian canonical limbs.  status[b] |= 1 when a blob element is >= r
 // (src/kzg_proof.rs:36-41 -> KzgError::BadArgs).
+constexpr int EVAL_SCRATCH_WORDS = 16 * 9;
+__global__ __launch_bounds__(64) void k_eval_powers(const Fr* __restrict__ z_in, uint32_t* __restrict__ scratch, int T) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= T) return;
+    const Fr zin = z_in[b];
+    const Fr29 r2 = fr29_const(c29::FR29_R2);
+    Fr29* Z = reinterpret_cast<Fr29*>(scratch + (size_t)b * EVAL_SCRATCH_WORDS);
+    Fr29 z = fr29_mul(fr29_from_words(zin.l), r2);  // any z < 2^256 < 2.3 r
+    Z[0] = z;
+    Z[13] = fr29_mul(z, r2);
+    for (int l = 1; l <= 12; l++) {
+        z = fr29_mul(z, z);
+        Z[l] = z;
+    }
+}
+// tail: N0 (the tree's root) and S R' (the sum of the blob's elements), both below 3r with limbs below 2^29
+__global__ __launch_bounds__(64) void k_eval_finish(const uint32_t* __restrict__ scratch, Fr* __restrict__ y_out, int T) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= T) return;
+    const Fr29* Z = reinterpret_cast<const Fr29*>(scratch + (size_t)b * EVAL_SCRATCH_WORDS);
+    const Fr29 n = Z[14], sm = Z[15];
+    // N = z N0 - (z^4096 - 1) S = z N0 + S - z^4096 S
+    const Fr29 x = fr29_mul(sm, Z[12]);
+    const Fr29 nw = fr29_sub_biased(fr29_add(fr29_mul(n, Z[0]), sm), x);
+    const Fr29 y29 = fr29_mul(nw, fr29_const(c29::FR29_INV4096_PLAIN));  // (N R')(1/4096) R'^-1 = N/4096, below 2r
+    Fr y;
+    fr29_to_words(y.l, y29);
+    y_out[b] = FrF::reduce_once(y);
+}
+
 // One wavefront per blob, four blobs per workgroup (single-wave workgroups are not spread evenly over the SIMDs).
 constexpr int EVAL_BLOBS_PER_BLOCK = 4;
-__global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restrict__ blobs, const Fr* __restrict__ z_in,
-                                                       const EvalTables tab, Fr* __restrict__ y_out,
-                                                       uint32_t* __restrict__ status, int T) {
+__global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restrict__ blobs, const EvalTables tab,
+                                                       uint32_t* __restrict__ scratch, uint32_t* __restrict__ status, int T) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int blob_idx = blockIdx.x * EVAL_BLOBS_PER_BLOCK + wave;
     const bool active = blob_idx < T;
@@ -437,19 +470,9 @@ __global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restr
     Fr29* Z = Zs[wave];
     uint4 (*stack_a)[64] = stack_as[wave], (*stack_b)[64] = stack_bs[wave];
     uint32_t (*stack_c)[64] = stack_cs[wave];
-    if (lane == 0 && active) {
-        const Fr zin = z_in[blob_idx];
-        const Fr29 r2 = fr29_const(c29::FR29_R2);
-        Fr29 z = fr29_mul(fr29_from_words(zin.l), r2);  // any z < 2^256 < 2.3 r
-        Z[0] = z;
-        Z[13] = fr29_mul(z, r2);
-        for (int l = 1; l <= 12; l++) {
-            z = fr29_mul(z, z);
-            Z[l] = z;
-        }
-    }
-    __syncthreads();
-    if (!active) return;
+    if (!active) return;  // no workgroup barrier below: a wavefront only ever touches its own part of the LDS
+    uint32_t* const my = scratch + (size_t)blob_idx * EVAL_SCRATCH_WORDS;
+    for (int i = lane; i < 14 * 9; i += 64) reinterpret_cast<uint32_t*>(Z)[i] = my[i];
     const uint4* src = reinterpret_cast<const uint4*>(blobs + (size_t)blob_idx * BLOB_BYTES) + (size_t)lane * 128;
     const Fr29 zd = Z[13];
     bool bad = false;
@@ -505,17 +528,18 @@ __global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restr
         if (sh & 0x2A) sm = fr29_normalize(sm);  // after steps 2, 4, 6
     }
     unsigned long long any_bad = __ballot(bad);
-    if (lane == 0) {
-        sm = fr29_mul(sm, fr29_const(c29::FR29_ONE));  // same residue, value back below 3r
-        // N = z N0 - (z^4096 - 1) S = z N0 + S - z^4096 S
-        const Fr29 x = fr29_mul(sm, Z[12]);
-        const Fr29 nw = fr29_sub_biased(fr29_add(fr29_mul(n, Z[0]), sm), x);
-        const Fr29 y29 = fr29_mul(nw, fr29_const(c29::FR29_INV4096_PLAIN));  // (N R')(1/4096) R'^-1 = N/4096, below 2r
-        Fr y;
-        fr29_to_words(y.l, y29);
-        y_out[blob_idx] = FrF::reduce_once(y);
-        if (any_bad) atomicOr(&status[blob_idx], 1u);
+    sm = fr29_mul(sm, fr29_const(c29::FR29_ONE));  // same residue, value back below 3r (every lane holds the same sum)
+    if (lane < 9) {
+        uint32_t vn = n.l[0], vs = sm.l[0];
+#pragma unroll
+        for (int i = 1; i < 9; i++) {
+            vn = lane == i ? n.l[i] : vn;
+            vs = lane == i ? sm.l[i] : vs;
+        }
+        my[14 * 9 + lane] = vn;
+        my[15 * 9 + lane] = vs;
     }
+    if (lane == 0 && any_bad) atomicOr(&status[blob_idx], 1u);
 }
 
 // ---------------------------------------------------------------- quotient polynomial (prover side)
