@@ -147,4 +147,13 @@ static bool fp29_enabled() {
     }();
     return v;
 }
+// Throughput layout of the verification MSM (MSM_CHUNKS tables) with AFFINE entries and mixed additions (msm.hpp
+// k_mult_to_affine29); KZG_MSM_AFFINE=0 keeps Jacobian entries (A/B measurement).  Radix-2^29 field only.
+static bool msm_affine_enabled() {
+    static const bool v = [] {
+        const char* e = getenv("KZG_MSM_AFFINE");
+        return fp29_enabled() && !(e && e[0] == '0');
+    }();
+    return v;
+}
 constexpr size_t MULT_ENTRY_BYTES = sizeof(G1Jac29Mem) > sizeof(G1Jac) ? sizeof(G1Jac29Mem) : sizeof(G1Jac);

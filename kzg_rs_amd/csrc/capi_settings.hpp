@@ -22,7 +22,9 @@ struct Workspace {
     uint32_t *d_status = nullptr, *d_pflag = nullptr, *d_term_point = nullptr, *d_term_scalar = nullptr, *d_sorted = nullptr;
     G1Aff* d_points = nullptr;
     G1Jac *d_window = nullptr, *d_window_sl = nullptr, *d_ab = nullptr, *d_parts = nullptr;
-    void* d_mult = nullptr;  // MSM tables: G1Jac29Mem or G1Jac entries (fp29_enabled())
+    void* d_mult = nullptr;  // MSM tables: G1Jac29Mem / G1Aff29Mem / G1Jac entries (fp29_enabled(), msm_affine_enabled())
+    G1Jac29Mem* d_jtmp = nullptr;  // 2^64 P of every decoded point on its way to the affine table (k_mult_to_affine29)
+    bool mult_affine = false;      // format of d_mult as the last decode left it
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
     uint8_t *d_stage_blobs = nullptr, *d_stage_cp = nullptr, *d_bytes = nullptr, *d_records = nullptr;
     // pinned host mirrors
@@ -39,6 +41,7 @@ struct KzgSettings {
     Fp* d_tau4 = nullptr;   // [tau]G2 affine (x.c0 x.c1 y.c0 y.c1), Montgomery
     Fp* d_prep = nullptr;   // prepared lines: [tau]G2 then generator (2 * 408 Fp)
     void* d_gen_mult = nullptr;   // the generator's MSM tables: [0, 4) the default layout, [4, 20) the latency layout (msm.hpp)
+    G1Aff29Mem* d_gen_mult_aff = nullptr;  // [0, 4) as affine entries
     // full trusted setup (kzg_settings_load_trusted_setup only; not needed by verification):
     G1Aff* d_g1 = nullptr;            // g1_points, bit-reversal permuted (build.rs:79,89-105), 4096 entries
     uint32_t* d_g1_flag = nullptr;    // 0 finite / 1 identity (unchecked decode, build.rs:68)
@@ -177,6 +180,8 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
         if (fp29_enabled()) {
             HIPCHK(hipMalloc(&s->d_gen_mult, sizeof(G1Jac29Mem) * NG));
             hipLaunchKernelGGL(k_jac_to_jac29, dim3(1), dim3(64), 0, s->s1, d_gm, (G1Jac29Mem*)s->d_gen_mult, NG);
+            HIPCHK(hipMalloc(&s->d_gen_mult_aff, sizeof(G1Aff29Mem) * MSM_CHUNKS));
+            hipLaunchKernelGGL(k_jac29_to_aff29, dim3(1), dim3(64), 0, s->s1, (const G1Jac29Mem*)s->d_gen_mult, s->d_gen_mult_aff, MSM_CHUNKS);
             HIPCHK(hipStreamSynchronize(s->s1));
             HIPCHK(hipFree(d_gm));
         } else {
@@ -269,8 +274,8 @@ extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char*
     HIPCHK(hipMemcpyAsync(d_bytes, g1b.data(), g1b.size(), hipMemcpyHostToDevice, s->s1));
     hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, s->d_g1, s->d_g1_flag, N, 0);
     if (fp29_enabled())
-        hipLaunchKernelGGL(k_g1_decode_multiples29<MSM_CHUNKS>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
-                           d_flag2, (G1Jac29Mem*)s->d_g1_mult, N, N);
+        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
+                           d_flag2, s->d_g1_mult, (G1Jac29Mem*)nullptr, N, N);
     else
         hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
                            d_flag2, (G1Jac*)s->d_g1_mult, N, N);
@@ -311,7 +316,7 @@ extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_
 
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
-                    w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_mult, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
+                    w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_mult, w.d_jtmp, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
                     w.d_records};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -322,7 +327,7 @@ static void ws_free(Workspace& w) {
 extern "C" void kzg_settings_free(KzgSettings* s) {
     if (!s) return;
     ws_free(s->ws);
-    void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_eval_scratch, s->d_tau4, s->d_prep, s->d_gen_mult, s->prep.blob, s->verify.blob};
+    void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_eval_scratch, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : s->ev)

@@ -78,6 +78,7 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
         HIPCHK(hipMalloc(&w.d_window_sl, sizeof(G1Jac) * 2 * MSM_WINDOWS * MSM_MAX_SLICES * 4));  // sliced launches have <= 4 batches
         HIPCHK(hipMalloc(&w.d_mult, MULT_ENTRY_BYTES * std::max((size_t)MSM_CHUNKS * np, (size_t)MSM_CHUNKS_LATENCY * std::min(np, (size_t)(2 * LATENCY_MAX_BLOBS + 1)))));
         HIPCHK(hipMalloc(&w.d_ab, sizeof(G1Jac) * 2 * capB));
+        if (msm_affine_enabled()) HIPCHK(hipMalloc(&w.d_jtmp, sizeof(G1Jac29Mem) * np));
         HIPCHK(hipMalloc(&w.d_parts, sizeof(G1Jac) * 2 * capB * MAX_WORLD));
         HIPCHK(hipMalloc(&w.d_slp_in, sizeof(Fp) * 6 * capB));
         HIPCHK(hipMalloc(&w.d_slp_out, sizeof(Fp) * 6 * capB));
@@ -148,7 +149,8 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     const int nsc = (int)(B * (2 * n + 1));
     hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc);
-    if (fp29_enabled()) hipLaunchKernelGGL(k_msm_window<Curve29>, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
+    if (w.mult_affine) hipLaunchKernelGGL(k_msm_window<Curve29Aff>, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
+    else if (fp29_enabled()) hipLaunchKernelGGL(k_msm_window<Curve29>, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
     else hipLaunchKernelGGL(k_msm_window<Curve32>, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
     if (S > 1)
         hipLaunchKernelGGL(k_msm_fold_slices, dim3((unsigned)(2 * B * slots * W)), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, (int)W);
@@ -169,12 +171,22 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
     const uint8_t *c = (const uint8_t*)d_commitments, *p = (const uint8_t*)d_proofs;
     const int n2 = (int)(2 * T);
     const size_t gen_off = w.chunks == MSM_CHUNKS ? 0 : MSM_CHUNKS;
-    if (fp29_enabled()) {
+    w.mult_affine = msm_affine_enabled() && w.chunks == MSM_CHUNKS;
+    if (w.mult_affine) {
+        // affine tables: rows 0 and 2 straight from the decode pass, rows 1 and 3 from 2^64 P through one inversion per 16 points
+        G1Aff29Mem* mult = (G1Aff29Mem*)w.d_mult;
+        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, true>), dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, w.d_jtmp, n2, np);
+        const unsigned conv_blocks = (unsigned)((n2 + 64 * AFFINE_BATCH - 1) / (64 * AFFINE_BATCH));
+        hipLaunchKernelGGL(k_mult_to_affine29, dim3(conv_blocks), dim3(64), 0, s->s2, w.d_jtmp, w.d_pflag, mult, n2, np);
+        HIPCHK(hipEventRecord(s->ev[10], s->s2));
+        hipLaunchKernelGGL(k_set_generator_multiples<G1Aff29Mem>, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, mult,
+                           (const G1Aff29Mem*)s->d_gen_mult_aff, n2, np, w.chunks);
+    } else if (fp29_enabled()) {
         G1Jac29Mem* mult = (G1Jac29Mem*)w.d_mult;
         if (w.chunks == MSM_CHUNKS_LATENCY)
-            hipLaunchKernelGGL(k_g1_decode_multiples29<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
+            hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS_LATENCY, false>), dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
         else
-            hipLaunchKernelGGL(k_g1_decode_multiples29<MSM_CHUNKS>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
+            hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
         HIPCHK(hipEventRecord(s->ev[10], s->s2));
         hipLaunchKernelGGL(k_set_generator_multiples<G1Jac29Mem>, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, mult,
                            (const G1Jac29Mem*)s->d_gen_mult + gen_off, n2, np, w.chunks);

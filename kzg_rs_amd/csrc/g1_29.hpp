@@ -19,6 +19,13 @@ struct alignas(16) Fp29Mem {
 struct G1Jac29Mem {
     Fp29Mem x, y, z;
 };
+// an affine table entry (never the identity: the MSM skips flagged points before it looks at their entries)
+struct G1Aff29 {
+    Fp29 x, y;
+};
+struct G1Aff29Mem {
+    Fp29Mem x, y;
+};
 
 __device__ __forceinline__ Fp29 fp29_load(const Fp29Mem& m) {
     const uint4* p = reinterpret_cast<const uint4*>(m.l);
@@ -49,6 +56,16 @@ __device__ __forceinline__ void g1j29_store(G1Jac29Mem& m, const G1Jac29& p) {
     fp29_store(m.x, p.x);
     fp29_store(m.y, p.y);
     fp29_store(m.z, p.z);
+}
+__device__ __forceinline__ G1Aff29 g1a29_load(const G1Aff29Mem& m) {
+    G1Aff29 r;
+    r.x = fp29_load(m.x);
+    r.y = fp29_load(m.y);
+    return r;
+}
+__device__ __forceinline__ void g1a29_store(G1Aff29Mem& m, const Fp29& x, const Fp29& y) {
+    fp29_store(m.x, x);
+    fp29_store(m.y, y);
 }
 
 // ---- conversions to / from the 12x32 Montgomery form (radix 2^384) of field.hpp
@@ -122,6 +139,33 @@ __device__ __forceinline__ G1Jac29 g1j29_add(const G1Jac29& p, const G1Jac29& q)
     return r;
 }
 
+// mixed addition p + q, q affine and not the identity: 8M + 3S instead of 12M + 4S (madd-2007-bl without the
+// doubling tricks).  p below X < 256p, Y < 256p, Z < 2^10 p (every output of dbl / add / this function is); q below 8p.
+// Outputs X < 14p, Y < 6p, Z < 2p (or a dbl / q passed through).
+__device__ __forceinline__ G1Jac29 g1j29_add_affine(const G1Jac29& p, const G1Aff29& q) {
+    const Fp29 Z1Z1 = fp29_sqr(p.z);
+    if (fp29_is_zero_mod_p(Z1Z1)) {
+        G1Jac29 r;
+        r.x = q.x;
+        r.y = q.y;
+        r.z = fp29_const(cp29::FP29_ONE);
+        return r;
+    }
+    const Fp29 U2 = fp29_mul(q.x, Z1Z1), S2 = fp29_mul(fp29_mul(q.y, p.z), Z1Z1);
+    const Fp29 H = fp29_sub<9>(U2, p.x), Rr = fp29_sub<9>(S2, p.y);  // < 514p
+    const Fp29 HH = fp29_sqr(H), RR = fp29_sqr(Rr);
+    if (fp29_is_zero_mod_p(HH)) {
+        if (fp29_is_zero_mod_p(RR)) return g1j29_dbl(p);
+        return g1j29_identity();
+    }
+    const Fp29 HHH = fp29_mul(H, HH), V = fp29_mul(p.x, HH);
+    G1Jac29 r;
+    r.x = fp29_sub<3>(fp29_sub<2>(RR, HHH), fp29_dbl(V));                             // < 14p
+    r.y = fp29_sub<2>(fp29_mul(Rr, fp29_sub<5>(V, r.x)), fp29_mul(p.y, HHH));         // < 6p
+    r.z = fp29_mul(p.z, H);                                                           // < 2p
+    return r;
+}
+
 // -phi(P) = (beta x, -y, z); y below 64p in, below 128p out
 __device__ __forceinline__ G1Jac29 g1j29_neg_phi(const G1Jac29& p) {
     G1Jac29 r;
@@ -174,16 +218,17 @@ __device__ inline bool g1j29_in_subgroup_with_multiples(const Fp29& x, const Fp2
     return fp29_is_zero_mod_p(dx) && fp29_is_zero_mod_p(dy);
 }
 
-// a^((p+1)/4) with the 3-bit sliding window of g1.hpp's fp_pow_window3; a below 8p
-__device__ inline Fp29 fp29_sqrt_candidate(const Fp29& a) {
+// a^e (e: little-endian 32-bit words, `top` = index of its highest set bit) with the 3-bit sliding window of g1.hpp's
+// fp_pow_window3; a below 8p
+__device__ inline Fp29 fp29_pow_window3(const Fp29& a, const uint32_t (&e)[12], int top) {
     const Fp29 a2 = fp29_sqr(a);
     Fp29 t[4];
     t[0] = a;
     for (int k = 1; k < 4; k++) t[k] = fp29_mul(t[k - 1], a2);
     Fp29 acc = fp29_const(cp29::FP29_ONE);
     bool started = false;
-    int i = 379;  // (p+1)/4 has 379 bits
-    auto bit = [](int k) { return (consts::FP_SQRT_EXP[k >> 5] >> (k & 31)) & 1u; };
+    int i = top;
+    auto bit = [&](int k) { return (e[k >> 5] >> (k & 31)) & 1u; };
     while (i >= 0) {
         if (!bit(i)) {
             if (started) acc = fp29_sqr(acc);
@@ -206,6 +251,8 @@ __device__ inline Fp29 fp29_sqrt_candidate(const Fp29& a) {
     }
     return acc;
 }
+__device__ inline Fp29 fp29_sqrt_candidate(const Fp29& a) { return fp29_pow_window3(a, consts::FP_SQRT_EXP, 378); }  // (p+1)/4 has 379 bits
+__device__ inline Fp29 fp29_inverse(const Fp29& a) { return fp29_pow_window3(a, consts::FP_P_MINUS_2, 380); }       // p - 2 has 381 bits; a != 0 mod p
 
 // 48 compressed bytes -> affine point in this field (x R'', y R'' below 2p... y possibly 4p - y).  Subgroup NOT checked.
 // Returns G1_OK / G1_INFINITY / G1_INVALID exactly like g1_decompress.

@@ -155,10 +155,14 @@ __global__ __launch_bounds__(64, 2) void k_g1_decode_multiples(const uint8_t* __
 
 // The same pass in the radix-2^29 field (fp29.hpp, g1_29.hpp): tables written as G1Jac29Mem (lazy values), the affine
 // point as a canonical 12x32 element like the kernel above.
-template <int CHUNKS>
+// AFF (CHUNKS = 4 only): the AFFINE table layout of the throughput path.  P and -phi(P) are affine as they are; the one
+// Jacobian multiple 2^64 P goes to jtmp[i] and k_mult_to_affine29 below turns it into table rows 1 and 3, so that the
+// window kernel's bucket additions are mixed additions (8M + 3S instead of 12M + 4S).
+template <int CHUNKS, bool AFF>
 __global__ __launch_bounds__(64, 2) void k_g1_decode_multiples29(const uint8_t* __restrict__ bytes0, const uint8_t* __restrict__ bytes1,
                                                                  int n0, G1Aff* __restrict__ points, uint32_t* __restrict__ pflag,
-                                                                 G1Jac29Mem* __restrict__ mult, int n, int stride) {
+                                                                 void* __restrict__ mult_, G1Jac29Mem* __restrict__ jtmp, int n, int stride) {
+    static_assert(!AFF || CHUNKS == 4, "the affine layout has one Jacobian multiple per point");
     constexpr int HALF = CHUNKS / 2, STEP = 256 / CHUNKS;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -169,16 +173,25 @@ __global__ __launch_bounds__(64, 2) void k_g1_decode_multiples29(const uint8_t* 
     a.x = FpF::zero();
     a.y = FpF::zero();
     if (st == G1_OK) {
-        G1Jac29 p;
-        p.x = x;
-        p.y = y;
-        p.z = fp29_const(cp29::FP29_ONE);
-        g1j29_store(mult[i], p);
-        g1j29_store(mult[(size_t)HALF * stride + i], g1j29_neg_phi(p));
-        const bool in = g1j29_in_subgroup_with_multiples<STEP>(x, y, [&](int k, const G1Jac29& m) {
-            g1j29_store(mult[(size_t)k * stride + i], m);
-            g1j29_store(mult[(size_t)(HALF + k) * stride + i], g1j29_neg_phi(m));
-        });
+        bool in;
+        if constexpr (AFF) {
+            G1Aff29Mem* mult = static_cast<G1Aff29Mem*>(mult_);
+            g1a29_store(mult[i], x, y);
+            g1a29_store(mult[(size_t)HALF * stride + i], fp29_mul(x, fp29_const(cp29::FP29_BETA_MONT)), fp29_neg<3>(y));  // y < 4p
+            in = g1j29_in_subgroup_with_multiples<STEP>(x, y, [&](int, const G1Jac29& m) { g1j29_store(jtmp[i], m); });
+        } else {
+            G1Jac29Mem* mult = static_cast<G1Jac29Mem*>(mult_);
+            G1Jac29 p;
+            p.x = x;
+            p.y = y;
+            p.z = fp29_const(cp29::FP29_ONE);
+            g1j29_store(mult[i], p);
+            g1j29_store(mult[(size_t)HALF * stride + i], g1j29_neg_phi(p));
+            in = g1j29_in_subgroup_with_multiples<STEP>(x, y, [&](int k, const G1Jac29& m) {
+                g1j29_store(mult[(size_t)k * stride + i], m);
+                g1j29_store(mult[(size_t)(HALF + k) * stride + i], g1j29_neg_phi(m));
+            });
+        }
         if (in) {
             a.x = fp29_to_std(x);
             a.y = fp29_to_std(y);
@@ -186,12 +199,54 @@ __global__ __launch_bounds__(64, 2) void k_g1_decode_multiples29(const uint8_t* 
             st = G1_INVALID;
         }
     }
-    if (st != G1_OK) {
+    if (st != G1_OK && !AFF) {  // (affine entries of a flagged point are never read)
+        G1Jac29Mem* mult = static_cast<G1Jac29Mem*>(mult_);
         const G1Jac29 id = g1j29_identity();
         for (int k = 0; k < CHUNKS; k++) g1j29_store(mult[(size_t)k * stride + i], id);
     }
     points[i] = a;
     pflag[i] = st;
+}
+
+// jtmp[i] = 2^64 P_i (Jacobian) -> table rows 1 and 3 of the affine layout: (X / Z^2, Y / Z^3) and its -phi image.
+// Thread t owns the K points t, t + nthreads, ...: ONE inversion per thread (Montgomery's trick; the prefix products
+// are parked in the x slot of the output row until the backward sweep overwrites it).  Flagged points are skipped.
+constexpr int AFFINE_BATCH = 16;
+__global__ __launch_bounds__(64, 2) void k_mult_to_affine29(const G1Jac29Mem* __restrict__ jtmp, const uint32_t* __restrict__ pflag,
+                                                           G1Aff29Mem* __restrict__ mult, int n, int stride) {
+    const int nthreads = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    G1Aff29Mem* row1 = mult + stride;
+    G1Aff29Mem* row3 = mult + (size_t)3 * stride;
+    Fp29 acc = fp29_const(cp29::FP29_ONE);
+#pragma unroll 1
+    for (int k = 0; k < AFFINE_BATCH; k++) {
+        const int i = t + k * nthreads;
+        if (i >= n || pflag[i]) continue;
+        fp29_store(row1[i].x, acc);
+        acc = fp29_mul(acc, fp29_load(jtmp[i].z));  // Z of a point of G1 that is not the identity: never 0 mod p
+    }
+    Fp29 inv = fp29_inverse(acc);
+    const Fp29 beta = fp29_const(cp29::FP29_BETA_MONT);
+#pragma unroll 1
+    for (int k = AFFINE_BATCH - 1; k >= 0; k--) {
+        const int i = t + k * nthreads;
+        if (i >= n || pflag[i]) continue;
+        const Fp29 zi = fp29_mul(inv, fp29_load(row1[i].x));  // 1 / Z_i
+        inv = fp29_mul(inv, fp29_load(jtmp[i].z));
+        const Fp29 zi2 = fp29_sqr(zi), zi3 = fp29_mul(zi2, zi);
+        const Fp29 x = fp29_mul(fp29_load(jtmp[i].x), zi2), y = fp29_mul(fp29_load(jtmp[i].y), zi3);  // < 2p
+        g1a29_store(row1[i], x, y);
+        g1a29_store(row3[i], fp29_mul(x, beta), fp29_neg<2>(y));  // < 4p
+    }
+}
+
+// Jacobian table entries -> affine ones, one inversion each (set-up time only: the generator's multiples)
+__global__ void k_jac29_to_aff29(const G1Jac29Mem* __restrict__ in, G1Aff29Mem* __restrict__ out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const G1Jac29 p = g1j29_load(in[i]);
+    const Fp29 zi = fp29_inverse(p.z), zi2 = fp29_sqr(zi);
+    g1a29_store(out[i], fp29_mul(p.x, zi2), fp29_mul(p.y, fp29_mul(zi2, zi)));
 }
 
 // tables made in the 12x32 form (k_g1_multiples: the generator, kzg_g1_msm) -> the radix-2^29 table format
@@ -331,7 +386,9 @@ __device__ __forceinline__ G1Jac29 lds_load_jac29(const uint32_t* base, int slot
 struct Curve32 {
     using Pt = G1Jac;
     using Mem = G1Jac;
+    using Entry = G1Jac;
     static constexpr int WORDS = 36;
+    __device__ static __forceinline__ Pt add_entry(const Pt& a, const Entry& b) { return g1_add(a, b); }
     __device__ static __forceinline__ Pt identity() { return g1_identity(); }
     __device__ static __forceinline__ Pt add(const Pt& a, const Pt& b) { return g1_add(a, b); }
     __device__ static __forceinline__ Pt dbl(const Pt& a) { return g1_dbl(a); }
@@ -343,7 +400,9 @@ struct Curve32 {
 struct Curve29 {
     using Pt = G1Jac29;
     using Mem = G1Jac29Mem;
+    using Entry = G1Jac29;
     static constexpr int WORDS = 42;
+    __device__ static __forceinline__ Pt add_entry(const Pt& a, const Entry& b) { return g1j29_add(a, b); }
     __device__ static __forceinline__ Pt identity() { return g1j29_identity(); }
     __device__ static __forceinline__ Pt add(const Pt& a, const Pt& b) { return g1j29_add(a, b); }
     __device__ static __forceinline__ Pt dbl(const Pt& a) { return g1j29_dbl(a); }
@@ -351,6 +410,14 @@ struct Curve29 {
     __device__ static __forceinline__ void lds_store(uint32_t* b, int s, const Pt& p) { lds_store_jac29(b, s, p); }
     __device__ static __forceinline__ Pt lds_load(const uint32_t* b, int s) { return lds_load_jac29(b, s); }
     __device__ static __forceinline__ G1Jac to_std(const Pt& p) { return g1j29_to_std(p); }
+};
+
+// Curve29 with AFFINE table entries (k_mult_to_affine29): bucket accumulation by mixed additions
+struct Curve29Aff : Curve29 {
+    using Mem = G1Aff29Mem;
+    using Entry = G1Aff29;
+    __device__ static __forceinline__ Pt add_entry(const Pt& a, const Entry& b) { return g1j29_add_affine(a, b); }
+    __device__ static __forceinline__ Entry load(const Mem& m) { return g1a29_load(m); }
 };
 
 #ifndef KZG_MSM_OCC
@@ -423,7 +490,7 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     if (bucket > 0) {
         for (uint32_t k = off[bucket]; k < off[bucket + 1]; k++) {
             const uint32_t e = sorted[k];
-            acc = CV::add(acc, CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
+            acc = CV::add_entry(acc, CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
         }
     }
     // 3. sum_b b*B_b with b = 16 hi + lo:   16 * sum_hi hi*R_hi + sum_lo lo*C_lo,
