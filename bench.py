@@ -31,11 +31,11 @@ BYTES_PER_BLOB = 131072
 ALG_BYTES = {
     "k_blob_challenge": BYTES_PER_BLOB + 48 + 32,   # blob + commitment read, z written       (per blob)
     "k_blob_evaluate": BYTES_PER_BLOB + 32 + 32,    # blob + z read, y written                (per blob)
-    "k_g1_decode_multiples": 2 * (48 + 96 + 4 + 4 * 144),  # two points per blob: compressed in; affine, flag, 4 Jacobian multiples out
+    "k_g1_decode_multiples": 2 * (48 + 96 + 4 + 4 * 128 + 192),  # two points per blob: compressed in; affine, flag, 4 affine table rows, 2^64 P out
     "k_msm": 3 * 128,                               # three (point, scalar) terms per blob, 96 + 32 B each
     "k_slp_run(pairing)": 0,
 }
-PMC_FILE = "r1g_pmc.json"
+PMC_FILE = "r1h_pmc.json"
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
 
 
@@ -210,7 +210,8 @@ def main():
     # committed PMC profile (the largest VALU instruction count: the challenge kernel); its duration is still the live
     # one, measured with HIP events on the library's own stream over the timed region.
     PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge", "k_blob_evaluate": "kzg::k_blob_evaluate",
-                "k_g1_decode_multiples": "kzg::k_g1_decode_multiples<4>", "k_msm": "kzg::k_msm_window", "k_slp_run(pairing)": "kzg::k_slp_run<false>"}
+                "k_g1_decode_multiples": "kzg::k_g1_decode_multiples29<4, true>", "k_msm": "kzg::k_msm_window<kzg::Curve29Aff>",
+                "k_slp_run(pairing)": "kzg::k_slp_run<false>"}
     try:
         prof = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
         dom = max(kernels, key=lambda k: prof.get(PMC_NAME[k], {}).get("SQ_INSTS_VALU", 0))
@@ -227,7 +228,8 @@ def main():
         pk = pmc["kernels"].get(PMC_NAME[dom])
         if pk and "hbm_bytes_corrected" in pk:
             traffic = round(pk["hbm_bytes_corrected"] * units / pmc["blobs_per_launch"])
-        path = list(PMC_NAME.values()) + ["kzg::k_msm_combine", "kzg::k_batch_scalars", "kzg::k_glv_split"]
+        path = list(PMC_NAME.values()) + ["kzg::k_msm_combine", "kzg::k_batch_scalars", "kzg::k_glv_split", "kzg::k_mult_to_affine29",
+                                           "kzg::k_eval_powers", "kzg::k_eval_finish"]
         insts = sum(pmc["kernels"][k].get("SQ_INSTS_VALU", 0) for k in path if k in pmc["kernels"])
         per_blob = insts / pmc["blobs_per_launch"]  # wave-instructions per blob, all kernels of the path
         simds, clock = 1024, 2.4e9

@@ -479,8 +479,15 @@ __global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restr
     Fr29 n, psum;  // psum: this lane's share of S = sum_i p_i (plain integer, < 64 r)
 #pragma unroll
     for (int i = 0; i < 9; i++) psum.l[i] = 0;
+    // Software pipelining: the blob words and the leaf entry of pair q + 1 and the root entry of the next merge are
+    // requested one product ahead of their use (three waves per SIMD do not hide an L2 / HBM round trip by themselves).
+    uint4 a_hi = src[0], a_lo = src[1], b_hi = src[2], b_lo = src[3];
+    Fr29 leaf = eval_table_load(tab, 0, lane);
     for (int q = 0; q < 32; q++) {
-        uint4 a_hi = src[4 * q], a_lo = src[4 * q + 1], b_hi = src[4 * q + 2], b_lo = src[4 * q + 3];
+        const int qn = q < 31 ? q + 1 : 31;
+        const uint4 na_hi = src[4 * qn], na_lo = src[4 * qn + 1], nb_hi = src[4 * qn + 2], nb_lo = src[4 * qn + 3];
+        const Fr29 leaf_next = eval_table_load(tab, qn, lane);
+        Fr29 root = eval_table_load(tab, 32 + (q >> 1), lane);  // level-1 merge of this pair (used when q is odd)
         Fr wa = fr_from_be_words(a_hi, a_lo), wb = fr_from_be_words(b_hi, b_lo);
         // canonical check (>= r -> BadArgs): the full 8-limb compare only when some lane's top word reaches r's
         if (__any((wa.l[7] >= consts::FR_MOD[7]) | (wb.l[7] >= consts::FR_MOD[7]))) bad |= FrF::geq_mod(wa) | FrF::geq_mod(wb);
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restr
         const Fr29 s = fr29_add(pa, pb), u = fr29_sub_biased4(pa, pb);
         psum = fr29_add(psum, s);
         if (q & 1) psum = fr29_normalize(psum);  // limbs: 2^29 + 2 * 2^30 < 2^32 between normalisations
-        n = fr29_mul2(s, zd, u, eval_table_load(tab, q, lane));  // z s + roots[2k] u, k = 32 lane + q: ONE reduction (fr29.hpp)
+        n = fr29_mul2(s, zd, u, leaf);  // z s + roots[2k] u, k = 32 lane + q: ONE reduction (fr29.hpp)
         int level = 1;
         for (int qq = q; qq & 1; qq >>= 1) {
             Fr29 na;
@@ -496,9 +503,11 @@ __global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restr
             na.l[0] = h0.x; na.l[1] = h0.y; na.l[2] = h0.z; na.l[3] = h0.w;
             na.l[4] = h1.x; na.l[5] = h1.y; na.l[6] = h1.z; na.l[7] = h1.w;
             na.l[8] = stack_c[level - 1][lane];
+            Fr29 root_next = root;
+            if (qq & 2) root_next = eval_table_load(tab, 64 - (32 >> level) + (q >> (level + 1)), lane);  // the merge one level up follows
             const Fr29 sum = fr29_add(na, n), dif = fr29_sub_biased4(na, n);
-            const int slot = 64 - (32 >> (level - 1)) + (q >> level);
-            n = fr29_mul2(sum, Z[level], dif, eval_table_load(tab, slot, lane));
+            n = fr29_mul2(sum, Z[level], dif, root);
+            root = root_next;
             level++;
         }
         if (q != 31) {  // level <= 5 here
@@ -506,6 +515,8 @@ __global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restr
             stack_b[level - 1][lane] = make_uint4(n.l[4], n.l[5], n.l[6], n.l[7]);
             stack_c[level - 1][lane] = n.l[8];
         }
+        a_hi = na_hi; a_lo = na_lo; b_hi = nb_hi; b_lo = nb_lo;
+        leaf = leaf_next;
     }
     // n = N0_{6,lane}; fold across lanes
     for (int L = 6; L < 12; L++) {

@@ -321,6 +321,26 @@ def test_challenge_kernel_forms(form):
     assert got == [O.compute_challenge(b, c).hex() for b, c in zip(blobs, cs)]
 
 
+@pytest.mark.parametrize("env", [
+    {"KZG_MSM_LATENCY_LAYOUT": "0"},                         # small batches through the throughput layout: affine tables, mixed additions
+    {"KZG_MSM_LATENCY_LAYOUT": "0", "KZG_MSM_AFFINE": "0"},  # ... with Jacobian tables in the radix-2^29 field
+    {"KZG_FP29": "0"},                                       # point kernels in the 12x32 field
+    {"KZG_EVALUATE_KERNEL": "32"},                           # evaluation in the 8x32 field
+], ids=["affine-tables", "jacobian29-tables", "fp-12x32", "fr-8x32"])
+def test_kernel_variants_differential_fuzz(env):
+    """The alternative forms of the point and evaluation kernels (each selected for a whole process by an environment
+    variable) through 12 s of tools/fuzz_campaign.py: mutated c-kzg vectors with duplicates, points at infinity, points
+    off the curve or outside G1 and non-canonical scalars, three entry points, every outcome equal to the oracle's.
+    The default process takes the latency layout for batches this small, so this is also what runs the throughput
+    layout's mixed-addition special cases (P + P, P - P, first addition into an empty bucket) against the oracle."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(O.ROOT, "tools", "fuzz_campaign.py"), "12", "20261002"],
+                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    assert "no mismatch" in out.stdout
+
+
 def test_evaluate_at_roots_of_unity(settings, osettings):
     """src/kzg_proof.rs:109-111: z equal to roots_of_unity[i] returns polynomial[i]."""
     rng = random.Random(7)
