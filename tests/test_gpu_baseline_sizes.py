@@ -158,3 +158,66 @@ def test_mid_size_launch_groups(n, B):
     torch.cuda.synchronize()
     got = api.verify_blob_kzg_proof_batches_device(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, B, st)
     assert got == [b != wrong for b in range(B)]
+
+
+def test_throughput_layout_special_batches():
+    """A launch of 130 batches x 64 blobs (8 320 blobs: the throughput MSM layout with affine tables, beyond the
+    latency layout's 4 096) in which single batches hold what the big synthetic runs never do: 64 copies of one
+    tuple (equal points meet in the buckets: the doubling branch of the mixed addition), a zero blob whose commitment
+    and proof are the point at infinity (flagged points are skipped, the batch stays valid), a commitment on the
+    curve but outside G1 (Err), a junk proof encoding (Err) and a wrong proof (false).  Expected values from the
+    oracle on each special batch alone."""
+    import torch
+    from kzg_rs_amd import synth
+    n, B = 64, 130
+    blobs, cs, ps, st = synth.make_valid_batch(n, seed=4242)
+    ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])
+    inf = bytes([0xC0]) + bytes(47)
+    P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    x = 5
+    while True:  # a point of the curve: with overwhelming probability outside the subgroup (the oracle confirms below)
+        y2 = (x * x * x + 4) % P
+        y = pow(y2, (P + 1) // 4, P)
+        if y * y % P == y2:
+            break
+        x += 1
+    enc = bytearray(x.to_bytes(48, "big"))
+    enc[0] |= 0x80 | (0x20 if y > P - y else 0)
+    off_subgroup = bytes(enc)
+    with pytest.raises(O.OracleError):
+        O.g1_decompress(off_subgroup)
+    idx = torch.cat([torch.roll(torch.arange(n), 5 * b) for b in range(B)])
+    all_blobs = torch.from_numpy(blobs)[idx].contiguous()
+    c_all = [cs[i] for i in idx.tolist()]
+    p_all = [ps[i] for i in idx.tolist()]
+    want = [True] * B
+
+    def setb(b, k, blob=None, c=None, p=None):
+        if blob is not None:
+            all_blobs[b * n + k] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+        if c is not None:
+            c_all[b * n + k] = c
+        if p is not None:
+            p_all[b * n + k] = p
+
+    for k in range(n):                                  # batch 3: one tuple 64 times
+        setb(3, k, blobs[9].tobytes(), cs[9], ps[9])
+    setb(40, 7, bytes(131072), inf, inf)               # batch 40: zero polynomial
+    setb(41, 0, bytes(131072), inf, inf)
+    setb(41, 63, bytes(131072), inf, inf)
+    setb(77, 11, c=off_subgroup)                        # batch 77: commitment outside G1 -> Err
+    setb(78, 12, p=bytes([0x81]) + bytes(range(1, 48)))  # batch 78: junk proof -> Err
+    setb(129, 63, p=O.g1_add(p_all[129 * n + 63], cs[0]))  # last batch: wrong proof -> false
+    for b in (3, 40, 41, 77, 78, 129):
+        bl = [all_blobs[i].numpy().tobytes() for i in range(b * n, (b + 1) * n)]
+        try:
+            want[b] = O.verify_blob_kzg_proof_batch(bl, c_all[b * n:(b + 1) * n], p_all[b * n:(b + 1) * n], ost)
+        except O.OracleError:
+            want[b] = None
+    assert [want[b] for b in (3, 40, 41, 77, 78, 129)] == [True, True, True, None, None, False]
+    d_b = all_blobs.cuda()
+    d_c = torch.frombuffer(bytearray(b"".join(c_all)), dtype=torch.uint8).cuda()
+    d_p = torch.frombuffer(bytearray(b"".join(p_all)), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    got = api.verify_blob_kzg_proof_batches_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, B, st)
+    assert got == want

@@ -66,6 +66,32 @@ def res(fn):
         return None
 
 
+# Deterministic prologue: proof tuples built so that the MSM's special cases happen in a known bucket.  With one tuple
+# r^0 = 1, so B = C + z pi - y G has scalar 1 on C, z on pi and -y on G: z = 1 puts pi beside C in bucket 1 of the first
+# window, y = r - 1 puts G there too.  C = pi / G gives P + P (the doubling branch of the bucket addition), C = -pi / -G
+# gives P - P (the identity branch), with affine or Jacobian table entries depending on the process's layout.
+def neg48(pt):
+    b = bytearray(pt); b[0] ^= 0x20; return bytes(b)
+
+
+G1_GEN = bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+one, rm1, zero = (1).to_bytes(32, "big"), (R - 1).to_bytes(32, "big"), bytes(32)
+pi0 = next(t[2] for t in tuples if t[2] != G1_INF)
+special = []
+for c in (pi0, neg48(pi0), G1_GEN, neg48(G1_GEN), G1_INF):
+    for y in (one, rm1, zero):
+        for prf in (pi0, G1_GEN, neg48(G1_GEN), G1_INF):
+            special.append((c, one, y, prf))
+for c, z, y, prf in special:
+    want = res(lambda: O.verify_kzg_proof_batch([c], [z], [y], [prf], ost))
+    got = res(lambda: KzgProof.verify_kzg_proof_batch([Bytes48(c)], [Bytes32(z)], [Bytes32(y)], [Bytes48(prf)], st))
+    got1 = res(lambda: KzgProof.verify_kzg_proof(Bytes48(c), Bytes32(z), Bytes32(y), Bytes48(prf), st))
+    want2 = res(lambda: O.verify_kzg_proof_batch([c, c], [z, z], [y, y], [prf, prf], ost))
+    got2 = res(lambda: KzgProof.verify_kzg_proof_batch([Bytes48(c)] * 2, [Bytes32(z)] * 2, [Bytes32(y)] * 2, [Bytes48(prf)] * 2, st))
+    if got != want or got1 != want or got2 != want2:
+        print("MISMATCH special tuple c=%s y=%s pi=%s got=%r/%r/%r want=%r/%r" % (c.hex()[:8], y.hex()[-4:], prf.hex()[:8], got, got1, got2, want, want2)); sys.exit(1)
+print("special bucket cases: %d tuples x 3 calls, no mismatch (%d true)" % (len(special), sum(1 for c, z, y, prf in special if res(lambda: O.verify_kzg_proof_batch([c], [z], [y], [prf], ost)))))
+
 t_end, cases, counts = time.time() + budget, 0, {True: 0, False: 0, None: 0}
 while time.time() < t_end:
     n = rng.choice([1, 1, 2, 3, 4, 7, 12])
