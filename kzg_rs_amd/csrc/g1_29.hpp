@@ -103,15 +103,27 @@ __device__ __forceinline__ G1Jac29 g1j29_identity() {
 }
 
 // dbl-2009-l (a = 0): 2M + 5S.  Inputs below 2^10 p; outputs X < 130p, Y < 34p, Z < 4p.  Z = 0 mod p stays so.
+// The linear steps are taken limb-wise on un-normalised words and carried ONCE per result (8 carry passes instead of
+// 14): every intermediate word stays below 2^32 by the bounds noted, the biases are 16p / 128p with limbs boosted by
+// 2^31 / 2^30 so that no limb borrows (tools/gen_constants.py).
 __device__ __forceinline__ G1Jac29 g1j29_dbl(const G1Jac29& p) {
-    const Fp29 A = fp29_sqr(p.x), B = fp29_sqr(p.y), C = fp29_sqr(B);  // < 2p
+    const Fp29 A = fp29_sqr(p.x), B = fp29_sqr(p.y), C = fp29_sqr(B);  // < 2p, limbs < 2^29
     const Fp29 t = fp29_sqr(fp29_add(p.x, B));                          // < 2p
-    const Fp29 D = fp29_dbl(fp29_sub<3>(t, fp29_add(A, C)));            // 2 (t + 8p - (A + C)) < 20p
-    const Fp29 E = fp29_add(fp29_dbl(A), A);                            // < 6p
-    const Fp29 F = fp29_sqr(E);                                         // < 2p
+    Fp29 D, E, X, C8;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        D.l[i] = ((t.l[i] - A.l[i] - C.l[i]) << 1) + cp29::FP29_BIASX4[i];  // 2t + 16p - 2A - 2C: words < 2^30 + 2^29 + 2^31
+        E.l[i] = (A.l[i] << 1) + A.l[i];                                   // 3A: words < 2^31
+        C8.l[i] = C.l[i] << 3;                                             // 8C: words < 2^32
+    }
+    D = fp29_normalize(D);    // < 20p
+    E = fp29_normalize(E);    // < 6p
+    C8 = fp29_normalize(C8);  // < 16p
+    const Fp29 F = fp29_sqr(E);  // < 2p
+#pragma unroll
+    for (int i = 0; i < 14; i++) X.l[i] = F.l[i] + cp29::FP29_BIASW7[i] - (D.l[i] << 1);  // F + 128p - 2D: words < 2^31
     G1Jac29 r;
-    r.x = fp29_sub<7>(F, fp29_dbl(D));                                  // F + 128p - 2D (2D < 40p) < 130p
-    const Fp29 C8 = fp29_dbl(fp29_dbl(fp29_dbl(C)));                    // < 16p
+    r.x = fp29_normalize(X);                                            // < 130p
     r.z = fp29_dbl(fp29_mul(p.y, p.z));                                 // < 4p
     r.y = fp29_sub<5>(fp29_mul(E, fp29_sub<9>(D, r.x)), C8);            // E (D + 512p - X3) + 32p - 8C < 34p
     return r;
