@@ -32,11 +32,12 @@ extern "C" KzgRet kzg_debug_slp_bench(float* ms_out, float* mhz_out, int instanc
     if (!s || !ms_out || instances < 1) return fail(KZG_BADARGS, "bad argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    Fp *d_in, *d_out;
-    unsigned long long* d_clk;
-    HIPCHK(hipMalloc(&d_in, sizeof(Fp) * 6 * instances));
-    HIPCHK(hipMalloc(&d_out, sizeof(Fp) * 6 * instances));
-    HIPCHK(hipMalloc(&d_clk, 16));
+    DevTmp t_in, t_out, t_clk;
+    HIPCHK(hipMalloc(&t_in.p, sizeof(Fp) * 6 * instances));
+    HIPCHK(hipMalloc(&t_out.p, sizeof(Fp) * 6 * instances));
+    HIPCHK(hipMalloc(&t_clk.p, 16));
+    Fp *d_in = t_in.as<Fp>(), *d_out = t_out.as<Fp>();
+    unsigned long long* d_clk = t_clk.as<unsigned long long>();
     HIPCHK(hipMemset(d_in, 0, sizeof(Fp) * 6 * instances));
     KzgRet rc = run_program(s->verify, d_in, s->d_prep, d_out, instances, s->s1);
     if (rc != KZG_OK) return rc;
@@ -54,7 +55,6 @@ extern "C" KzgRet kzg_debug_slp_bench(float* ms_out, float* mhz_out, int instanc
     HIPCHK(hipMemcpyAsync(h, d_clk, 16, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
     if (mhz_out) *mhz_out = h[1] ? (float)((double)h[0] / (double)h[1] * 100.0) : 0.f;
-    (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_clk);
     return KZG_OK;
 }
 

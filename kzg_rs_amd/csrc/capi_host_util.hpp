@@ -138,6 +138,20 @@ static void reverse32(uint8_t* dst, const uint8_t* src) {
     for (int i = 0; i < 32; i++) dst[i] = src[31 - i];
 }
 
+// a scratch device allocation of one call: released on every path out of the function (hipFree waits for the work that
+// may still use it)
+struct DevTmp {
+    void* p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp&) = delete;
+    DevTmp& operator=(const DevTmp&) = delete;
+    ~DevTmp() {
+        if (p) (void)hipFree(p);
+    }
+    template <class T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
 // Point arithmetic of the decode and MSM kernels: the radix-2^29 field (fp29.hpp) unless KZG_FP29=0 selects the 12x32
 // field (A/B measurement, cross-check).  Decides the table format (G1Jac29Mem / G1Jac) for the whole process.
 static bool fp29_enabled() {

@@ -91,12 +91,11 @@ extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const 
     HIPCHK(hipStreamSynchronize(s->s1));
     for (size_t i = 0; i < n; i++) status_out[i] = (uint8_t)st[i];
     if (xy_out) {
-        uint8_t* d_xy;
-        HIPCHK(hipMalloc(&d_xy, 96 * n));
-        hipLaunchKernelGGL(k_aff_to_bytes, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_points, d_xy, (int)n);
-        HIPCHK(hipMemcpyAsync(xy_out, d_xy, 96 * n, hipMemcpyDeviceToHost, s->s1));
+        DevTmp xy;
+        HIPCHK(hipMalloc(&xy.p, 96 * n));
+        hipLaunchKernelGGL(k_aff_to_bytes, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_points, xy.as<uint8_t>(), (int)n);
+        HIPCHK(hipMemcpyAsync(xy_out, xy.p, 96 * n, hipMemcpyDeviceToHost, s->s1));
         HIPCHK(hipStreamSynchronize(s->s1));
-        HIPCHK(hipFree(d_xy));
     }
     return KZG_OK;
 }
@@ -132,9 +131,10 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
             if (st[i] == G1_INVALID) return fail(KZG_BADARGS, "invalid G1 point");
     }
     // the tables are made in the 12x32 form (the points are already decoded), then converted to the window kernel's format
-    G1Jac* d_std = nullptr;
+    DevTmp std_tab;
     if (n) {
-        if (fp29_enabled()) HIPCHK(hipMalloc(&d_std, sizeof(G1Jac) * MSM_CHUNKS * (size_t)mt));
+        if (fp29_enabled()) HIPCHK(hipMalloc(&std_tab.p, sizeof(G1Jac) * MSM_CHUNKS * (size_t)mt));
+        G1Jac* d_std = std_tab.as<G1Jac>();
         G1Jac* tab = fp29_enabled() ? d_std : (G1Jac*)w.d_mult;
         hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_points, w.d_pflag, tab, (int)n, mt, MSM_CHUNKS);
         if (fp29_enabled())
@@ -168,7 +168,6 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, w.d_bytes, 48, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
-    if (d_std) (void)hipFree(d_std);
     elapsed(&s->timings[2], s->ev[2], s->ev[3]);
     return KZG_OK;
 }
@@ -186,17 +185,16 @@ extern "C" KzgRet kzg_g1_mul_generator(uint8_t* out48, const uint8_t* scalars, s
         while (be_geq_r(t)) be_sub_r(t);
         reverse32(le.data() + 32 * i, t);
     }
-    Fr* d_s;
-    uint8_t* d_o;
-    HIPCHK(hipMalloc(&d_s, 32 * n));
-    HIPCHK(hipMalloc(&d_o, 48 * n));
+    DevTmp ts, to;
+    HIPCHK(hipMalloc(&ts.p, 32 * n));
+    HIPCHK(hipMalloc(&to.p, 48 * n));
+    Fr* d_s = ts.as<Fr>();
+    uint8_t* d_o = to.as<uint8_t>();
     HIPCHK(hipMemcpyAsync(d_s, le.data(), 32 * n, hipMemcpyHostToDevice, s->s1));
     hipLaunchKernelGGL(k_g1_mul_generator, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, d_s, d_o, (int)n);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out48, d_o, 48 * n, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
-    HIPCHK(hipFree(d_s));
-    HIPCHK(hipFree(d_o));
     return KZG_OK;
 }
 
