@@ -261,6 +261,10 @@ def main():
                      "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                      "traffic": traffic, "traffic_source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH x2 gfx950 correction)",
                      "algorithmic_bytes_per_launch": ALG_BYTES[dom] * units,
+                     "launch_ms_source": ("the kernel's own execution interval, stamped inside the kernel with s_memrealtime and averaged over "
+                                          "the launch groups of the timed region (agrees with rocprofv3 --stats of this command, profiles/"
+                                          + PMC_FILE.replace("pmc.json", "kernel_stats.csv") + ")") if dom == "k_blob_challenge" else
+                                         "HIP events on the kernel's stream (includes waiting behind the other launch groups' kernels)",
                      "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 5)"},
         "valu": valu,
         "kernel_ms_per_launch_group": {k: round(v, 4) for k, v in kernels.items()},

@@ -23,6 +23,8 @@ struct Workspace {
     G1Aff* d_points = nullptr;
     G1Jac *d_window = nullptr, *d_window_sl = nullptr, *d_ab = nullptr, *d_parts = nullptr;
     void* d_mult = nullptr;  // MSM tables: G1Jac29Mem / G1Aff29Mem / G1Jac entries (fp29_enabled(), msm_affine_enabled())
+    unsigned long long* d_ktime = nullptr;  // execution interval of the last throughput-form challenge kernel (fr_kernels.hpp)
+    bool ktime_valid = false;
     G1Jac29Mem* d_jtmp = nullptr;  // 2^64 P of every decoded point on its way to the affine table (k_mult_to_affine29)
     bool mult_affine = false;      // format of d_mult as the last decode left it
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
@@ -316,7 +318,7 @@ extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_
 
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
-                    w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_mult, w.d_jtmp, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
+                    w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_mult, w.d_jtmp, w.d_ktime, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
                     w.d_records};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);

@@ -92,10 +92,15 @@ __device__ __forceinline__ void bswap4(uint32_t* w, const uint4& q) {
 // SIMDs, while single-wave workgroups are placed with no regard for balance - the same kernel launched as 1024
 // workgroups of 64 threads ran 1.8x slower (10.3 ms against 5.6 ms for 65 536 blobs) with two waves sharing a SIMD
 // on some CUs and idle SIMDs on others.
+// ktime (optional): { max over waves of ~start, max of end } in ticks of the 100 MHz s_memrealtime counter - the kernel's
+// own execution interval, which a HIP-event pair around the launch cannot give while other launch groups share the chip
+// (the events also time the wait for free CUs).  Zeroed by the host before the launch.
 __global__ __launch_bounds__(256) void k_blob_challenge(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
-                                                       Fr* __restrict__ z_out, int n) {
+                                                       Fr* __restrict__ z_out, int n, unsigned long long* __restrict__ ktime) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const bool stamp = ktime && (threadIdx.x & 63) == 0;
+    if (stamp) atomicMax(&ktime[0], ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
     const uint4* blob = reinterpret_cast<const uint4*>(blobs + (size_t)i * BLOB_BYTES);
     const uint4* cm = reinterpret_cast<const uint4*>(commitments + (size_t)i * 48);
     Sha256State st;
@@ -145,6 +150,7 @@ __global__ __launch_bounds__(256) void k_blob_challenge(const uint8_t* __restric
 #pragma unroll
     for (int k = 0; k < 8; k++) d.l[k] = st.h[7 - k];
     z_out[i] = FrF::from_mont(FrF::to_mont(d));
+    if (stamp) atomicMax(&ktime[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 // ---------------------------------------------------------------- challenge, producer / consumer form
