@@ -228,7 +228,7 @@ def main():
         pk = pmc["kernels"].get(PMC_NAME[dom])
         if pk and "hbm_bytes_corrected" in pk:
             traffic = round(pk["hbm_bytes_corrected"] * units / pmc["blobs_per_launch"])
-        path = list(PMC_NAME.values()) + ["kzg::k_msm_combine", "kzg::k_batch_scalars", "kzg::k_glv_split", "kzg::k_mult_to_affine29",
+        path = list(PMC_NAME.values()) + ["kzg::k_msm_combine", "kzg::k_msm_combine_lanes", "kzg::k_batch_scalars", "kzg::k_glv_split", "kzg::k_mult_to_affine29",
                                            "kzg::k_eval_powers", "kzg::k_eval_finish"]
         insts = sum(pmc["kernels"][k].get("SQ_INSTS_VALU", 0) for k in path if k in pmc["kernels"])
         per_blob = insts / pmc["blobs_per_launch"]  # wave-instructions per blob, all kernels of the path

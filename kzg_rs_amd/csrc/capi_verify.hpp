@@ -161,7 +161,10 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     else hipLaunchKernelGGL(k_msm_window<Curve32>, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
     if (S > 1)
         hipLaunchKernelGGL(k_msm_fold_slices, dim3((unsigned)(2 * B * slots * W)), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, (int)W);
-    hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(2 * B)), dim3(64), 0, s->s1, w.d_window, w.d_ab, (int)slots, (int)W);
+    if (2 * B >= 64)  // enough outputs to fill wavefronts with one lane each
+        hipLaunchKernelGGL(k_msm_combine_lanes, dim3((unsigned)((2 * B + 63) / 64)), dim3(64), 0, s->s1, w.d_window, w.d_ab, (int)slots, (int)W, (int)(2 * B));
+    else
+        hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)(2 * B)), dim3(64), 0, s->s1, w.d_window, w.d_ab, (int)slots, (int)W);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
     return KZG_OK;

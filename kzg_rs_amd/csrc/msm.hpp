@@ -613,4 +613,22 @@ __global__ __launch_bounds__(64) void k_msm_combine(const G1Jac* __restrict__ wi
     out[o] = acc;
 }
 
+// The same sum with ONE LANE per output, for launches with many outputs (a launch group of batches): the Horner chain
+// is serial either way, and a workgroup per output spends a whole wavefront's issue slots on its single busy lane.
+__global__ __launch_bounds__(64) void k_msm_combine_lanes(const G1Jac* __restrict__ window_sums, G1Jac* __restrict__ out, int nslots, int W,
+                                                          int nout) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nout) return;
+    const G1Jac* S = window_sums + (size_t)o * nslots * W;  // slot (g, w) at index g * W + w
+    G1Jac acc = g1_identity();
+#pragma unroll 1
+    for (int w = W - 1; w >= 0; w--) {
+        if (w != W - 1)
+            for (int k = 0; k < MSM_C; k++) acc = g1_dbl(acc);
+#pragma unroll 1
+        for (int g = 0; g < nslots; g++) acc = g1_add(acc, S[g * W + w]);
+    }
+    out[o] = acc;
+}
+
 }  // namespace kzg
