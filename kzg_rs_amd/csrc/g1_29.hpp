@@ -6,22 +6,16 @@
 #pragma once
 #include "fp29.hpp"
 #include "g1.hpp"
+#include "g1_29_formulas.hpp"
 
 namespace kzg {
 
-struct G1Jac29 {
-    Fp29 x, y, z;  // Jacobian, lazy values; z = 0 mod p <=> infinity
-};
 // the table entry in global memory: coordinates padded to 64 bytes (b128 loads)
 struct alignas(16) Fp29Mem {
     uint32_t l[16];
 };
 struct G1Jac29Mem {
     Fp29Mem x, y, z;
-};
-// an affine table entry (never the identity: the MSM skips flagged points before it looks at their entries)
-struct G1Aff29 {
-    Fp29 x, y;
 };
 struct G1Aff29Mem {
     Fp29Mem x, y;
@@ -91,99 +85,6 @@ __device__ __forceinline__ G1Jac g1j29_to_std(const G1Jac29& p) {
     if (FpF::is_zero(r.z)) return g1_identity();
     r.x = fp29_to_std(p.x);
     r.y = fp29_to_std(p.y);
-    return r;
-}
-
-__device__ __forceinline__ G1Jac29 g1j29_identity() {
-    G1Jac29 r;
-    r.x = fp29_zero();
-    r.y = fp29_const(cp29::FP29_ONE);
-    r.z = fp29_zero();
-    return r;
-}
-
-// dbl-2009-l (a = 0): 2M + 5S.  Inputs below 2^10 p; outputs X < 130p, Y < 34p, Z < 4p.  Z = 0 mod p stays so.
-// The linear steps are taken limb-wise on un-normalised words and carried ONCE per result (8 carry passes instead of
-// 14): every intermediate word stays below 2^32 by the bounds noted, the biases are 16p / 128p with limbs boosted by
-// 2^31 / 2^30 so that no limb borrows (tools/gen_constants.py).
-__device__ __forceinline__ G1Jac29 g1j29_dbl(const G1Jac29& p) {
-    const Fp29 A = fp29_sqr(p.x), B = fp29_sqr(p.y), C = fp29_sqr(B);  // < 2p, limbs < 2^29
-    const Fp29 t = fp29_sqr(fp29_add(p.x, B));                          // < 2p
-    Fp29 D, E, X, C8;
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        D.l[i] = ((t.l[i] - A.l[i] - C.l[i]) << 1) + cp29::FP29_BIASX4[i];  // 2t + 16p - 2A - 2C: words < 2^30 + 2^29 + 2^31
-        E.l[i] = (A.l[i] << 1) + A.l[i];                                   // 3A: words < 2^31
-        C8.l[i] = C.l[i] << 3;                                             // 8C: words < 2^32
-    }
-    D = fp29_normalize(D);    // < 20p
-    E = fp29_normalize(E);    // < 6p
-    C8 = fp29_normalize(C8);  // < 16p
-    const Fp29 F = fp29_sqr(E);  // < 2p
-#pragma unroll
-    for (int i = 0; i < 14; i++) X.l[i] = F.l[i] + cp29::FP29_BIASW7[i] - (D.l[i] << 1);  // F + 128p - 2D: words < 2^31
-    G1Jac29 r;
-    r.x = fp29_normalize(X);                                            // < 130p
-    r.z = fp29_dbl(fp29_mul(p.y, p.z));                                 // < 4p
-    r.y = fp29_sub<5>(fp29_mul(E, fp29_sub<9>(D, r.x)), C8);            // E (D + 512p - X3) + 32p - 8C < 34p
-    return r;
-}
-
-// general addition with every special case (identity operands, P + P, P - P).  Inputs below 2^10 p;
-// outputs X < 14p, Y < 6p, Z < 2p (or a dbl / operand passed through).
-__device__ __forceinline__ G1Jac29 g1j29_add(const G1Jac29& p, const G1Jac29& q) {
-    const Fp29 Z1Z1 = fp29_sqr(p.z), Z2Z2 = fp29_sqr(q.z);
-    if (fp29_is_zero_mod_p(Z1Z1)) return q;
-    if (fp29_is_zero_mod_p(Z2Z2)) return p;
-    const Fp29 U1 = fp29_mul(p.x, Z2Z2), U2 = fp29_mul(q.x, Z1Z1);
-    const Fp29 S1 = fp29_mul(fp29_mul(p.y, q.z), Z2Z2), S2 = fp29_mul(fp29_mul(q.y, p.z), Z1Z1);
-    const Fp29 H = fp29_sub<2>(U2, U1), Rr = fp29_sub<2>(S2, S1);  // < 6p
-    const Fp29 HH = fp29_sqr(H), RR = fp29_sqr(Rr);
-    if (fp29_is_zero_mod_p(HH)) {
-        if (fp29_is_zero_mod_p(RR)) return g1j29_dbl(p);
-        return g1j29_identity();
-    }
-    const Fp29 HHH = fp29_mul(H, HH), V = fp29_mul(U1, HH);
-    G1Jac29 r;
-    r.x = fp29_sub<3>(fp29_sub<2>(RR, HHH), fp29_dbl(V));                             // RR + 4p - HHH + 8p - 2V < 14p
-    r.y = fp29_sub<2>(fp29_mul(Rr, fp29_sub<5>(V, r.x)), fp29_mul(S1, HHH));          // < 6p
-    r.z = fp29_mul(fp29_mul(p.z, q.z), H);                                            // < 2p
-    return r;
-}
-
-// mixed addition p + q, q affine and not the identity: 8M + 3S instead of 12M + 4S (madd-2007-bl without the
-// doubling tricks).  p below X < 256p, Y < 256p, Z < 2^10 p (every output of dbl / add / this function is); q below 8p.
-// Outputs X < 14p, Y < 6p, Z < 2p (or a dbl / q passed through).
-__device__ __forceinline__ G1Jac29 g1j29_add_affine(const G1Jac29& p, const G1Aff29& q) {
-    const Fp29 Z1Z1 = fp29_sqr(p.z);
-    if (fp29_is_zero_mod_p(Z1Z1)) {
-        G1Jac29 r;
-        r.x = q.x;
-        r.y = q.y;
-        r.z = fp29_const(cp29::FP29_ONE);
-        return r;
-    }
-    const Fp29 U2 = fp29_mul(q.x, Z1Z1), S2 = fp29_mul(fp29_mul(q.y, p.z), Z1Z1);
-    const Fp29 H = fp29_sub<9>(U2, p.x), Rr = fp29_sub<9>(S2, p.y);  // < 514p
-    const Fp29 HH = fp29_sqr(H), RR = fp29_sqr(Rr);
-    if (fp29_is_zero_mod_p(HH)) {
-        if (fp29_is_zero_mod_p(RR)) return g1j29_dbl(p);
-        return g1j29_identity();
-    }
-    const Fp29 HHH = fp29_mul(H, HH), V = fp29_mul(p.x, HH);
-    G1Jac29 r;
-    r.x = fp29_sub<3>(fp29_sub<2>(RR, HHH), fp29_dbl(V));                             // < 14p
-    r.y = fp29_sub<2>(fp29_mul(Rr, fp29_sub<5>(V, r.x)), fp29_mul(p.y, HHH));         // < 6p
-    r.z = fp29_mul(p.z, H);                                                           // < 2p
-    return r;
-}
-
-// -phi(P) = (beta x, -y, z); y below 64p in, below 128p out
-__device__ __forceinline__ G1Jac29 g1j29_neg_phi(const G1Jac29& p) {
-    G1Jac29 r;
-    r.x = fp29_mul(p.x, fp29_const(cp29::FP29_BETA_MONT));
-    r.y = fp29_neg<7>(p.y);
-    r.z = p.z;
     return r;
 }
 

@@ -1,0 +1,18 @@
+// Host build of kzg_rs_amd/csrc/g1_29_formulas.hpp for tests/test_g1_29_host.py (no GPU needed: the header is plain C++).
+// A point crosses the boundary as 42 words: x, y, z with 14 limbs each (28 words for an affine one).
+#include "g1_29_formulas.hpp"
+using namespace kzg;
+static Fp29 ld(const uint32_t* p) { Fp29 r; for (int i = 0; i < 14; i++) r.l[i] = p[i]; return r; }
+static void st(uint32_t* p, const Fp29& a) { for (int i = 0; i < 14; i++) p[i] = a.l[i]; }
+static G1Jac29 ldj(const uint32_t* p) { G1Jac29 r; r.x = ld(p); r.y = ld(p + 14); r.z = ld(p + 28); return r; }
+static void stj(uint32_t* p, const G1Jac29& a) { st(p, a.x); st(p + 14, a.y); st(p + 28, a.z); }
+extern "C" {
+void h_g1_dbl(uint32_t* o, const uint32_t* p) { stj(o, g1j29_dbl(ldj(p))); }
+void h_g1_add(uint32_t* o, const uint32_t* p, const uint32_t* q) { stj(o, g1j29_add(ldj(p), ldj(q))); }
+void h_g1_add_affine(uint32_t* o, const uint32_t* p, const uint32_t* q) {
+    G1Aff29 a; a.x = ld(q); a.y = ld(q + 14);
+    stj(o, g1j29_add_affine(ldj(p), a));
+}
+void h_g1_neg_phi(uint32_t* o, const uint32_t* p) { stj(o, g1j29_neg_phi(ldj(p))); }
+void h_g1_identity(uint32_t* o) { stj(o, g1j29_identity()); }
+}
