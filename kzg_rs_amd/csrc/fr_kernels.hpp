@@ -471,8 +471,8 @@ __global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restr
     const int blob_idx = blockIdx.x * EVAL_BLOBS_PER_BLOCK + wave;
     const bool active = blob_idx < T;
     __shared__ Fr29 Zs[EVAL_BLOBS_PER_BLOCK][14];              // Z[L] = z^(2^L) R'; Z[13] = z R'^2 (takes plain operands)
-    __shared__ uint4 stack_as[EVAL_BLOBS_PER_BLOCK][5][64], stack_bs[EVAL_BLOBS_PER_BLOCK][5][64];  // levels 1..5, limbs 0..3 / 4..7, lane-major: conflict-free b128
-    __shared__ uint32_t stack_cs[EVAL_BLOBS_PER_BLOCK][5][64];                                      // limb 8
+    __shared__ uint4 stack_as[EVAL_BLOBS_PER_BLOCK][4][64], stack_bs[EVAL_BLOBS_PER_BLOCK][4][64];  // levels 2..5, limbs 0..3 / 4..7, lane-major: conflict-free b128
+    __shared__ uint32_t stack_cs[EVAL_BLOBS_PER_BLOCK][4][64];                                      // limb 8
     Fr29* Z = Zs[wave];
     uint4 (*stack_a)[64] = stack_as[wave], (*stack_b)[64] = stack_bs[wave];
     uint32_t (*stack_c)[64] = stack_cs[wave];
@@ -485,44 +485,60 @@ __global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restr
     Fr29 n, psum;  // psum: this lane's share of S = sum_i p_i (plain integer, < 64 r)
 #pragma unroll
     for (int i = 0; i < 9; i++) psum.l[i] = 0;
-    // Software pipelining: the blob words and the leaf entry of pair q + 1 and the root entry of the next merge are
-    // requested one product ahead of their use (three waves per SIMD do not hide an L2 / HBM round trip by themselves).
-    uint4 a_hi = src[0], a_lo = src[1], b_hi = src[2], b_lo = src[3];
-    Fr29 leaf = eval_table_load(tab, 0, lane);
-    for (int q = 0; q < 32; q++) {
-        const int qn = q < 31 ? q + 1 : 31;
-        const uint4 na_hi = src[4 * qn], na_lo = src[4 * qn + 1], nb_hi = src[4 * qn + 2], nb_lo = src[4 * qn + 3];
-        const Fr29 leaf_next = eval_table_load(tab, qn, lane);
-        Fr29 root = eval_table_load(tab, 32 + (q >> 1), lane);  // level-1 merge of this pair (used when q is odd)
+    // One iteration = one 128-byte line of the blob = four elements = two leaf pairs and their level-1 merge, all in
+    // registers (a lane that fetched the two halves of a line in different iterations had them evicted in between:
+    // 1.6x the blob in HBM reads).  Software pipelining: the next line, the two leaf entries of the next iteration and
+    // the root entry of the next merge are requested one product ahead of their use (three waves per SIMD do not hide an
+    // L2 / HBM round trip by themselves).
+    uint4 cur[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cur[i] = src[i];
+    Fr29 leaf0 = eval_table_load(tab, 0, lane), leaf1 = eval_table_load(tab, 1, lane);
+    auto leaf_pair = [&](const uint4& a_hi, const uint4& a_lo, const uint4& b_hi, const uint4& b_lo, const Fr29& w) {
         Fr wa = fr_from_be_words(a_hi, a_lo), wb = fr_from_be_words(b_hi, b_lo);
         // canonical check (>= r -> BadArgs): the full 8-limb compare only when some lane's top word reaches r's
         if (__any((wa.l[7] >= consts::FR_MOD[7]) | (wb.l[7] >= consts::FR_MOD[7]))) bad |= FrF::geq_mod(wa) | FrF::geq_mod(wb);
         const Fr29 pa = fr29_from_words(wa.l), pb = fr29_from_words(wb.l);
         const Fr29 s = fr29_add(pa, pb), u = fr29_sub_biased4(pa, pb);
         psum = fr29_add(psum, s);
-        if (q & 1) psum = fr29_normalize(psum);  // limbs: 2^29 + 2 * 2^30 < 2^32 between normalisations
-        n = fr29_mul2(s, zd, u, leaf);  // z s + roots[2k] u, k = 32 lane + q: ONE reduction (fr29.hpp)
-        int level = 1;
-        for (int qq = q; qq & 1; qq >>= 1) {
+        return fr29_mul2(s, zd, u, w);  // z s + roots[2k] u, k = 32 lane + q: ONE reduction (fr29.hpp)
+    };
+    for (int j = 0; j < 16; j++) {  // pairs q = 2j, 2j + 1
+        const int jn = j < 15 ? j + 1 : 15;
+        uint4 nxt[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) nxt[i] = src[8 * jn + i];
+        const Fr29 leaf0_next = eval_table_load(tab, 2 * jn, lane), leaf1_next = eval_table_load(tab, 2 * jn + 1, lane);
+        Fr29 root = eval_table_load(tab, 32 + j, lane);  // the level-1 merge of the two pairs
+        const Fr29 n0 = leaf_pair(cur[0], cur[1], cur[2], cur[3], leaf0);
+        Fr29 root_next = root;
+        if (j & 1) root_next = eval_table_load(tab, 48 + (j >> 1), lane);  // a level-2 merge follows
+        const Fr29 n1 = leaf_pair(cur[4], cur[5], cur[6], cur[7], leaf1);
+        psum = fr29_normalize(psum);  // limbs: 2^29 + 2 * 2^30 < 2^32 between normalisations
+        n = fr29_mul2(fr29_add(n0, n1), Z[1], fr29_sub_biased4(n0, n1), root);
+        root = root_next;
+        int level = 2;  // level of the merge that may follow: node index at level L is (32 lane + 2j + 1) >> L
+        for (int jj = j; jj & 1; jj >>= 1) {
             Fr29 na;
-            const uint4 h0 = stack_a[level - 1][lane], h1 = stack_b[level - 1][lane];
+            const uint4 h0 = stack_a[level - 2][lane], h1 = stack_b[level - 2][lane];
             na.l[0] = h0.x; na.l[1] = h0.y; na.l[2] = h0.z; na.l[3] = h0.w;
             na.l[4] = h1.x; na.l[5] = h1.y; na.l[6] = h1.z; na.l[7] = h1.w;
-            na.l[8] = stack_c[level - 1][lane];
-            Fr29 root_next = root;
-            if (qq & 2) root_next = eval_table_load(tab, 64 - (32 >> level) + (q >> (level + 1)), lane);  // the merge one level up follows
+            na.l[8] = stack_c[level - 2][lane];
+            if (jj & 2) root_next = eval_table_load(tab, 64 - (32 >> level) + (j >> level), lane);  // the merge one level up follows
             const Fr29 sum = fr29_add(na, n), dif = fr29_sub_biased4(na, n);
             n = fr29_mul2(sum, Z[level], dif, root);
             root = root_next;
             level++;
         }
-        if (q != 31) {  // level <= 5 here
-            stack_a[level - 1][lane] = make_uint4(n.l[0], n.l[1], n.l[2], n.l[3]);
-            stack_b[level - 1][lane] = make_uint4(n.l[4], n.l[5], n.l[6], n.l[7]);
-            stack_c[level - 1][lane] = n.l[8];
+        if (j != 15) {  // level <= 5 here
+            stack_a[level - 2][lane] = make_uint4(n.l[0], n.l[1], n.l[2], n.l[3]);
+            stack_b[level - 2][lane] = make_uint4(n.l[4], n.l[5], n.l[6], n.l[7]);
+            stack_c[level - 2][lane] = n.l[8];
         }
-        a_hi = na_hi; a_lo = na_lo; b_hi = nb_hi; b_lo = nb_lo;
-        leaf = leaf_next;
+#pragma unroll
+        for (int i = 0; i < 8; i++) cur[i] = nxt[i];
+        leaf0 = leaf0_next;
+        leaf1 = leaf1_next;
     }
     // n = N0_{6,lane}; fold across lanes
     for (int L = 6; L < 12; L++) {
