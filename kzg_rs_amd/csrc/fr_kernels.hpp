@@ -123,17 +123,23 @@ __global__ __launch_bounds__(256) void k_blob_challenge(const uint8_t* __restric
         const uint4 n2 = L[2], n3 = L[3], n4 = L[4], n5 = L[5];
         c0 = L[6];
         c1 = L[7];
-        if (m + 1 < 1024) {  // the next line, in flight during the two compressions below
-            const uint4* p = blob + 8 * (m + 1);
+        {  // the next line, in flight during the two compressions below (the last iteration re-reads its own line: no
+           // branch in the loop, so the compiler's wait counters stay exact - a two-way merge here made every iteration
+           // wait for three of the loads it had just issued)
+            const uint4* p = blob + 8 * (m + 1 < 1024 ? m + 1 : 1023);
 #pragma unroll
             for (int j = 0; j < 8; j++) L[j] = p[j];
-        } else {
-            L[0] = cm[0]; L[1] = cm[1]; L[2] = cm[2];
+            // all eight loads of the line issue HERE: left alone, the scheduler sinks three of them ~3 000 cycles into the
+            // first compression, by when the line may have left the L2 again (HBM reads were 1.20x the blob bytes)
+            __builtin_amdgcn_sched_barrier(0x7);  // ALU instructions may cross, memory instructions may not
         }
         sha256_compress(st, w);  // block 2m
         bswap4(w, n2); bswap4(w + 4, n3); bswap4(w + 8, n4); bswap4(w + 12, n5);
         sha256_compress(st, w);  // block 2m + 1
     }
+    L[0] = cm[0];
+    L[1] = cm[1];
+    L[2] = cm[2];
     {
         uint32_t w[16];
         bswap4(w, c0); bswap4(w + 4, c1); bswap4(w + 8, L[0]); bswap4(w + 12, L[1]);  // block 2048: blob tail | commitment[0..32)
@@ -464,8 +470,10 @@ __global__ __launch_bounds__(64) void k_eval_finish(const uint32_t* __restrict__
 }
 
 // One wavefront per blob, four blobs per workgroup (single-wave workgroups are not spread evenly over the SIMDs).
+// Register budget of two waves per SIMD (192 VGPRs used): with 168 the allocator reuses the prefetch registers and the
+// wait counters turn the prefetches into stalls - three waves per SIMD were 2 % slower than two with working prefetches.
 constexpr int EVAL_BLOBS_PER_BLOCK = 4;
-__global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restrict__ blobs, const EvalTables tab,
+__global__ __launch_bounds__(256, 2) void k_blob_evaluate(const uint8_t* __restrict__ blobs, const EvalTables tab,
                                                        uint32_t* __restrict__ scratch, uint32_t* __restrict__ status, int T) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int blob_idx = blockIdx.x * EVAL_BLOBS_PER_BLOCK + wave;
@@ -505,14 +513,17 @@ __global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restr
     };
     for (int j = 0; j < 16; j++) {  // pairs q = 2j, 2j + 1
         const int jn = j < 15 ? j + 1 : 15;
+        // Loads complete in issue order (one vmcnt counter): what this iteration needs is requested first, what the next
+        // one needs last, and no load sits in a branch (a control-flow merge makes the wait counters conservative).
+        Fr29 root = eval_table_load(tab, 32 + j, lane);             // the level-1 merge of the two pairs
+        Fr29 root_next = eval_table_load(tab, 48 + (j >> 1), lane);  // the level-2 merge that follows when j is odd
+        __builtin_amdgcn_sched_barrier(0x7);
         uint4 nxt[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) nxt[i] = src[8 * jn + i];
         const Fr29 leaf0_next = eval_table_load(tab, 2 * jn, lane), leaf1_next = eval_table_load(tab, 2 * jn + 1, lane);
-        Fr29 root = eval_table_load(tab, 32 + j, lane);  // the level-1 merge of the two pairs
+        __builtin_amdgcn_sched_barrier(0x7);
         const Fr29 n0 = leaf_pair(cur[0], cur[1], cur[2], cur[3], leaf0);
-        Fr29 root_next = root;
-        if (j & 1) root_next = eval_table_load(tab, 48 + (j >> 1), lane);  // a level-2 merge follows
         const Fr29 n1 = leaf_pair(cur[4], cur[5], cur[6], cur[7], leaf1);
         psum = fr29_normalize(psum);  // limbs: 2^29 + 2 * 2^30 < 2^32 between normalisations
         n = fr29_mul2(fr29_add(n0, n1), Z[1], fr29_sub_biased4(n0, n1), root);
@@ -524,7 +535,7 @@ __global__ __launch_bounds__(256, 3) void k_blob_evaluate(const uint8_t* __restr
             na.l[0] = h0.x; na.l[1] = h0.y; na.l[2] = h0.z; na.l[3] = h0.w;
             na.l[4] = h1.x; na.l[5] = h1.y; na.l[6] = h1.z; na.l[7] = h1.w;
             na.l[8] = stack_c[level - 2][lane];
-            if (jj & 2) root_next = eval_table_load(tab, 64 - (32 >> level) + (j >> level), lane);  // the merge one level up follows
+            root_next = eval_table_load(tab, 64 - (32 >> level) + (j >> level), lane);  // for the merge one level up, if it follows (always a valid slot)
             const Fr29 sum = fr29_add(na, n), dif = fr29_sub_biased4(na, n);
             n = fr29_mul2(sum, Z[level], dif, root);
             root = root_next;
