@@ -185,7 +185,8 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
     if (w.mult_affine) {
         // affine tables: rows 0 and 2 straight from the decode pass, rows 1 and 3 from 2^64 P through one inversion per 16 points
         G1Aff29Mem* mult = (G1Aff29Mem*)w.d_mult;
-        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, true>), dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, w.d_jtmp, n2, np);
+        // 256-thread workgroups: their four waves are dealt one to each SIMD of a CU (single-wave workgroups are placed unevenly)
+        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, true>), dim3((unsigned)((2 * T + 255) / 256)), dim3(256), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, w.d_jtmp, n2, np);
         const unsigned conv_blocks = (unsigned)((n2 + 64 * AFFINE_BATCH - 1) / (64 * AFFINE_BATCH));
         hipLaunchKernelGGL(k_mult_to_affine29, dim3(conv_blocks), dim3(64), 0, s->s2, w.d_jtmp, w.d_pflag, mult, n2, np);
         HIPCHK(hipEventRecord(s->ev[10], s->s2));

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64, 2) void k_g1_decode_multiples(const uint8_t* __
 // Jacobian multiple 2^64 P goes to jtmp[i] and k_mult_to_affine29 below turns it into table rows 1 and 3, so that the
 // window kernel's bucket additions are mixed additions (8M + 3S instead of 12M + 4S).
 template <int CHUNKS, bool AFF>
-__global__ __launch_bounds__(64, KZG_DECODE_OCC) void k_g1_decode_multiples29(const uint8_t* __restrict__ bytes0, const uint8_t* __restrict__ bytes1,
+__global__ __launch_bounds__(256, KZG_DECODE_OCC) void k_g1_decode_multiples29(const uint8_t* __restrict__ bytes0, const uint8_t* __restrict__ bytes1,
                                                                  int n0, G1Aff* __restrict__ points, uint32_t* __restrict__ pflag,
                                                                  void* __restrict__ mult_, G1Jac29Mem* __restrict__ jtmp, int n, int stride) {
     static_assert(!AFF || CHUNKS == 4, "the affine layout has one Jacobian multiple per point");
