@@ -85,18 +85,22 @@ FP29_FN G1Jac29 g1j29_add_affine(const G1Jac29& p, const G1Aff29& q) {
         r.z = fp29_const(cp29::FP29_ONE);
         return r;
     }
+    // ordered so that every operand dies as early as it can (the bucket loop of the MSM window kernel is register-bound)
     const Fp29 U2 = fp29_mul(q.x, Z1Z1), S2 = fp29_mul(fp29_mul(q.y, p.z), Z1Z1);
-    const Fp29 H = fp29_sub<9>(U2, p.x), Rr = fp29_sub<9>(S2, p.y);  // < 514p
-    const Fp29 HH = fp29_sqr(H), RR = fp29_sqr(Rr);
-    if (fp29_is_zero_mod_p(HH)) {
-        if (fp29_is_zero_mod_p(RR)) return g1j29_dbl(p);
+    const Fp29 H = fp29_sub<9>(U2, p.x);  // < 514p
+    const Fp29 HH = fp29_sqr(H);
+    if (fp29_is_zero_mod_p(HH)) {  // same x: P + P or P - P
+        const Fp29 Rr = fp29_sub<9>(S2, p.y);
+        if (fp29_is_zero_mod_p(fp29_sqr(Rr))) return g1j29_dbl(p);
         return g1j29_identity();
     }
-    const Fp29 HHH = fp29_mul(H, HH), V = fp29_mul(p.x, HH);
     G1Jac29 r;
-    r.x = fp29_sub<3>(fp29_sub<2>(RR, HHH), fp29_dbl(V));                             // < 14p
-    r.y = fp29_sub<2>(fp29_mul(Rr, fp29_sub<5>(V, r.x)), fp29_mul(p.y, HHH));         // < 6p
     r.z = fp29_mul(p.z, H);                                                           // < 2p
+    const Fp29 HHH = fp29_mul(H, HH), V = fp29_mul(p.x, HH);
+    const Fp29 Rr = fp29_sub<9>(S2, p.y);                                             // < 514p
+    r.x = fp29_sub<3>(fp29_sub<2>(fp29_sqr(Rr), HHH), fp29_dbl(V));                   // < 14p
+    const Fp29 T = fp29_mul(p.y, HHH);
+    r.y = fp29_sub<2>(fp29_mul(Rr, fp29_sub<5>(V, r.x)), T);                          // < 6p
     return r;
 }
 
