@@ -57,19 +57,23 @@ FP29_FN G1Jac29 g1j29_add(const G1Jac29& p, const G1Jac29& q) {
     const Fp29 Z1Z1 = fp29_sqr(p.z), Z2Z2 = fp29_sqr(q.z);
     if (fp29_is_zero_mod_p(Z1Z1)) return q;
     if (fp29_is_zero_mod_p(Z2Z2)) return p;
-    const Fp29 U1 = fp29_mul(p.x, Z2Z2), U2 = fp29_mul(q.x, Z1Z1);
+    // ordered so that every operand dies as early as it can
+    const Fp29 U1 = fp29_mul(p.x, Z2Z2);
+    const Fp29 H = fp29_sub<2>(fp29_mul(q.x, Z1Z1), U1);  // < 6p
     const Fp29 S1 = fp29_mul(fp29_mul(p.y, q.z), Z2Z2), S2 = fp29_mul(fp29_mul(q.y, p.z), Z1Z1);
-    const Fp29 H = fp29_sub<2>(U2, U1), Rr = fp29_sub<2>(S2, S1);  // < 6p
-    const Fp29 HH = fp29_sqr(H), RR = fp29_sqr(Rr);
-    if (fp29_is_zero_mod_p(HH)) {
-        if (fp29_is_zero_mod_p(RR)) return g1j29_dbl(p);
+    const Fp29 HH = fp29_sqr(H);
+    if (fp29_is_zero_mod_p(HH)) {  // same x: P + P or P - P
+        const Fp29 Rr = fp29_sub<2>(S2, S1);
+        if (fp29_is_zero_mod_p(fp29_sqr(Rr))) return g1j29_dbl(p);
         return g1j29_identity();
     }
-    const Fp29 HHH = fp29_mul(H, HH), V = fp29_mul(U1, HH);
     G1Jac29 r;
-    r.x = fp29_sub<3>(fp29_sub<2>(RR, HHH), fp29_dbl(V));                             // RR + 4p - HHH + 8p - 2V < 14p
-    r.y = fp29_sub<2>(fp29_mul(Rr, fp29_sub<5>(V, r.x)), fp29_mul(S1, HHH));          // < 6p
     r.z = fp29_mul(fp29_mul(p.z, q.z), H);                                            // < 2p
+    const Fp29 HHH = fp29_mul(H, HH), V = fp29_mul(U1, HH);
+    const Fp29 Rr = fp29_sub<2>(S2, S1);                                              // < 6p
+    r.x = fp29_sub<3>(fp29_sub<2>(fp29_sqr(Rr), HHH), fp29_dbl(V));                   // RR + 4p - HHH + 8p - 2V < 14p
+    const Fp29 T = fp29_mul(S1, HHH);
+    r.y = fp29_sub<2>(fp29_mul(Rr, fp29_sub<5>(V, r.x)), T);                          // < 6p
     return r;
 }
 
