@@ -29,7 +29,9 @@ FP29_FN G1Jac29 g1j29_identity() {
 // 14): every intermediate word stays below 2^32 by the bounds noted, the biases are 16p / 128p with limbs boosted by
 // 2^31 / 2^30 so that no limb borrows (tools/gen_constants.py).
 FP29_FN G1Jac29 g1j29_dbl(const G1Jac29& p) {
-    const Fp29 A = fp29_sqr(p.x), B = fp29_sqr(p.y), C = fp29_sqr(B);  // < 2p, limbs < 2^29
+    G1Jac29 r;
+    r.z = fp29_dbl(fp29_mul(p.y, p.z));                                 // < 4p; first, so that p.z and then p.y die early
+    const Fp29 B = fp29_sqr(p.y), C = fp29_sqr(B), A = fp29_sqr(p.x);  // < 2p, limbs < 2^29
     const Fp29 t = fp29_sqr(fp29_add(p.x, B));                          // < 2p
     Fp29 D, E, X, C8;
 #pragma unroll
@@ -44,9 +46,7 @@ FP29_FN G1Jac29 g1j29_dbl(const G1Jac29& p) {
     const Fp29 F = fp29_sqr(E);  // < 2p
 #pragma unroll
     for (int i = 0; i < 14; i++) X.l[i] = F.l[i] + cp29::FP29_BIASW7[i] - (D.l[i] << 1);  // F + 128p - 2D: words < 2^31
-    G1Jac29 r;
     r.x = fp29_normalize(X);                                            // < 130p
-    r.z = fp29_dbl(fp29_mul(p.y, p.z));                                 // < 4p
     r.y = fp29_sub<5>(fp29_mul(E, fp29_sub<9>(D, r.x)), C8);            // E (D + 512p - X3) + 32p - 8C < 34p
     return r;
 }
