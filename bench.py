@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the north-star path: verify_blob_kzg_proof_batch on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--blobs 1024] [--group G] [--inflight F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|configs1|config5] [--blobs n] [--group G] [--inflight 3]
 
-One "step" = one verify_blob_kzg_proof_batch over a batch of `--blobs` synthetic blobs per GPU that are already
-resident in HBM (BASELINE.json configs[1]: 1 024 blobs of 4096 Fr per GPU).  Every step is a complete, independent
-verification (its own transcript, challenge r, MSMs and pairing; its own boolean).  At this batch size each phase
-is a latency-bound serial chain that occupies a sliver of the chip, so steps are issued in LAUNCH GROUPS of G
-independent batches (a batch dimension inside every kernel) and F groups are kept in flight by a fixed-order
-software pipeline on one host thread.  `--group 1 --inflight 1` gives strictly sequential single-batch steps; that
-latency is also measured and reported as `single_batch` in the same JSON line.
+One "step" = one LAUNCH GROUP: `--group` (256) independent verify_blob_kzg_proof_batch calls
+(src/kzg_proof.rs:472-525) of `--blobs` (1 024, BASELINE.json configs[1]) synthetic blobs each, all already resident
+in HBM - 262 144 blobs, 32 GiB of blob bytes per step and GPU.  Every batch of the group is a complete, independent
+verification (its own transcript, challenge r, MSMs and pairing; its own boolean).  At n = 1 024 each phase of ONE
+batch is a latency-bound serial chain that occupies a sliver of the chip, so the batch dimension lives inside every
+kernel, and `--inflight` groups are kept in flight by a fixed-order software pipeline on one host thread.
+The latency of ONE batch at a time (the reference's call shape) is measured too and reported as `single_batch`
+(device-resident) and `end_to_end` (host `Vec<Blob>` layout through kzg_verify_blob_kzg_proof_batch, PCIe included).
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every batch is N * blobs, sharded by blob, with the
-two small all-gathers of kzg_rs_amd/distributed.py (RCCL); per-GPU work is fixed, so scaling is "weak".
+With N > 1 (launched by torch.distributed.run, one rank per GPU over RCCL) the default workload is BASELINE.json
+configs[4]: every batch is 32 768 x N blobs sharded by blob (at N = 8: 262 144 blobs over 8 GPUs), 8 batches per step -
+the same 262 144 blobs = 32 GiB per GPU and step as at N = 1, so scaling is "weak".  Each batch's 160 n-byte transcript
+is hashed once (the batches of a step are dealt to the ranks), r travels as 32 bytes, and the "G1 all-reduce" is an
+all-gather of 288-byte partial sums folded on every rank (kzg_rs_amd/distributed.py).  `--workload configs1` keeps
+1 024 blobs per GPU and batch at any N; `--workload config5` (= `--config5`) runs the 32 768-blob shard shape on one GPU.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -35,7 +40,10 @@ ALG_BYTES = {
     "k_msm": 3 * 128,                               # three (point, scalar) terms per blob, 96 + 32 B each
     "k_slp_run(pairing)": 0,
 }
-PMC_FILE = "r1h_pmc.json"
+PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge", "k_blob_evaluate": "kzg::k_blob_evaluate",
+            "k_g1_decode_multiples": "kzg::k_g1_decode_multiples29<4, true>", "k_msm": "kzg::k_msm_window<kzg::Curve29Aff>",
+            "k_slp_run(pairing)": "kzg::k_slp_run<false>"}
+PMC_FILES = ("r2_pmc.json", "r1h_pmc.json")  # newest first; the first that exists is used
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
 
 
@@ -64,18 +72,33 @@ def cpu_baseline(blobs, cs, ps, tau_g2, max_blobs):
     }
 
 
+def load_pmc():
+    for name in PMC_FILES:
+        try:
+            return name, json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6144)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blobs", type=int, default=1024, help="blobs per GPU per step (batch)")
-    ap.add_argument("--group", type=int, default=256, help="independent batches per launch group (batch dimension inside the kernels)")
+    ap.add_argument("--steps", type=int, default=20, help="launch groups timed")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed launch groups (at least one per pipeline handle is always run)")
+    ap.add_argument("--workload", choices=["auto", "configs1", "config5"], default="auto",
+                    help="configs1: 1 024 blobs per GPU per batch, 256 batches per step; config5: 32 768 blobs per GPU per batch "
+                         "(BASELINE configs[4] at 8 GPUs), 8 batches per step; auto: configs1 on one GPU, config5 on several")
+    ap.add_argument("--config5", action="store_true", help="same as --workload config5")
+    ap.add_argument("--blobs", type=int, default=None, help="blobs per GPU per batch (overrides the workload's)")
+    ap.add_argument("--group", type=int, default=None, help="independent batches per launch group = per step (overrides the workload's)")
     ap.add_argument("--inflight", type=int, default=3, help="launch groups kept in flight by the fixed-order software pipeline")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single_batch / end_to_end legs (profiling runs)")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,17 +127,17 @@ def main():
     from kzg_rs_amd import api, synth
     from kzg_rs_amd.distributed import HipBackend, PipelinedVerifier, verify_blob_kzg_proof_batch_sharded
 
-    n, G, F = args.blobs, max(1, args.group), max(1, args.inflight)
-    blobs, cs, ps, settings = synth.make_valid_batch(n, seed=1000 + rank)
+    workload = "config5" if args.config5 else args.workload
+    if workload == "auto":
+        workload = "configs1" if world == 1 else "config5"
+    n = args.blobs or (1024 if workload == "configs1" else 32768)
+    G = max(1, args.group or (256 if workload == "configs1" else 8))
+    F = max(1, args.inflight)
+    blobs, cs, ps, settings = synth.make_valid_batch(n, seed=1000 + rank, chunk=1024)
     d_blobs = torch.from_numpy(blobs).to(dev)
     d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).to(dev)
     d_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).to(dev)
     torch.cuda.synchronize()
-    if os.environ.get("KZG_PMC_CALIBRATE") == "1":  # a 128 MiB device-to-device copy: the known-size dispatch that
-        cal = torch.empty_like(d_blobs)              # checks the FETCH_SIZE / WRITE_SIZE scaling in a PMC run
-        cal.copy_(d_blobs)
-        torch.cuda.synchronize()
-        del cal
     backend0 = HipBackend(settings)
 
     # ---- pipeline: depth (d1, d2, d3) groups between the phases; one handle (2 HIP streams + workspace) per group in flight
@@ -128,7 +151,8 @@ def main():
     handles = [settings] + [api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1]) for _ in range(n_handles - 1)]
     backends = [backend0] + [HipBackend(h) for h in handles[1:]]
     pipe = PipelinedVerifier(backends, dist, coll_dev, depth, equal_shards=True)
-    # every batch is a different permutation of the rank's shard (different transcript and r), at its own HBM address
+    # every batch is a different permutation of the rank's shard (different transcript and r), at its own HBM address:
+    # one variant (G x n blobs = G x 128 MiB) per handle, so the groups in flight stream disjoint memory
     gen = torch.Generator(device="cpu").manual_seed(7 + rank)
     c_t, p_t = d_c.view(n, 48), d_p.view(n, 48)
     variants = []
@@ -137,16 +161,19 @@ def main():
         variants.append((torch.cat([d_blobs[p] for p in perms]).contiguous(), torch.cat([c_t[p] for p in perms]).contiguous(),
                          torch.cat([p_t[p] for p in perms]).contiguous()))
     torch.cuda.synchronize()
+    if os.environ.get("KZG_PMC_CALIBRATE") == "1":
+        # a known-size dispatch for the FETCH_SIZE / WRITE_SIZE scaling check of a PMC run: an elementwise kernel (the
+        # only one of this name and grid in the process) that reads 128 MiB and writes 128 MiB
+        cal = d_blobs.view(torch.int32).add(1)
+        torch.cuda.synchronize()
+        del cal
 
-    def run_batches(k):
-        """k independent batches = ceil(k / G) launch groups (the last one possibly smaller)."""
-        groups, left, i = [], k, 0
-        while left > 0:
-            g = min(G, left)
+    def run_groups(k):
+        """k launch groups of G independent batches each through the pipeline."""
+        groups = []
+        for i in range(k):
             v = variants[i % n_handles]
-            groups.append(((v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), n), g))
-            left -= g
-            i += 1
+            groups.append(((v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), n), G))
         res = pipe.run(groups)
         if not all(all(r) for r in res):
             raise SystemExit("verification of a valid synthetic batch returned false")
@@ -169,110 +196,155 @@ def main():
             el = float(t.item())
         return el, out
 
-    if args.warmup:
-        run_batches(args.warmup * G)
+    # warm-up: every handle allocates its workspace and runs every kernel once before the timed region
+    W = max(args.warmup, n_handles) if args.warmup else 0
+    if W:
+        run_groups(W)
     K = args.steps
     for h in handles:
         h.timing_totals(reset=True)  # the warm-up groups do not count
-    elapsed, groups = timed(lambda: run_batches(K))
-    # kernel times: HIP events on the library's own streams, AVERAGED over every full launch group of the timed region
-    # (all handles) - the quantity rocprofv3 --stats reports as the kernel's average duration for the same command
+    elapsed, _ = timed(lambda: run_groups(K))
+    # kernel times: on the library's own streams, AVERAGED over every launch group of the timed region (all handles)
+    # - the quantity rocprofv3 --stats reports as the kernel's average duration for the same command
     sums, cnt = [0.0] * 8, 0
     for h in handles:
         t, c = h.timing_totals(reset=True)
         sums = [a + b for a, b in zip(sums, t)]
         cnt += c
     tm = [x / max(cnt, 1) for x in sums]
-    g0 = min(G, K)  # batches per launch group the averages refer to (a shorter last group is averaged in; K % G == 0 by default)
     kernels = {"k_blob_challenge": tm[5], "k_blob_evaluate": tm[4], "k_g1_decode_multiples": tm[6], "k_msm": tm[2],
                "k_slp_run(pairing)": tm[3]}
 
-    # ---- strictly sequential single-batch steps (latency), same inputs
-    def seq_steps(k):
-        for _ in range(k):
-            if world == 1:
-                ok = api.KzgProof.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, settings)
-            else:
-                ok = verify_blob_kzg_proof_batch_sharded((d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n), n, backend0, dist, coll_dev)
-            if not ok:
-                raise SystemExit("verification of a valid synthetic batch returned false")
+    # ---- ONE batch at a time (the reference's call shape): device-resident, then from host memory
+    single = end2end = None
+    if not args.no_latency:
+        stage_s = {}
 
-    seq_steps(2)
-    KS = 8
-    seq_elapsed, _ = timed(lambda: seq_steps(KS))
-    seq_tm = settings.last_timings()
+        def seq_steps(k, tm=None):
+            for _ in range(k):
+                if world == 1:
+                    ok = api.KzgProof.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, settings)
+                else:
+                    ok = verify_blob_kzg_proof_batch_sharded((d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n), n, backend0, dist, coll_dev, timings=tm)
+                if not ok:
+                    raise SystemExit("verification of a valid synthetic batch returned false")
+
+        seq_steps(2)
+        KS = 16 if n <= 4096 else 4
+        seq_elapsed, _ = timed(lambda: seq_steps(KS, stage_s))
+        seq_tm = settings.last_timings()
+        single = {"value": round(n * world * KS / seq_elapsed, 2), "unit": "blobs/s", "ms_per_step": round(seq_elapsed / KS * 1e3, 4),
+                  "steps": KS, "what": "one verify_blob_kzg_proof_batch call of %d device-resident blobs at a time%s"
+                                       % (n * world, "" if world == 1 else ", sharded by blob over %d ranks (transcript hashed once on rank 0)" % world),
+                  "stage_ms_rank0": {k[:-2] + "_ms": round(v / KS * 1e3, 4) for k, v in stage_s.items()} if world > 1 else None,
+                  "kernel_ms": {"k_blob_challenge": round(seq_tm[5], 4), "k_blob_evaluate": round(seq_tm[4], 4),
+                                "k_g1_decode_multiples": round(seq_tm[6], 4), "k_msm": round(seq_tm[2], 4),
+                                "k_slp_run(pairing)": round(seq_tm[3], 4)}}
+        if world == 1 and n <= 4096:
+            import ctypes as C
+
+            h_c, h_p = b"".join(cs), b"".join(ps)
+            h_blobs = np.ascontiguousarray(blobs)  # pageable host memory, exactly a Rust Vec<Blob>
+            ok = C.c_bool(False)
+
+            def host_steps(k):
+                for _ in range(k):
+                    api._chk(api.lib().kzg_verify_blob_kzg_proof_batch(C.byref(ok), h_blobs.ctypes.data_as(C.c_char_p), h_c, h_p, n, settings._h))
+                    if not ok.value:
+                        raise SystemExit("verification of a valid synthetic batch returned false")
+
+            host_steps(2)
+            KH = 16
+            h_elapsed, _ = timed(lambda: host_steps(KH))
+            end2end = {"value": round(n * KH / h_elapsed, 2), "unit": "blobs/s", "ms_per_step": round(h_elapsed / KH * 1e3, 4), "steps": KH,
+                       "source": "host Vec<Blob> layout (pageable memory) through kzg_verify_blob_kzg_proof_batch, one %d-blob batch at a "
+                                 "time, PCIe transfer included" % n}
     if rank != 0:
         if dist:
             dist.destroy_process_group()
         return
     # The dominant kernel.  With several launch groups in flight the event-to-event time of a kernel measures how long
-    # it SHARED the chip, not what it costs, so dominance is decided by the kernels' stand-alone cost recorded in the
-    # committed PMC profile (the largest VALU instruction count: the challenge kernel); its duration is still the live
-    # one, measured with HIP events on the library's own stream over the timed region.
-    PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge", "k_blob_evaluate": "kzg::k_blob_evaluate",
-                "k_g1_decode_multiples": "kzg::k_g1_decode_multiples29<4, true>", "k_msm": "kzg::k_msm_window<kzg::Curve29Aff>",
-                "k_slp_run(pairing)": "kzg::k_slp_run<false>"}
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
+    # it SHARED the chip, not what it costs, so dominance is decided by the kernels' stand-alone cost in the newest
+    # committed PMC profile (largest VALU instruction count); if that profile does not know this build's kernels the
+    # largest live interval decides.  The duration itself is always live: measured in this run on the library's stream.
+    pmc_file, pmc = load_pmc()
+    prof = (pmc or {}).get("kernels", {})
+    if all(PMC_NAME[k] in prof for k in ("k_blob_challenge", "k_blob_evaluate")):
         dom = max(kernels, key=lambda k: prof.get(PMC_NAME[k], {}).get("SQ_INSTS_VALU", 0))
-    except Exception:
+        dom_source = "largest SQ_INSTS_VALU in profiles/" + pmc_file
+    else:
         dom = max(kernels, key=kernels.get)
-    units = n * g0
+        dom_source = "largest live interval (no matching PMC profile)"
+    units = n * G
     achieved = ALG_BYTES[dom] * units / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
-    # HBM traffic of that kernel and the VALU instruction counts of all kernels, from the PMC passes committed under
-    # profiles/ (tools/prof/collect_round.sh; rocprofv3 --pmc cannot run inside this process): per launch of
-    # `blobs_per_launch` blobs, scaled to this launch's unit count
-    traffic, valu = None, None
+    # HBM traffic of that kernel and the VALU instruction counts of all kernels come from the PMC passes committed under
+    # profiles/ (tools/prof/collect_round.sh; rocprofv3 --pmc cannot run inside this process).  They are per launch of
+    # `blobs_per_launch` blobs there; if that differs from this run's launch size the figure is scaled and SAYS so.
+    traffic, traffic_source, valu = None, None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
-        pk = pmc["kernels"].get(PMC_NAME[dom])
+        pk = prof.get(PMC_NAME[dom])
         if pk and "hbm_bytes_corrected" in pk:
+            same = pmc["blobs_per_launch"] == units
             traffic = round(pk["hbm_bytes_corrected"] * units / pmc["blobs_per_launch"])
+            traffic_source = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 correction, collected on a launch of "
+                              "%d blobs - %s" % (pmc_file, pmc["blobs_per_launch"], "the same launch size as this run, not re-measured by it" if same else
+                                                 "EXTRAPOLATED linearly to this run's %d blobs per launch" % units))
         path = list(PMC_NAME.values()) + ["kzg::k_msm_combine", "kzg::k_msm_combine_lanes", "kzg::k_batch_scalars", "kzg::k_glv_split", "kzg::k_mult_to_affine29",
                                            "kzg::k_eval_powers", "kzg::k_eval_finish"]
-        insts = sum(pmc["kernels"][k].get("SQ_INSTS_VALU", 0) for k in path if k in pmc["kernels"])
+        insts = sum(prof[k].get("SQ_INSTS_VALU", 0) for k in path if k in prof)
         per_blob = insts / pmc["blobs_per_launch"]  # wave-instructions per blob, all kernels of the path
         simds, clock = 1024, 2.4e9
-        valu = {"wave_insts_per_blob": round(per_blob), "insts_per_cycle_per_simd": round(per_blob * (n * K / elapsed) / (simds * clock), 4),
-                "note": "VALU wave-instructions issued per SIMD cycle at the measured throughput (SQ_INSTS_VALU of every kernel of the path, "
-                        + PMC_FILE + "); gfx950 issues the path's instruction mix at 2.4-4.3 cycles per wave-instruction "
-                        "(profiles/r1_issuebench_valu_issue_cost.txt), i.e. 0.23-0.42 is the ceiling"}
+        valu = {"wave_insts_per_blob": round(per_blob), "insts_per_cycle_per_simd": round(per_blob * (n * G * K / elapsed) / (simds * clock), 4),
+                "note": "VALU wave-instructions issued per SIMD cycle at the measured throughput (SQ_INSTS_VALU of every kernel of the path, profiles/"
+                        + pmc_file + "); gfx950 issues the path's instruction mix at 2.4-4.3 cycles per wave-instruction "
+                        "(profiles/r1_issuebench_valu_issue_cost.txt, the builder's own microbenchmark), i.e. 0.23-0.42 is the ceiling"}
     except Exception:
         pass
     out = {
         "metric": "blobs/sec verify_blob_kzg_proof_batch",
-        "value": round(n * world * K / elapsed, 2),
+        "value": round(n * world * G * K / elapsed, 2),
         "unit": "blobs/s",
         "n_gpus": world,
         "steps": K,
-        "warmup": args.warmup,
+        "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u32 limbs (255-bit Fr / 381-bit Fp modular integers)",
         "data": "synthetic",
-        "config": {"workload": "verify_blob_kzg_proof_batch, %d synthetic blobs (4096 Fr each) per GPU per step, device-resident, "
-                               "known-tau test setup (BASELINE.json configs[1]); every step is an independent batch verification"
-                               % n,
-                   "blobs_per_gpu": n, "batch": n * world, "parallelism": "shard-by-blob x%d" % world,
-                   "batches_per_launch_group": G, "groups_in_flight": F},
-        "roofline": {"bound": "hbm", "kernel": dom, "units_per_launch": units, "launch_ms": round(kernels[dom], 4),
+        "config": {"workload": "verify_blob_kzg_proof_batch, batches of %d synthetic blobs (4096 Fr each)%s, device-resident, known-tau test setup (%s); "
+                               "one step = one launch group of %d independent batches = %d blobs per GPU"
+                               % (n * world, "" if world == 1 else " sharded by blob over %d GPUs (%d per GPU)" % (world, n),
+                                  "BASELINE.json configs[1]" if n == 1024 and world == 1 else
+                                  "BASELINE.json configs[4]" + ("" if world == 8 else " shard shape: 32 768 blobs per GPU") if n == 32768 else "custom size", G, n * G),
+                   "blobs_per_gpu_per_batch": n, "batch": n * world, "batches_per_step": G, "blobs_per_step": n * world * G,
+                   "parallelism": "shard-by-blob x%d" % world, "groups_in_flight": F},
+        "roofline": {"bound": "hbm", "kernel": dom, "kernel_chosen_by": dom_source, "units_per_launch": units, "launch_ms": round(kernels[dom], 4),
                      "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                     "traffic": traffic, "traffic_source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, FETCH x2 gfx950 correction)",
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": ALG_BYTES[dom] * units,
-                     "launch_ms_source": ("the kernel's own execution interval, stamped inside the kernel with s_memrealtime and averaged over "
-                                          "the launch groups of the timed region (agrees with rocprofv3 --stats of this command, profiles/"
-                                          + PMC_FILE.replace("pmc.json", "kernel_stats.csv") + ")") if dom == "k_blob_challenge" else
-                                         "HIP events on the kernel's stream (includes waiting behind the other launch groups' kernels)",
+                     "launch_ms_source": ("live: the kernel's own execution interval, stamped inside the kernel with s_memrealtime (first wavefront in, last "
+                                          "wavefront out) and averaged over the %d launch groups of the timed region; rocprofv3 --kernel-trace --stats of this "
+                                          "same command reports the same quantity as the kernel's AverageNs" % cnt) if dom == "k_blob_challenge" else
+                                         "live: HIP events on the kernel's stream (includes waiting behind the other launch groups' kernels)",
                      "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 5)"},
         "valu": valu,
         "kernel_ms_per_launch_group": {k: round(v, 4) for k, v in kernels.items()},
-        "single_batch": {"value": round(n * world * KS / seq_elapsed, 2), "unit": "blobs/s", "ms_per_step": round(seq_elapsed / KS * 1e3, 4),
-                         "steps": KS, "kernel_ms": {"k_blob_challenge": round(seq_tm[5], 4), "k_blob_evaluate": round(seq_tm[4], 4),
-                                                     "k_g1_decode_multiples": round(seq_tm[6], 4), "k_msm": round(seq_tm[2], 4),
-                                                     "k_slp_run(pairing)": round(seq_tm[3], 4)}},
+        "single_batch": single,
+        "end_to_end": end2end,
     }
+    if dist:
+        g = max(pipe.stats["groups"], 1)  # warm-up groups included; per-step averages of THIS rank's host time
+        out["multi_gpu"] = {"ranks": world, "backend": dist.get_backend(), "rccl_ranks": world if dist.get_backend() == "nccl" else 0,
+                            "transcript_hash": "once per batch: rank j hashes batches [jB/N, (j+1)B/N) of every step" if G % world == 0 else
+                                               "every rank hashes every batch (batches per step not divisible by the rank count)",
+                            "r_hash_ms_per_step": round(pipe.stats["r_hash_s"] / g * 1e3, 4),
+                            "exchange1_ms_per_step": round(pipe.stats["exchange1_s"] / g * 1e3, 4),
+                            "exchange2_ms_per_step": round(pipe.stats["exchange2_s"] / g * 1e3, 4),
+                            "note": "exchange 1 = all-to-all of 160 B transcript records + all-gather of r (32 B per batch) and error flags; exchange 2 = "
+                                    "all-gather of the 288 B partial sums (A_k, B_k) - the G1 all-reduce of the north star, folded on every rank; host "
+                                    "times of rank 0, overlapped with the GPU work of the other groups in flight"}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blobs, cs, ps, synth.synthetic_setup()[1], args.cpu_sample)
     print(json.dumps(out))

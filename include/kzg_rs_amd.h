@@ -139,6 +139,14 @@ KzgRet kzg_shard_phase1_wait(uint8_t *records_out, uint8_t *bad_out, const KzgSe
 KzgRet kzg_shard_records_device(void *d_records_out, const KzgSettings *s);
 KzgRet kzg_shard_phase2_launch(const uint8_t *all_records, size_t n_total, size_t offset, const KzgSettings *s);
 KzgRet kzg_shard_phase2_launch_gathered(const uint8_t *gathered, size_t world, size_t rank, const KzgSettings *s);
+/* Hash once, not on every rank: kzg_batch_challenges is the hash half of compute_r_powers (src/kzg_proof.rs:291-334) as
+ * pure HOST code (no handle, no GPU): r_b = SHA-256(domain || degree || n_total || records of batch b) mod r for n_batches
+ * batches, written as 32 little-endian bytes each (= Scalar::to_bytes()).  records: world == 0: [n_batches][n_local] x
+ * 160 B (n_total = n_local); world > 0: [world][n_batches][n_local] x 160 B as an all-gather / all-to-all of equal
+ * shards leaves them (n_total = world n_local).  kzg_shard_phase2_launch_r is phase 2 with the challenges supplied
+ * (n_batches x 32 B, canonical) - so ONE rank hashes a batch's transcript and 32 bytes travel instead. */
+KzgRet kzg_batch_challenges(uint8_t *r_le_out, const uint8_t *records, size_t world, size_t n_batches, size_t n_local);
+KzgRet kzg_shard_phase2_launch_r(const uint8_t *r_le, size_t n_total, size_t offset, const KzgSettings *s);
 KzgRet kzg_shard_phase2_wait(uint8_t *partial_out, const KzgSettings *s);
 KzgRet kzg_shard_finish_launch(const uint8_t *partials, size_t world, size_t n_batches, const KzgSettings *s);
 KzgRet kzg_shard_finish_wait(bool *ok /* n_batches */, const KzgSettings *s);

@@ -124,6 +124,32 @@ class _BytesN:
     def as_slice(self):
         return self.data
 
+    # ---- wire formats of the reference's optional derives (src/dtypes.rs:9-17, Cargo.toml:41-43) ----
+    # `serde`: the newtype serialises as its inner [u8; N] through serde_arrays, i.e. a fixed-size sequence of N u8 -
+    # N raw bytes in a binary format such as bincode, a list of N numbers in a self-describing one such as JSON.
+    # `rkyv`: the archived form of a [u8; N] newtype is the N bytes themselves (alignment 1, no header).
+    def to_wire_bytes(self):
+        """bincode(serde) / rkyv archived bytes: exactly SIZE raw bytes."""
+        return self.data
+
+    @classmethod
+    def from_wire_bytes(cls, data):
+        """Inverse of to_wire_bytes; a wrong length is the deserialiser's error (InvalidBytesLength here)."""
+        return cls.from_slice(bytes(data))
+
+    def to_json(self):
+        """serde_json form: a JSON array of SIZE integers 0..255."""
+        import json
+        return json.dumps(list(self.data), separators=(",", ":"))
+
+    @classmethod
+    def from_json(cls, text):
+        import json
+        v = json.loads(text)
+        if not isinstance(v, list) or len(v) != cls.SIZE or any((not isinstance(x, int)) or isinstance(x, bool) or not 0 <= x <= 255 for x in v):
+            raise InvalidBytesLength("expected an array of %d u8" % cls.SIZE)
+        return cls(bytes(v))
+
 
 class Bytes32(_BytesN):
     SIZE = 32

@@ -26,7 +26,7 @@ def build(force=False, verbose=False):
     data = os.path.join(HERE, "data")
     # 1. generated sources
     gens = [os.path.join(ROOT, "tools", "gen_constants.py"), os.path.join(ROOT, "tools", "gen_mac_chains.py")]
-    if force or _newer(os.path.join(csrc, "constants.inc"), [gens[0], os.path.join(ROOT, "oracle", "pymodel.py")]):
+    if force or _newer(os.path.join(csrc, "constants.inc"), [gens[0], os.path.join(ROOT, "tools", "bls_params.py")]):
         subprocess.check_call([sys.executable, gens[0]])
     if force or _newer(os.path.join(csrc, "mac_chains.inc"), [gens[1]]):
         subprocess.check_call([sys.executable, gens[1]])

@@ -14,7 +14,9 @@ extern "C" const char* kzg_last_error(void) { return g_err.c_str(); }
         hipError_t e_ = (expr);                                                                            \
         if (e_ != hipSuccess) {                                                                            \
             (void)hipGetLastError();                                                                       \
-            return fail(KZG_ERROR, std::string("HIP: ") + hipGetErrorString(e_) + " at " #expr);           \
+            /* c-kzg-4844's C_KZG_MALLOC: the device (or pinned host) allocation did not fit */           \
+            return fail(e_ == hipErrorOutOfMemory ? KZG_MALLOC : KZG_ERROR,                                \
+                        std::string("HIP: ") + hipGetErrorString(e_) + " at " #expr);                      \
         }                                                                                                  \
     } while (0)
 

@@ -9,7 +9,7 @@ extern "C" KzgRet kzg_compute_challenges(uint8_t* z_out, const uint8_t* blobs, c
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
     select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
-    KzgRet rc = ws_reserve(s, n, 1, true);
+    KzgRet rc = ws_reserve(s, n, 1, STAGE_BLOBS);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     select_streams(s, n);  // before the staging copies: they must be on the stream the kernels of this launch run on
@@ -46,7 +46,7 @@ extern "C" KzgRet kzg_evaluate_polynomials_device(void* d_y, const void* d_blobs
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
     select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
-    KzgRet rc = ws_reserve(s, n, 1, false);
+    KzgRet rc = ws_reserve(s, n, 1, STAGE_NONE);
     if (rc != KZG_OK) return rc;
     bool bad = false;
     if ((rc = evaluate_device_locked(d_y, d_blobs, d_z, n, s, &bad)) != KZG_OK) return rc;
@@ -59,7 +59,7 @@ extern "C" KzgRet kzg_evaluate_polynomials(uint8_t* ys_out, const uint8_t* blobs
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
     select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
-    KzgRet rc = ws_reserve(s, n, 1, true);
+    KzgRet rc = ws_reserve(s, n, 1, STAGE_BLOBS);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     for (size_t i = 0; i < n; i++) reverse32(w.h_buf + 32 * i, zs + 32 * i);
@@ -80,7 +80,7 @@ extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const 
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
     select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
-    KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, 1, false);
+    KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, 1, STAGE_NONE);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     HIPCHK(hipMemcpyAsync(w.d_bytes, points48, 48 * n, hipMemcpyHostToDevice, s->s1));
@@ -105,7 +105,7 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
     select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
-    KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, 1, false);
+    KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, 1, STAGE_NONE);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     int mt = (int)(n ? n : 1);
@@ -203,7 +203,7 @@ extern "C" KzgRet kzg_pairing_check(bool* ok, const uint8_t a[48], const uint8_t
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
     select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
-    KzgRet rc = ws_reserve(s, 2, 1, false);
+    KzgRet rc = ws_reserve(s, 2, 1, STAGE_NONE);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     HIPCHK(hipMemcpyAsync(w.d_bytes, a, 48, hipMemcpyHostToDevice, s->s1));
@@ -263,13 +263,13 @@ extern "C" KzgRet kzg_settings_tau_g2(const KzgSettings* s, uint8_t out[96]) {
     if (!s || !out) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    uint8_t* d;
-    HIPCHK(hipMalloc(&d, 96));
+    DevTmp t;
+    HIPCHK(hipMalloc(&t.p, 96));
+    uint8_t* d = t.as<uint8_t>();
     hipLaunchKernelGGL(k_g2_compress, dim3(1), dim3(64), 0, s->s1, s->d_tau4, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d, 96, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
-    HIPCHK(hipFree(d));
     return KZG_OK;
 }
 
@@ -278,13 +278,13 @@ extern "C" KzgRet kzg_settings_g1_point(const KzgSettings* s, size_t i, uint8_t 
     if (!s->d_g1) return fail(KZG_BADARGS, "these settings were not loaded from a trusted-setup file");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    uint8_t* d;
-    HIPCHK(hipMalloc(&d, 48));
+    DevTmp t;
+    HIPCHK(hipMalloc(&t.p, 48));
+    uint8_t* d = t.as<uint8_t>();
     hipLaunchKernelGGL(k_aff_compress, dim3(1), dim3(64), 0, s->s1, s->d_g1 + i, s->d_g1_flag + i, d, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d, 48, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
-    HIPCHK(hipFree(d));
     return KZG_OK;
 }
 
@@ -293,13 +293,13 @@ extern "C" KzgRet kzg_settings_g2_point(const KzgSettings* s, size_t i, uint8_t 
     if (!s->d_g2 || i >= s->n_g2) return fail(KZG_BADARGS, "no such G2 point in these settings");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    uint8_t* d;
-    HIPCHK(hipMalloc(&d, 96));
+    DevTmp t;
+    HIPCHK(hipMalloc(&t.p, 96));
+    uint8_t* d = t.as<uint8_t>();
     hipLaunchKernelGGL(k_g2_compress, dim3(1), dim3(64), 0, s->s1, s->d_g2 + 4 * i, d);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, d, 96, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
-    HIPCHK(hipFree(d));
     return KZG_OK;
 }
 

@@ -17,7 +17,7 @@ struct Workspace {
     size_t pending_n = 0, pending_b = 0, finish_b = 0;  // group currently in flight on this handle
     int chunks = MSM_CHUNKS;                              // MSM layout of the group in flight (msm.hpp)
     size_t off_r = 0, off_part = 0, off_out = 0, off_parts = 0;  // pinned-buffer layout
-    size_t cap_stage = 0;   // staged host-input capacity (blobs)
+    size_t cap_stage = 0, cap_stage_cp = 0;   // staged host-input capacity: blobs | (commitment, proof) pairs
     Fr *d_z = nullptr, *d_y = nullptr, *d_scalars = nullptr, *d_partial = nullptr, *d_r = nullptr;
     uint32_t *d_status = nullptr, *d_pflag = nullptr, *d_term_point = nullptr, *d_term_scalar = nullptr, *d_sorted = nullptr;
     G1Aff* d_points = nullptr;
@@ -152,12 +152,13 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
     if ((rc = upload_program(s->prep, kzg_slp_prep_begin, kzg_slp_prep_end)) != KZG_OK) return rc;
     if ((rc = upload_program(s->verify, kzg_slp_verify_begin, kzg_slp_verify_end)) != KZG_OK) return rc;
     // decompress [tau]G2 on the device, then prepare the lines of [tau]G2 and of the generator
-    uint8_t* d_bytes;
-    uint32_t* d_flag;
-    Fp* d_q;  // 2 instances x 4 Fp
-    HIPCHK(hipMalloc(&d_bytes, 96));
-    HIPCHK(hipMalloc(&d_flag, 4));
-    HIPCHK(hipMalloc(&d_q, sizeof(Fp) * 8));
+    DevTmp t_bytes, t_flag, t_q;  // released on every path out of this function
+    HIPCHK(hipMalloc(&t_bytes.p, 96));
+    HIPCHK(hipMalloc(&t_flag.p, 4));
+    HIPCHK(hipMalloc(&t_q.p, sizeof(Fp) * 8));  // 2 instances x 4 Fp
+    uint8_t* d_bytes = t_bytes.as<uint8_t>();
+    uint32_t* d_flag = t_flag.as<uint32_t>();
+    Fp* d_q = t_q.as<Fp>();
     HIPCHK(hipMalloc(&s->d_tau4, sizeof(Fp) * 4));
     HIPCHK(hipMalloc(&s->d_prep, sizeof(Fp) * 2 * s->prep.p.n_out));
     HIPCHK(hipMemcpyAsync(d_bytes, tau_g2, 96, hipMemcpyHostToDevice, s->s1));
@@ -169,13 +170,14 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
     HIPCHK(hipMemcpyAsync(s->d_tau4, d_q, sizeof(Fp) * 4, hipMemcpyDeviceToDevice, s->s1));
     if ((rc = run_program(s->prep, d_q, nullptr, s->d_prep, 2, s->s1)) != KZG_OK) return rc;
     {  // multiples of the generator (msm.hpp): the same for every batch
-        G1Aff* d_g;
-        uint32_t* d_gf;
-        HIPCHK(hipMalloc(&d_g, sizeof(G1Aff)));
-        HIPCHK(hipMalloc(&d_gf, 4));
+        DevTmp t_g, t_gf, t_gm;
+        HIPCHK(hipMalloc(&t_g.p, sizeof(G1Aff)));
+        HIPCHK(hipMalloc(&t_gf.p, 4));
         constexpr int NG = MSM_CHUNKS + MSM_CHUNKS_LATENCY;
-        G1Jac* d_gm;
-        HIPCHK(hipMalloc(&d_gm, sizeof(G1Jac) * NG));
+        HIPCHK(hipMalloc(&t_gm.p, sizeof(G1Jac) * NG));
+        G1Aff* d_g = t_g.as<G1Aff>();
+        uint32_t* d_gf = t_gf.as<uint32_t>();
+        G1Jac* d_gm = t_gm.as<G1Jac>();
         hipLaunchKernelGGL(k_set_generator, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, 0);
         hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, d_gm, 1, 1, MSM_CHUNKS);
         hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, d_gm + MSM_CHUNKS, 1, 1, MSM_CHUNKS_LATENCY);
@@ -184,23 +186,65 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
             hipLaunchKernelGGL(k_jac_to_jac29, dim3(1), dim3(64), 0, s->s1, d_gm, (G1Jac29Mem*)s->d_gen_mult, NG);
             HIPCHK(hipMalloc(&s->d_gen_mult_aff, sizeof(G1Aff29Mem) * MSM_CHUNKS));
             hipLaunchKernelGGL(k_jac29_to_aff29, dim3(1), dim3(64), 0, s->s1, (const G1Jac29Mem*)s->d_gen_mult, s->d_gen_mult_aff, MSM_CHUNKS);
-            HIPCHK(hipStreamSynchronize(s->s1));
-            HIPCHK(hipFree(d_gm));
         } else {
-            s->d_gen_mult = d_gm;
+            s->d_gen_mult = d_gm;  // the handle owns it from here
+            t_gm.p = nullptr;
         }
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(s->s1));
-        HIPCHK(hipFree(d_g));
-        HIPCHK(hipFree(d_gf));
+        HIPCHK(hipStreamSynchronize(s->s1));  // before the temporaries of this scope are released
     }
     HIPCHK(hipStreamSynchronize(s->s1));
-    HIPCHK(hipFree(d_bytes));
-    HIPCHK(hipFree(d_flag));
-    HIPCHK(hipFree(d_q));
     if (flag != G1_OK) return fail(KZG_BAD_SETUP, "g2_points[1] is not a valid (finite) compressed G2 point");
     if (s->verify.p.n_set != 2 * s->prep.p.n_out || s->verify.p.n_in != 6 || s->prep.p.n_in != 4)
         return fail(KZG_ERROR, "embedded SLP programs do not fit together");
+    return KZG_OK;
+}
+
+// Device half of kzg_settings_load_trusted_setup: the G1 Lagrange points - unchecked decode (build.rs:66-70) for the table, and
+// the decode + subgroup test + multiples pass of the MSM (msm.hpp) so that commitments can be computed against them - and
+// all G2 monomial points (build.rs:72-75; verification itself reads only [1]).  Temporaries live in DevTmp, so every
+// return path releases them; the caller releases the handle on failure.
+static KzgRet settings_load_points(KzgSettings* s, const std::vector<uint8_t>& g1b, const std::vector<uint8_t>& g2b, int N, size_t n2) {
+    DevTmp t_bytes, t_flag2, t_gflag, t_tmp;
+    HIPCHK(hipMalloc(&t_bytes.p, std::max(g1b.size(), g2b.size())));
+    HIPCHK(hipMalloc(&t_flag2.p, 4 * (size_t)N));
+    HIPCHK(hipMalloc(&t_tmp.p, sizeof(G1Aff) * (size_t)N));
+    uint8_t* d_bytes = t_bytes.as<uint8_t>();
+    uint32_t* d_flag2 = t_flag2.as<uint32_t>();
+    G1Aff* d_tmp = t_tmp.as<G1Aff>();
+    HIPCHK(hipMalloc(&s->d_g1, sizeof(G1Aff) * (size_t)N));
+    HIPCHK(hipMalloc(&s->d_g1_flag, 4 * (size_t)N));
+    HIPCHK(hipMalloc(&s->d_g1_mult, MULT_ENTRY_BYTES * MSM_CHUNKS * (size_t)N));
+    HIPCHK(hipMemcpyAsync(d_bytes, g1b.data(), g1b.size(), hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, s->d_g1, s->d_g1_flag, N, 0);
+    if (fp29_enabled())
+        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
+                           d_flag2, s->d_g1_mult, (G1Jac29Mem*)nullptr, N, N);
+    else
+        hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
+                           d_flag2, (G1Jac*)s->d_g1_mult, N, N);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> f1((size_t)N), f2((size_t)N);
+    HIPCHK(hipMemcpyAsync(f1.data(), s->d_g1_flag, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(f2.data(), d_flag2, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    s->g1_in_subgroup = true;
+    for (int i = 0; i < N; i++) {
+        if (f1[i] == G1_INVALID) return fail(KZG_BAD_SETUP, "load_trusted_setup Invalid g1 bytes");
+        if (f2[i] == G1_INVALID) s->g1_in_subgroup = false;
+    }
+    s->n_g2 = n2;
+    HIPCHK(hipMalloc(&s->d_g2, sizeof(Fp) * 4 * n2));
+    HIPCHK(hipMalloc(&t_gflag.p, 4 * n2));
+    uint32_t* d_gflag = t_gflag.as<uint32_t>();
+    HIPCHK(hipMemcpyAsync(d_bytes, g2b.data(), g2b.size(), hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_g2_decompress_n, dim3((unsigned)n2), dim3(64), 0, s->s1, d_bytes, s->d_g2, d_gflag);
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> fg(n2);
+    HIPCHK(hipMemcpyAsync(fg.data(), d_gflag, 4 * n2, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    for (size_t i = 0; i < n2; i++)
+        if (fg[i] == G1_INVALID) return fail(KZG_BAD_SETUP, "load_trusted_setup Invalid g2 bytes");
     return KZG_OK;
 }
 
@@ -256,57 +300,14 @@ extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char*
     if (rc != KZG_OK) return rc;
     KzgSettings* s = *out;
     *out = nullptr;
-    auto bail = [&](KzgRet code, const char* msg) {
-        kzg_settings_free(s);
-        return fail(code, msg);
-    };
     memcpy(s->g1_first, first, sizeof first);
-    // G1 Lagrange points: unchecked decode (build.rs:66-70) for the table, and the decode + subgroup test + multiples
-    // pass of the MSM (msm.hpp) so that commitments can be computed against them
-    uint8_t* d_bytes;
-    uint32_t *d_flag2, *d_gflag;
-    G1Aff* d_tmp;
-    const int N = (int)n1;
-    HIPCHK(hipMalloc(&d_bytes, std::max(g1b.size(), g2b.size())));
-    HIPCHK(hipMalloc(&d_flag2, 4 * (size_t)N));
-    HIPCHK(hipMalloc(&d_tmp, sizeof(G1Aff) * (size_t)N));
-    HIPCHK(hipMalloc(&s->d_g1, sizeof(G1Aff) * (size_t)N));
-    HIPCHK(hipMalloc(&s->d_g1_flag, 4 * (size_t)N));
-    HIPCHK(hipMalloc(&s->d_g1_mult, MULT_ENTRY_BYTES * MSM_CHUNKS * (size_t)N));
-    HIPCHK(hipMemcpyAsync(d_bytes, g1b.data(), g1b.size(), hipMemcpyHostToDevice, s->s1));
-    hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, s->d_g1, s->d_g1_flag, N, 0);
-    if (fp29_enabled())
-        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
-                           d_flag2, s->d_g1_mult, (G1Jac29Mem*)nullptr, N, N);
-    else
-        hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
-                           d_flag2, (G1Jac*)s->d_g1_mult, N, N);
-    HIPCHK(hipGetLastError());
-    std::vector<uint32_t> f1((size_t)N), f2((size_t)N);
-    HIPCHK(hipMemcpyAsync(f1.data(), s->d_g1_flag, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipMemcpyAsync(f2.data(), d_flag2, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipStreamSynchronize(s->s1));
-    s->g1_in_subgroup = true;
-    for (int i = 0; i < N; i++) {
-        if (f1[i] == G1_INVALID) return bail(KZG_BAD_SETUP, "load_trusted_setup Invalid g1 bytes");
-        if (f2[i] == G1_INVALID) s->g1_in_subgroup = false;
+    rc = settings_load_points(s, g1b, g2b, (int)n1, (size_t)n2);
+    if (rc != KZG_OK) {  // any failure below settings_common releases the whole handle (and keeps the first message)
+        const std::string msg = g_err;
+        kzg_settings_free(s);
+        g_err = msg;
+        return rc;
     }
-    // G2 monomial points: all of them decoded (build.rs:72-75); verification itself reads only [1]
-    s->n_g2 = (size_t)n2;
-    HIPCHK(hipMalloc(&s->d_g2, sizeof(Fp) * 4 * (size_t)n2));
-    HIPCHK(hipMalloc(&d_gflag, 4 * (size_t)n2));
-    HIPCHK(hipMemcpyAsync(d_bytes, g2b.data(), g2b.size(), hipMemcpyHostToDevice, s->s1));
-    hipLaunchKernelGGL(k_g2_decompress_n, dim3((unsigned)n2), dim3(64), 0, s->s1, d_bytes, s->d_g2, d_gflag);
-    HIPCHK(hipGetLastError());
-    std::vector<uint32_t> fg((size_t)n2);
-    HIPCHK(hipMemcpyAsync(fg.data(), d_gflag, 4 * (size_t)n2, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipStreamSynchronize(s->s1));
-    HIPCHK(hipFree(d_bytes));
-    HIPCHK(hipFree(d_flag2));
-    HIPCHK(hipFree(d_gflag));
-    HIPCHK(hipFree(d_tmp));
-    for (long i = 0; i < n2; i++)
-        if (fg[(size_t)i] == G1_INVALID) return bail(KZG_BAD_SETUP, "load_trusted_setup Invalid g2 bytes");
     *out = s;
     return KZG_OK;
 }

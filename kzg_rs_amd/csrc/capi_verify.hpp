@@ -53,10 +53,12 @@ static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const 
 }
 
 // Workspace for a launch group of B batches with T blobs in total (B = 1 for the single-call entry points).
-static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
+// stage: host-input staging wanted - STAGE_BLOBS (T blobs + their commitments / proofs) or STAGE_CP (commitments / proofs only)
+enum { STAGE_NONE = 0, STAGE_BLOBS = 1, STAGE_CP = 2 };
+static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, int stage) {
     Workspace& w = s->ws;
     if (T > w.cap_n || B > w.cap_b) {
-        size_t keep_stage = w.cap_stage;
+        size_t keep_stage = w.cap_stage, keep_cp = w.cap_stage_cp;
         uint8_t *sb = w.d_stage_blobs, *sc = w.d_stage_cp;
         w.d_stage_blobs = nullptr;
         w.d_stage_cp = nullptr;
@@ -65,6 +67,7 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
         w.d_stage_blobs = sb;
         w.d_stage_cp = sc;
         w.cap_stage = keep_stage;
+        w.cap_stage_cp = keep_cp;
         if (capT < 16) capT = 16;
         const size_t np = 2 * capT + 1;            // points: C's, pi's, generator
         const size_t nsc = 2 * capT + capB;        // scalars: (2n+1) per batch
@@ -100,13 +103,20 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, bool stage) {
         w.cap_n = capT;
         w.cap_b = capB;
     }
-    if (stage && T > w.cap_stage) {
-        if (w.d_stage_blobs) (void)hipFree(w.d_stage_blobs);
+    if (stage != STAGE_NONE && T > w.cap_stage_cp) {  // 96 bytes per tuple: what the proof-tuple entry points stage
         if (w.d_stage_cp) (void)hipFree(w.d_stage_cp);
-        w.d_stage_blobs = w.d_stage_cp = nullptr;
+        w.d_stage_cp = nullptr;
+        w.cap_stage_cp = 0;
+        size_t cap = T < 4 ? 4 : T;
+        HIPCHK(hipMalloc(&w.d_stage_cp, 96 * cap));
+        w.cap_stage_cp = cap;
+    }
+    if (stage == STAGE_BLOBS && T > w.cap_stage) {  // 128 KiB per blob: only the host-blob entry points pay for it
+        if (w.d_stage_blobs) (void)hipFree(w.d_stage_blobs);
+        w.d_stage_blobs = nullptr;
+        w.cap_stage = 0;
         size_t cap = T < 4 ? 4 : T;
         HIPCHK(hipMalloc(&w.d_stage_blobs, (size_t)BLOB_BYTES * cap));
-        HIPCHK(hipMalloc(&w.d_stage_cp, 96 * cap));
         w.cap_stage = cap;
     }
     return KZG_OK;
@@ -318,15 +328,57 @@ static KzgRet phase1_wait_locked(uint8_t* records_out, uint8_t* bad_out, const K
     return KZG_OK;
 }
 
-// Phase 2: per batch b, r_b from its FULL transcript, this shard's scalars r_b^(offset+i) and its partial sums (A, B)_b.
-// Requires phase 1 of the same group on this handle.  The records come in one of three layouts:
-//   all_records != NULL, world == 0 : [B][n_total]          every batch's records in global blob order
-//   all_records != NULL, world  > 0 : [world][B][n]         as an all-gather of equal shards leaves them (n_total = world n)
-//   all_records == NULL             : the handle's own records of phase 1 (single rank: n_total = n)
-static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, size_t offset, const KzgSettings* s, size_t world = 0) {
+// compute_r_powers' hash (src/kzg_proof.rs:291-348) for B batches: r_b = SHA-256(domain || degree || n_total || records of batch b) mod r,
+// written as 32 little-endian bytes (= Scalar::to_bytes(), the device limb layout) to r_out + 32 b.  Pure host code (SHA-NI):
+// one serial chain of 160 n_total + 32 bytes per batch - hopeless on a GPU lane, ~2 GB/s on a CPU core - and the batches are
+// independent, so they are spread over a few host threads (KZG_HOST_THREADS, default 16).  Record layouts:
+//   world == 0 : [B][n_total]       every batch's records in global blob order
+//   world  > 0 : [world][B][n]      as an all-gather / all-to-all of equal shards leaves them (n_total = world n)
+static void host_batch_challenges(uint8_t* r_out, const uint8_t* all_records, size_t B, size_t n, size_t n_total, size_t world) {
+    auto digest_range = [&](size_t b0, size_t b1) {
+        std::vector<uint8_t> t(32 + 160 * n_total);
+        memcpy(t.data(), "RCKZGBATCH___V1_", 16);
+        memset(t.data() + 16, 0, 16);
+        t[22] = (uint8_t)(FE_PER_BLOB >> 8);
+        t[23] = (uint8_t)(FE_PER_BLOB & 0xff);
+        for (int k = 0; k < 8; k++) t[24 + k] = (uint8_t)((uint64_t)n_total >> (56 - 8 * k));
+        for (size_t b = b0; b < b1; b++) {
+            if (world == 0) memcpy(t.data() + 32, all_records + 160 * n_total * b, 160 * n_total);
+            else
+                for (size_t k = 0; k < world; k++) memcpy(t.data() + 32 + 160 * n * k, all_records + 160 * n * (k * B + b), 160 * n);
+            uint8_t dg[32];
+            hostsha::digest(dg, t.data(), t.size());
+            while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r: at most two subtractions (2^256 < 3r)
+            reverse32(r_out + 32 * b, dg);
+        }
+    };
+    static const size_t host_threads = [] {
+        const char* e = getenv("KZG_HOST_THREADS");
+        long v = e ? atol(e) : 16;
+        return (size_t)(v < 1 ? 1 : v > 64 ? 64 : v);
+    }();
+    const size_t nthr = std::min(host_threads, std::min(B, (B * 160 * n_total) / (512 * 1024) + 1));
+    if (nthr <= 1) {
+        digest_range(0, B);
+    } else {
+        std::vector<std::thread> pool;
+        for (size_t k = 1; k < nthr; k++) pool.emplace_back(digest_range, B * k / nthr, B * (k + 1) / nthr);
+        digest_range(0, B / nthr);
+        for (auto& th : pool) th.join();
+    }
+}
+
+// Phase 2: per batch b, this shard's scalars r_b^(offset+i) and its partial sums (A, B)_b.  Requires phase 1 of the same group on
+// this handle.  r_b comes from the batch's FULL transcript, in one of four ways:
+//   r_le != NULL                      : given by the caller, B x 32 little-endian bytes (kzg_batch_challenges on some rank)
+//   all_records != NULL, world == 0   : hashed here from [B][n_total] records in global blob order
+//   all_records != NULL, world  > 0   : hashed here from [world][B][n] records (n_total = world n)
+//   both NULL                         : hashed here from the handle's own records of phase 1 (single rank: n_total = n)
+static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, size_t offset, const KzgSettings* s, size_t world = 0,
+                                   const uint8_t* r_le = nullptr) {
     Workspace& w = s->ws;
     const size_t n = w.pending_n, B = w.pending_b;
-    if (!all_records) {
+    if (!all_records && !r_le) {
         if (n_total != n || offset != 0) return fail(KZG_BADARGS, "local phase 2 needs n_total == n_local");
         all_records = w.h_buf;
         world = 0;
@@ -336,41 +388,10 @@ static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, s
         // verify_blob_kzg_proof path (:482-489): r^0 = 1, no batch challenge
         hipLaunchKernelGGL(k_single_scalars, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_z, w.d_y, w.d_scalars);
     } else {
-        // compute_r_powers :291-348, once per batch.  The transcripts are hashed on the host (SHA-NI): one serial chain
-        // of 160 n_total + 32 bytes per batch - hopeless on a GPU lane, ~2 GB/s on a CPU core - and the batches of a
-        // launch group are independent, so they are spread over a few host threads (KZG_HOST_THREADS, default 16).
-        auto digest_range = [&](size_t b0, size_t b1) {
-            std::vector<uint8_t> t(32 + 160 * n_total);
-            memcpy(t.data(), "RCKZGBATCH___V1_", 16);
-            memset(t.data() + 16, 0, 16);
-            t[22] = (uint8_t)(FE_PER_BLOB >> 8);
-            t[23] = (uint8_t)(FE_PER_BLOB & 0xff);
-            for (int k = 0; k < 8; k++) t[24 + k] = (uint8_t)((uint64_t)n_total >> (56 - 8 * k));
-            for (size_t b = b0; b < b1; b++) {
-                if (world == 0) memcpy(t.data() + 32, all_records + 160 * n_total * b, 160 * n_total);
-                else
-                    for (size_t k = 0; k < world; k++) memcpy(t.data() + 32 + 160 * n * k, all_records + 160 * n * (k * B + b), 160 * n);
-                uint8_t dg[32];
-                hostsha::digest(dg, t.data(), t.size());
-                while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r: at most two subtractions (2^256 < 3r)
-                reverse32(w.h_buf + w.off_r + 32 * b, dg);  // pinned staging for the async H2D copy
-            }
-        };
-        static const size_t host_threads = [] {
-            const char* e = getenv("KZG_HOST_THREADS");
-            long v = e ? atol(e) : 16;
-            return (size_t)(v < 1 ? 1 : v > 64 ? 64 : v);
-        }();
-        const size_t nthr = std::min(host_threads, std::min(B, (B * 160 * n_total) / (512 * 1024) + 1));
-        if (nthr <= 1) {
-            digest_range(0, B);
-        } else {
-            std::vector<std::thread> pool;
-            for (size_t k = 1; k < nthr; k++) pool.emplace_back(digest_range, B * k / nthr, B * (k + 1) / nthr);
-            digest_range(0, B / nthr);
-            for (auto& th : pool) th.join();
-        }
-        HIPCHK(hipMemcpyAsync(w.d_r, w.h_buf + w.off_r, 32 * B, hipMemcpyHostToDevice, s->s1));
+        uint8_t* h_r = w.h_buf + w.off_r;  // pinned staging for the async H2D copy
+        if (r_le) memcpy(h_r, r_le, 32 * B);
+        else host_batch_challenges(h_r, all_records, B, n, n_total, world);
+        HIPCHK(hipMemcpyAsync(w.d_r, h_r, 32 * B, hipMemcpyHostToDevice, s->s1));
         unsigned blocks = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_batch_scalars, dim3(blocks, (unsigned)B), dim3(256), 0, s->s1, w.d_r, w.d_z, w.d_y, w.d_scalars,
                            w.d_partial, (int)n, (unsigned long long)offset);
@@ -448,7 +469,7 @@ static KzgRet batch_device_locked(bool* ok, const void* d_blobs, const void* d_c
 extern "C" KzgRet kzg_shard_phase1_launch(const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n_local,
                                           size_t n_batches, const KzgSettings* s) {
     KZG_ENTER(s && d_blobs && d_commitments && d_proofs && n_local && n_batches);
-    KzgRet rc = ws_reserve(s, n_local * n_batches, n_batches, false);
+    KzgRet rc = ws_reserve(s, n_local * n_batches, n_batches, STAGE_NONE);
     if (rc != KZG_OK) return rc;
     return phase1_launch_locked(d_blobs, d_commitments, d_proofs, n_local, n_batches, s);
 }
@@ -464,6 +485,21 @@ extern "C" KzgRet kzg_shard_phase2_launch_gathered(const uint8_t* gathered, size
     KZG_ENTER(s && gathered && s->ws.pending_n && world && rank < world);
     return phase2_launch_locked(gathered, world * s->ws.pending_n, rank * s->ws.pending_n, s, world);
 }
+extern "C" KzgRet kzg_shard_phase2_launch_r(const uint8_t* r_le, size_t n_total, size_t offset, const KzgSettings* s) {
+    KZG_ENTER(s && r_le && s->ws.pending_n && offset + s->ws.pending_n <= n_total);
+    for (size_t b = 0; b < s->ws.pending_b; b++) {  // canonical little-endian scalars only
+        uint8_t be[32];
+        reverse32(be, r_le + 32 * b);
+        if (be_geq_r(be)) return fail(KZG_BADARGS, "kzg_shard_phase2_launch_r: challenge not below r");
+    }
+    return phase2_launch_locked(nullptr, n_total, offset, s, 0, r_le);
+}
+// the hash half of compute_r_powers on the host, without a handle or a GPU: see include/kzg_rs_amd.h
+extern "C" KzgRet kzg_batch_challenges(uint8_t* r_le_out, const uint8_t* records, size_t world, size_t n_batches, size_t n_local) {
+    if (!r_le_out || !records || !n_batches || !n_local) return fail(KZG_BADARGS, "bad argument");
+    host_batch_challenges(r_le_out, records, n_batches, n_local, (world ? world : 1) * n_local, world);
+    return KZG_OK;
+}
 extern "C" KzgRet kzg_shard_records_device(void* d_records_out, const KzgSettings* s) {
     KZG_ENTER(s && d_records_out && s->ws.pending_n);
     HIPCHK(hipMemcpyAsync(d_records_out, s->ws.d_records, 160 * s->ws.pending_n * s->ws.pending_b, hipMemcpyDeviceToDevice, s->s1));
@@ -475,8 +511,18 @@ extern "C" KzgRet kzg_shard_phase2_wait(uint8_t* partial_out, const KzgSettings*
 }
 extern "C" KzgRet kzg_shard_finish_launch(const uint8_t* partials, size_t world, size_t n_batches, const KzgSettings* s) {
     KZG_ENTER(s && n_batches && (partials ? world > 0 : true));  // partials == NULL: pair this handle's own sums (single rank)
-    KzgRet rc = ws_reserve(s, 2 * n_batches, n_batches, false);
-    if (rc != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    // The finish needs only buffers sized by the batch count.  A handle that ran phases 1-2 of this group holds LIVE state
+    // (the sums in d_ab, pending_n / pending_b): its workspace must never be regrown here - ws_reserve frees and
+    // reallocates everything.  Only a handle without a group in flight (a rank that folds partials it did not produce)
+    // reserves, keeping its blob capacity.
+    if (!partials && (!w.pending_b || n_batches != w.pending_b))
+        return fail(KZG_BADARGS, "kzg_shard_finish_launch without partials needs the group of this handle's phase 2");
+    if (n_batches > w.cap_b) {
+        if (w.pending_b) return fail(KZG_BADARGS, "kzg_shard_finish_launch: more batches than the group in flight on this handle");
+        KzgRet rc = ws_reserve(s, w.cap_n ? w.cap_n : 16, n_batches, STAGE_NONE);
+        if (rc != KZG_OK) return rc;
+    }
     return finish_launch_locked(partials, world, n_batches, s);
 }
 extern "C" KzgRet kzg_shard_finish_wait(bool* ok, const KzgSettings* s) {
@@ -505,7 +551,7 @@ extern "C" KzgRet kzg_shard_finish(bool* ok, const uint8_t* partials, size_t wor
 extern "C" KzgRet kzg_verify_blob_kzg_proof_batches_device(bool* ok_out, uint8_t* err_out, const void* d_blobs, const void* d_commitments,
                                                            const void* d_proofs, size_t n, size_t n_batches, const KzgSettings* s) {
     KZG_ENTER(s && ok_out && d_blobs && d_commitments && d_proofs && n && n_batches);
-    KzgRet rc = ws_reserve(s, n * n_batches, n_batches, false);
+    KzgRet rc = ws_reserve(s, n * n_batches, n_batches, STAGE_NONE);
     if (rc != KZG_OK) return rc;
     if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, n_batches, s)) != KZG_OK) return rc;
     if ((rc = phase1_wait_locked(nullptr, err_out, s)) != KZG_OK) return rc;
@@ -528,7 +574,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_device(bool* ok, const void* d
     if (!d_blobs || !d_commitments || !d_proofs) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, n, 1, false);
+    KzgRet rc = ws_reserve(s, n, 1, STAGE_NONE);
     if (rc != KZG_OK) return rc;
     return batch_device_locked(ok, d_blobs, d_commitments, d_proofs, n, s);
 }
@@ -543,7 +589,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
     if (!blobs || !commitments || !proofs) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
-    KzgRet rc = ws_reserve(s, n, 1, true);
+    KzgRet rc = ws_reserve(s, n, 1, STAGE_BLOBS);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     select_streams(s, n);  // before the staging copies: they must be on the stream the kernels of this launch run on
@@ -584,7 +630,7 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
     select_streams(s, n);
-    KzgRet rc = ws_reserve(s, n, 1, true);
+    KzgRet rc = ws_reserve(s, n, 1, STAGE_CP);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     HIPCHK(hipEventRecord(s->ev[0], s->s1));

@@ -216,7 +216,7 @@ __device__ inline G1Jac g1_mul_xabs(const G1Jac& p) {
 // r-torsion test by the endomorphism: P in G1  <=>  phi(P) = -[x^2]P, phi(x, y) = (beta x, y)
 // (Scott, "A note on group membership tests for G1, G2 and GT", eprint 2021/1130 - the same
 // criterion zkcrypto/bls12_381 uses).  Accepts exactly the points with [r]P = O, which is what the
-// oracle checks by definition; tests/test_g1_decode.py compares the two on and off the subgroup.
+// CPU checker tests by definition; tests/test_gpu_parity.py::test_g1_decompress compares the two on and off the subgroup.
 __device__ inline bool g1_in_subgroup(const G1Aff& p) {
     G1Jac q = g1_from_affine(p);
 #pragma unroll 1

@@ -28,6 +28,7 @@ class HipBackend:
 
     def __init__(self, settings):
         self.settings = settings
+        self.bad = []
         L = api.lib()
         vp, u8, sz = C.c_void_p, C.c_char_p, C.c_size_t
         L.kzg_shard_phase1.argtypes = [u8, vp, vp, vp, sz, vp]
@@ -37,6 +38,8 @@ class HipBackend:
         L.kzg_shard_phase1_wait.argtypes = [u8, u8, vp]
         L.kzg_shard_phase2_launch.argtypes = [u8, sz, sz, vp]
         L.kzg_shard_phase2_launch_gathered.argtypes = [vp, sz, sz, vp]
+        L.kzg_shard_phase2_launch_r.argtypes = [u8, sz, sz, vp]
+        L.kzg_batch_challenges.argtypes = [u8, vp, sz, sz, sz]
         L.kzg_shard_records_device.argtypes = [vp, vp]
         L.kzg_shard_phase2_wait.argtypes = [u8, vp]
         L.kzg_shard_finish_launch.argtypes = [u8, sz, sz, vp]
@@ -45,6 +48,7 @@ class HipBackend:
     def phase1(self, shard):
         d_blobs, d_commitments, d_proofs, n_local = shard
         out = C.create_string_buffer(RECORD_BYTES * n_local)
+        self._n, self._b = n_local, 1
         api._chk(api.lib().kzg_shard_phase1(out, d_blobs, d_commitments, d_proofs, n_local, self.settings._h))
         return out.raw
 
@@ -52,6 +56,20 @@ class HipBackend:
         out = C.create_string_buffer(PARTIAL_BYTES)
         api._chk(api.lib().kzg_shard_phase2(out, all_records, n_total, offset, n_local, self.settings._h))
         return out.raw
+
+    # hash once: the transcript hash is host code that needs no handle; phase 2 then takes r (32 B per batch) instead
+    @staticmethod
+    def batch_challenges(records, world, n_batches, n_local):
+        """r of n_batches batches (32 little-endian bytes each) from records laid out [n_batches][n_local] (world = 0)
+        or [world][n_batches][n_local] (world > 0); `records` is bytes or a host address."""
+        out = C.create_string_buffer(32 * n_batches)
+        src = C.cast(C.c_char_p(records), C.c_void_p) if isinstance(records, (bytes, bytearray)) else C.c_void_p(records)
+        api._chk(api.lib().kzg_batch_challenges(out, src, world, n_batches, n_local))
+        return out.raw
+
+    def phase2_r(self, r_le, n_total, offset, n_local):
+        self.phase2_launch_r(r_le, n_total, offset)
+        return self.phase2_wait()
 
     def finish(self, partials, world):
         ok = C.c_bool(False)
@@ -65,17 +83,22 @@ class HipBackend:
         api._chk(api.lib().kzg_shard_phase1_launch(d_blobs, d_commitments, d_proofs, n_local, n_batches, self.settings._h))
 
     def phase1_wait(self, want_records=True):
-        """want_records=False leaves the records inside the handle (phase2_launch(None, ...) or the device exchange)."""
-        if not want_records:
-            api._chk(api.lib().kzg_shard_phase1_wait(None, None, self.settings._h))
-            return None
-        out = C.create_string_buffer(RECORD_BYTES * self._n * self._b)
-        api._chk(api.lib().kzg_shard_phase1_wait(out, None, self.settings._h))
-        return out.raw
+        """Leaves self.bad = one flag per batch (True: the batch holds an undecodable point or a non-canonical blob
+        element, i.e. the reference returns Err for it); the group keeps going, its result for that batch is forced
+        to None by the caller.  want_records=False leaves the records inside the handle (phase2_launch(None, ...) or
+        the device exchange)."""
+        bad = C.create_string_buffer(self._b)
+        out = C.create_string_buffer(RECORD_BYTES * self._n * self._b) if want_records else None
+        api._chk(api.lib().kzg_shard_phase1_wait(out, bad, self.settings._h))
+        self.bad = [x != 0 for x in bad.raw]
+        return out.raw if want_records else None
 
     def phase2_launch(self, all_records, n_total, offset):
         """all_records None: the handle's own records (single rank)."""
         api._chk(api.lib().kzg_shard_phase2_launch(all_records, n_total, offset, self.settings._h))
+
+    def phase2_launch_r(self, r_le, n_total, offset):
+        api._chk(api.lib().kzg_shard_phase2_launch_r(r_le, n_total, offset, self.settings._h))
 
     # bulk exchange without host copies (equal shards): records leave through device memory, come back gathered
     def records_to_device(self, d_ptr):
@@ -116,38 +139,91 @@ def _all_gather_bytes(dist, payload, device):
     return [bytes(o[:l].cpu().numpy().tobytes()) for o, l in zip(outs, lens)]
 
 
-def verify_blob_kzg_proof_batch_sharded(shard, n_local, backend, dist=None, device="cpu", force_collectives=False):
-    """Every rank calls this with its own shard (rank order = global blob order).  Returns the batch
-    result on every rank.  Raises KzgError on every rank if any shard holds an invalid input
-    (first-error identity is not observable in the reference beyond "is Err")."""
+def _gather_bytes_to_root(dist, payload, lens, device):
+    """Variable-length byte strings of every rank, in rank order, on rank 0 only (others get None)."""
     import torch
 
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mx = max(lens + [1])
+    buf = torch.zeros(mx, dtype=torch.uint8, device=device)
+    if payload:
+        buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(device)
+    outs = [torch.zeros(mx, dtype=torch.uint8, device=device) for _ in range(world)] if rank == 0 else None
+    dist.gather(buf, outs, dst=0)
+    if rank != 0:
+        return None
+    return [bytes(o[:l].cpu().numpy().tobytes()) for o, l in zip(outs, lens)]
+
+
+def verify_blob_kzg_proof_batch_sharded(shard, n_local, backend, dist=None, device="cpu", force_collectives=False, timings=None):
+    """ONE batch sharded by blob over the ranks (BASELINE.json configs[4]: 262 144 blobs over 8 GPUs).  Every rank calls
+    this with its own shard (rank order = global blob order).  Returns the batch result on every rank.  Raises KzgError
+    on every rank if any shard holds an invalid input (first-error identity is not observable in the reference beyond
+    "is Err").  The 160 n_total-byte transcript is hashed ONCE, on rank 0 (a serial SHA-256 chain, ~2 GB/s on a host
+    core), and the 32-byte challenge is broadcast.  timings (optional dict) receives the seconds spent in each stage."""
+    import time
+
+    import torch
+
+    def lap(key, t0):
+        if timings is not None:
+            timings[key] = timings.get(key, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
+    t = time.perf_counter()
     if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collectives):
         if n_local == 0:
             return True
         recs = backend.phase1(shard)
+        t = lap("phase1_s", t)
         part = backend.phase2(recs, n_local, 0, n_local)
-        return backend.finish(part, 1)
-    world = dist.get_world_size()
+        t = lap("phase2_s", t)
+        ok = backend.finish(part, 1)
+        lap("finish_s", t)
+        return ok
+    world, rank = dist.get_world_size(), dist.get_rank()
     err, recs = None, b""
     if n_local:
         try:
             recs = backend.phase1(shard)
         except api.KzgError as e:  # keep taking part in the collectives, then raise everywhere
             err = e
-    flag = torch.tensor([1 if err else 0], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-    if int(flag.item()):
+    t = lap("phase1_s", t)
+    # one small all-gather carries the error flag and the shard sizes
+    mine = torch.tensor([1 if err else 0, len(recs) // RECORD_BYTES], dtype=torch.int64, device=device)
+    meta = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(meta, mine)
+    meta = [[int(v) for v in m.tolist()] for m in meta]
+    if any(m[0] for m in meta):
         raise err if err else api.KzgError("BadArgs", "invalid input on another rank")
-    gathered = _all_gather_bytes(dist, recs, device)  # exchange 1: 160 B per blob
-    counts = [len(g) // RECORD_BYTES for g in gathered]
+    counts = [m[1] for m in meta]
     n_total = sum(counts)
     if n_total == 0:
         return True  # src/kzg_proof.rs:478-480
-    offset = sum(counts[: dist.get_rank()])
-    part = backend.phase2(b"".join(gathered), n_total, offset, n_local) if n_local else b""
+    offset = sum(counts[:rank])
+    if hasattr(backend, "batch_challenges") and hasattr(backend, "phase2_r"):
+        # exchange 1: records to rank 0 only (160 B per blob), which hashes the transcript; 32 bytes come back
+        gathered = _gather_bytes_to_root(dist, recs, [RECORD_BYTES * c for c in counts], device)
+        t = lap("exchange1_s", t)
+        r = torch.zeros(32, dtype=torch.uint8, device=device)
+        if rank == 0:
+            r_le = backend.batch_challenges(b"".join(gathered), 0, 1, n_total)
+            r = torch.frombuffer(bytearray(r_le), dtype=torch.uint8).to(device)
+        t = lap("r_hash_s", t)
+        dist.broadcast(r, src=0)
+        r_le = bytes(r.cpu().numpy().tobytes())
+        t = lap("r_broadcast_s", t)
+        part = backend.phase2_r(r_le, n_total, offset, n_local) if n_local else b""
+    else:
+        gathered = _all_gather_bytes(dist, recs, device)  # exchange 1: 160 B per blob, every rank hashes
+        t = lap("exchange1_s", t)
+        part = backend.phase2(b"".join(gathered), n_total, offset, n_local) if n_local else b""
+    t = lap("phase2_s", t)
     parts = [p for p in _all_gather_bytes(dist, part, device) if p]  # exchange 2: 288 B per rank
-    return backend.finish(b"".join(parts), len(parts))
+    t = lap("exchange2_s", t)
+    ok = backend.finish(b"".join(parts), len(parts))
+    lap("finish_s", t)
+    return ok
 
 
 class PipelinedVerifier:
@@ -160,11 +236,19 @@ class PipelinedVerifier:
     Iteration t runs, in this order:   phase1_launch(t);   phase1_wait(t-d1) + exchange 1 + phase2_launch;
     phase2_wait(t-d1-d2) + exchange 2 + finish_launch;   finish_wait(t-d1-d2-d3).
     The order is the same on every rank, so the collectives of different groups never interleave differently
-    on different ranks.  With one rank the exchanges and the phase-2 host round trip disappear."""
+    on different ranks.  With one rank the exchanges and the phase-2 host round trip disappear.
+
+    Exchange 1 with equal shards and a batch count divisible by the world size hashes every transcript ONCE: rank j
+    owns the batches [j B / world, (j + 1) B / world) of the group, an all-to-all brings it their records from every
+    rank ([src][B / world][n] x 160 B - 1/world of what an all-gather would deliver), it hashes them on its host
+    cores, and one all-gather returns every r (32 B per batch) together with the per-batch error flags.
+
+    A batch with an invalid input (the reference's Err) does not stop anything: it runs through the group like any
+    other batch, and its result is None - on every rank."""
 
     def __init__(self, backends, dist=None, device="cpu", depth=(1, 1, 1), equal_shards=False, force_collectives=False):
         """equal_shards: every rank holds the same number of blobs of every batch - enables the bulk exchange (records
-        go from the library's device buffer straight into the all-gather and come back through one pinned buffer)."""
+        go from the library's device buffer straight into the collective and come back through one pinned buffer)."""
         self.backends = backends
         self.equal_shards = equal_shards
         self._bufs = {}
@@ -172,6 +256,7 @@ class PipelinedVerifier:
         self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives)) else None
         self.device = device
         self.depth = depth if self.dist else (depth[0], 0, depth[2])
+        self.stats = {"r_hash_s": 0.0, "exchange1_s": 0.0, "exchange2_s": 0.0, "groups": 0}
         assert len(backends) >= sum(self.depth) + 1, "need depth+1 handles"
 
     def _regroup(self, gathered, n_batches):
@@ -179,26 +264,71 @@ class PipelinedVerifier:
         per_rank = [[g[i * (len(g) // n_batches): (i + 1) * (len(g) // n_batches)] for i in range(n_batches)] for g in gathered]
         return b"".join(per_rank[r][b] for b in range(n_batches) for r in range(len(gathered)))
 
-    def _exchange_buffers(self, slot, nbytes):
-        """Per handle: device send buffer, gathered receive buffer and its pinned host mirror (cached by size)."""
+    def _exchange_buffers(self, slot, nbytes, recv_bytes):
+        """Per handle: device send buffer, receive buffer and its pinned host mirror (cached by size)."""
         import torch
-        world = self.dist.get_world_size()
-        key = (slot, nbytes)
+        key = (slot, nbytes, recv_bytes)
         if key not in self._bufs:
             on_gpu = str(self.device) != "cpu"
             send = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
-            recv = torch.empty(world * nbytes, dtype=torch.uint8, device=self.device)
-            host = torch.empty(world * nbytes, dtype=torch.uint8, pin_memory=True) if on_gpu else recv
+            recv = torch.empty(recv_bytes, dtype=torch.uint8, device=self.device)
+            host = torch.empty(recv_bytes, dtype=torch.uint8, pin_memory=True) if on_gpu else recv
             self._bufs[key] = (send, recv, host)
         return self._bufs[key]
 
+    def _exchange1_bulk(self, b, slot, n, nb):
+        """Equal shards, records in device memory.  Returns after phase 2 of the group has been launched."""
+        import time
+
+        import torch
+        world, rank = self.dist.get_world_size(), self.dist.get_rank()
+        nbytes = RECORD_BYTES * n * nb
+        once = nb % world == 0  # every transcript hashed once, by the rank that owns the batch
+        send, recv, host = self._exchange_buffers(slot, nbytes, nbytes if once else world * nbytes)
+        b.phase1_wait(want_records=False)  # the handle's stream is drained: `send` is complete
+        t0 = time.perf_counter()
+        src = send if recv.is_cuda else send.cpu()
+        if once:
+            self.dist.all_to_all_single(recv, src)  # recv = [src rank][nb / world][n] records of MY batches
+        else:
+            self.dist.all_gather(list(recv.chunk(world)), src)  # [world][batch][n_local] records
+        if recv.is_cuda:
+            host.copy_(recv, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        t1 = time.perf_counter()
+        flags = torch.tensor([1 if x else 0 for x in b.bad], dtype=torch.uint8)
+        if once:
+            r_mine = b.batch_challenges(host.data_ptr(), world, nb // world, n)
+            t2 = time.perf_counter()
+            mine = torch.cat([torch.frombuffer(bytearray(r_mine), dtype=torch.uint8), flags]).to(self.device)
+            outs = [torch.empty_like(mine) for _ in range(world)]
+            self.dist.all_gather(outs, mine)
+            outs = [o.cpu() for o in outs]
+            r_all = b"".join(bytes(o[: 32 * (nb // world)].numpy().tobytes()) for o in outs)
+            fl = torch.stack([o[32 * (nb // world):] for o in outs]).amax(dim=0)
+            b.bad = [bool(x) for x in fl.tolist()]
+            b.phase2_launch_r(r_all, world * n, rank * n)
+            t3 = time.perf_counter()
+            self.stats["r_hash_s"] += t2 - t1
+            self.stats["exchange1_s"] += (t1 - t0) + (t3 - t2)
+        else:
+            fl = flags.to(self.device)
+            self.dist.all_reduce(fl, op=self.dist.ReduceOp.MAX)
+            b.bad = [bool(x) for x in fl.cpu().tolist()]
+            t2 = time.perf_counter()
+            b.phase2_launch_gathered(host.data_ptr(), world, rank)  # hashes every batch's transcript on this rank
+            self.stats["r_hash_s"] += time.perf_counter() - t2
+            self.stats["exchange1_s"] += t2 - t0
+
     def run(self, groups):
         """groups: list of ((d_blobs, d_commitments, d_proofs, n_local), n_batches): this rank's shard of every batch
-        of the group, batches contiguous.  Returns the per-batch results of every group, in order."""
-        import torch
+        of the group, batches contiguous.  Returns the per-batch results of every group, in order: True / False, or
+        None where the reference would return Err."""
+        import time
         K, S = len(groups), len(self.backends)
         d1, d2, d3 = self.depth
         results = [None] * K
+        bad = [None] * K
         # bulk path: equal shards on every rank and a backend that can hand its records over in device memory
         bulk = bool(self.dist) and self.equal_shards and hasattr(self.backends[0], "records_to_device")
         for t in range(K + d1 + d2 + d3):
@@ -206,25 +336,24 @@ class PipelinedVerifier:
                 b = self.backends[t % S]
                 b.phase1_launch(groups[t][0], groups[t][1])
                 if bulk:
-                    send, _, _ = self._exchange_buffers(t % S, RECORD_BYTES * groups[t][0][3] * groups[t][1])
+                    nbytes = RECORD_BYTES * groups[t][0][3] * groups[t][1]
+                    world = self.dist.get_world_size()
+                    send, _, _ = self._exchange_buffers(t % S, nbytes, nbytes if groups[t][1] % world == 0 else world * nbytes)
                     b.records_to_device(send.data_ptr())
             i = t - d1
             if 0 <= i < K:
                 b, nb = self.backends[i % S], groups[i][1]
                 if bulk:
-                    world, rank = self.dist.get_world_size(), self.dist.get_rank()
-                    send, recv, host = self._exchange_buffers(i % S, RECORD_BYTES * groups[i][0][3] * nb)
-                    b.phase1_wait(want_records=False)  # the handle's stream is drained: `send` is complete
-                    src = send if recv.is_cuda else send.cpu()
-                    self.dist.all_gather(list(recv.chunk(world)), src)  # exchange 1, [world][batch][n_local] records
-                    if recv.is_cuda:
-                        host.copy_(recv, non_blocking=True)
-                        torch.cuda.current_stream().synchronize()
-                    b.phase2_launch_gathered(host.data_ptr(), world, rank)
+                    self._exchange1_bulk(b, i % S, groups[i][0][3], nb)
                 elif self.dist:
                     recs = b.phase1_wait()
-                    gathered = _all_gather_bytes(self.dist, recs, self.device)
+                    t0 = time.perf_counter()
+                    flags = bytes(1 if x else 0 for x in getattr(b, "bad", None) or [False] * nb)
+                    gathered = _all_gather_bytes(self.dist, flags + recs, self.device)
+                    b.bad = [any(g[k] for g in gathered) for k in range(nb)]
+                    gathered = [g[nb:] for g in gathered]
                     counts = [len(g) // RECORD_BYTES // nb for g in gathered]
+                    self.stats["exchange1_s"] += time.perf_counter() - t0
                     b.phase2_launch(self._regroup(gathered, nb), sum(counts), sum(counts[: self.dist.get_rank()]))
                 else:
                     if hasattr(b, "records_to_device"):  # the records never leave the handle
@@ -234,12 +363,18 @@ class PipelinedVerifier:
                         recs = b.phase1_wait()
                         b.phase2_launch(recs, len(recs) // RECORD_BYTES // nb, 0)
                     b.finish_launch(None, 1)
+                bad[i] = list(getattr(b, "bad", None) or [False] * nb)
             j = t - d1 - d2
             if self.dist and 0 <= j < K:
                 b = self.backends[j % S]
-                parts = _all_gather_bytes(self.dist, b.phase2_wait(), self.device)
+                part = b.phase2_wait()
+                t0 = time.perf_counter()
+                parts = _all_gather_bytes(self.dist, part, self.device)
+                self.stats["exchange2_s"] += time.perf_counter() - t0
                 b.finish_launch(b"".join(parts), len(parts))
             k = t - d1 - d2 - d3
             if 0 <= k < K:
-                results[k] = self.backends[k % S].finish_wait()
+                res = self.backends[k % S].finish_wait()
+                results[k] = [None if e else r for r, e in zip(res, bad[k])]
+                self.stats["groups"] += 1
         return results

@@ -47,3 +47,29 @@ def test_constants_match_reference():
     # src/consts.rs:1-15
     assert (api.BYTES_PER_FIELD_ELEMENT, api.FIELD_ELEMENTS_PER_BLOB, api.BYTES_PER_BLOB) == (32, 4096, 131072)
     assert (api.BYTES_PER_COMMITMENT, api.BYTES_PER_PROOF) == (48, 48)
+
+
+def test_serde_rkyv_wire_formats_round_trip():
+    """the reference's optional `serde` / `rkyv` derives on Bytes32 / Bytes48 / Blob (src/dtypes.rs:9-17).
+    Binary form (bincode over serde_arrays, rkyv archive of a [u8; N] newtype): exactly N raw bytes; serde_json form:
+    an array of N numbers.  Round trips are byte-exact; wrong sizes and out-of-range elements are rejected."""
+    import json
+    import random
+    from kzg_rs_amd.api import Blob, Bytes32, Bytes48, KzgError
+    rng = random.Random(5)
+    for cls in (Bytes32, Bytes48, Blob):
+        raw = bytes(rng.getrandbits(8) for _ in range(cls.SIZE))
+        v = cls.from_slice(raw)
+        w = v.to_wire_bytes()
+        assert w == raw and len(w) == cls.SIZE
+        assert cls.from_wire_bytes(w).data == raw
+        j = v.to_json()
+        assert json.loads(j) == list(raw)
+        assert cls.from_json(j).data == raw
+        for bad in (raw[:-1], raw + b"\0"):
+            with pytest.raises(KzgError) as e:
+                cls.from_wire_bytes(bad)
+            assert e.value.kind == "InvalidBytesLength"
+        for bad in (json.dumps(list(raw[:-1])), json.dumps(list(raw[:-1]) + [256]), json.dumps(list(raw[:-1]) + [-1]), json.dumps({"a": 1})):
+            with pytest.raises(KzgError):
+                cls.from_json(bad)

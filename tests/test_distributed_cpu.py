@@ -43,16 +43,27 @@ class OracleBackend:
         self._mine = (cs, ps, out)
         return out
 
-    def phase2(self, all_records, n_total, offset, n_local):
+    def batch_challenges(self, records, world, n_batches, n_local):
+        """Same contract as HipBackend.batch_challenges for the [n_batches][n_total] layout (world = 0): r per batch,
+        32 little-endian bytes each."""
+        assert world == 0
+        out = b""
+        for b in range(n_batches):
+            recs = [records[160 * (b * n_local + i): 160 * (b * n_local + i) + 160] for i in range(n_local)]
+            out += self.O.compute_r(b"".join(x[:48] for x in recs), b"".join(x[48:80][::-1] for x in recs),
+                                    b"".join(x[80:112][::-1] for x in recs), b"".join(x[112:] for x in recs), n_local)[::-1]
+        return out
+
+    def phase2_r(self, r_le, n_total, offset, n_local):
+        return self.phase2(None, n_total, offset, n_local, r=int.from_bytes(r_le, "little"))
+
+    def phase2(self, all_records, n_total, offset, n_local, r=None):
         O = self.O
         cs, ps, mine = self._mine
         if n_total == 1:
             r = 1
-        else:
-            recs = [all_records[160 * i: 160 * i + 160] for i in range(n_total)]
-            r = int.from_bytes(O.compute_r(b"".join(x[:48] for x in recs), b"".join(x[48:80][::-1] for x in recs),
-                                           b"".join(x[80:112][::-1] for x in recs), b"".join(x[112:] for x in recs),
-                                           n_total), "big")
+        elif r is None:
+            r = int.from_bytes(self.batch_challenges(all_records, 0, 1, n_total), "little")
         A, B, g = G1_INF, G1_INF, 0
         for i in range(n_local):
             rec = mine[160 * i: 160 * i + 160]
@@ -78,19 +89,31 @@ class OracleBackend:
         self._grp = (shard, n_batches)
 
     def phase1_wait(self):
+        """Like HipBackend.phase1_wait: a batch with an invalid input does not raise, it sets self.bad[b] (and leaves
+        zero records); the pipeline carries the flag and reports None for that batch."""
+        from kzg_rs_amd import api
         (blobs, cs, ps), nb = self._grp
         n = len(blobs) // nb
-        self._per_batch, out = [], b""
+        self._per_batch, out, self.bad = [], b"", []
         for b in range(nb):
             sl = slice(b * n, (b + 1) * n)
-            out += self.phase1((blobs[sl], cs[sl], ps[sl]))
-            self._per_batch.append(self._mine)
+            try:
+                out += self.phase1((blobs[sl], cs[sl], ps[sl]))
+                self._per_batch.append(self._mine)
+                self.bad.append(False)
+            except api.KzgError:
+                out += bytes(160 * n)
+                self._per_batch.append(None)
+                self.bad.append(True)
         self._nloc = n
         return out
 
     def phase2_launch(self, all_records, n_total, offset):
         self._parts = b""
         for b, mine in enumerate(self._per_batch):
+            if mine is None or self.bad[b]:  # flagged on this or another rank: the result is forced to None anyway
+                self._parts += (G1_INF + G1_INF).ljust(288, b"\0")
+                continue
             self._mine = mine
             self._parts += self.phase2(all_records[160 * n_total * b: 160 * n_total * (b + 1)], n_total, offset, self._nloc)
 
@@ -197,8 +220,15 @@ def _pipe_worker(rank, world, port, q):
         if corrupt:
             ps[3] = O.g1_add(ps[3], G1_GEN)
         return blobs, cs, ps
-    plan = [[batch(0), batch(1, True)], [batch(2)], [batch(3), batch(1)]]
-    want = [[True, False], [True], [True, True]]
+    def invalid(rot, where):  # a non-canonical field element in one blob: the reference returns Err (src/dtypes.rs:48-57)
+        blobs, cs, ps = batch(rot)
+        b = bytearray(blobs[where])
+        b[64:96] = R.to_bytes(32, "big")
+        blobs[where] = bytes(b)
+        return blobs, cs, ps
+    # the invalid blob sits in the shard of rank 1 only (index 3): every rank must still report None for that batch
+    plan = [[batch(0), batch(1, True)], [batch(2)], [invalid(3, 3), batch(1)], [batch(3), batch(1)]]
+    want = [[True, False], [True], [None, True], [True, True]]
     groups = []
     for grp in plan:
         gb, gc, gp = [], [], []
@@ -206,8 +236,13 @@ def _pipe_worker(rank, world, port, q):
             lo, hi = 4 * rank // world, 4 * (rank + 1) // world
             gb += blobs[lo:hi]; gc += cs[lo:hi]; gp += ps[lo:hi]
         groups.append(((gb, gc, gp), len(grp)))
+    def unsharded(b, c, p):
+        try:
+            return O.verify_blob_kzg_proof_batch(b, c, p, st)
+        except O.OracleError:
+            return None
     for grp, w in zip(plan, want):  # sanity: the unsharded oracle agrees with the plan
-        assert [O.verify_blob_kzg_proof_batch(b, c, p, st) for b, c, p in grp] == w
+        assert [unsharded(b, c, p) for b, c, p in grp] == w
     pv = PipelinedVerifier([OracleBackend(O, st) for _ in range(4)], dist, "cpu", depth=(1, 1, 1))
     got = pv.run(groups)
     q.put((rank, got, want))

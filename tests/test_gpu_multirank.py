@@ -65,13 +65,24 @@ def _worker(rank, world, port, scenario, q):
             if corrupt:
                 p[4] = O.g1_add(p[4], G1_GEN)
             return bl, c, p
-        plan = [[batch(0), batch(1, True)], [batch(2)], [batch(3), batch(5)]]
+        def invalid(rot, where):  # a non-canonical field element in one blob (in the LAST rank's slice): Err in the reference
+            bl, c, p = batch(rot)
+            b = bytearray(bl[where])
+            b[64:96] = R.to_bytes(32, "big")
+            bl[where] = bytes(b)
+            return bl, c, p
+        # groups of 2, 1 and 3 batches: with 2 ranks the first, with 3 ranks the last is divisible by the world size (the
+        # hash-once all-to-all exchange of the bulk path); the others take the all-gather form
+        plan = [[batch(0), batch(1, True)], [batch(2)], [batch(3), invalid(4, 5), batch(5)]]
         per = 6 // world
         keep, groups, want = [], [], []
         for grp in plan:
             gb, gc, gp = [], [], []
             for bl, c, p in grp:
-                want.append(O.verify_blob_kzg_proof_batch(bl, c, p, ost))
+                try:
+                    want.append(O.verify_blob_kzg_proof_batch(bl, c, p, ost))
+                except O.OracleError:
+                    want.append(None)
                 sl = slice(rank * per, (rank + 1) * per)
                 gb += bl[sl]; gc += c[sl]; gp += p[sl]
             t, (db, dc, dp, _) = _device_shard(torch, gb, gc, gp)
@@ -127,7 +138,7 @@ def test_pipelined_groups_hip_path(world, scenario):
     """Launch groups through the fixed-order pipeline: the byte-string exchange (any shard sizes) and the bulk exchange
     (equal shards: records leave the library in device memory, come back as one gathered buffer)."""
     for rank, got, want in _run(world, scenario):
-        assert got == want == [True, False, True, True, True], (rank, got, want)
+        assert got == want == [True, False, True, True, None, True], (rank, got, want)
 
 
 def test_bench_script_two_ranks_shared_gpu():
@@ -138,14 +149,15 @@ def test_bench_script_two_ranks_shared_gpu():
     import subprocess
     env = dict(os.environ, KZG_BENCH_SHARE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "64", "--warmup", "1",
-           "--group", "16", "--no-cpu-baseline"]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--group", "16", "--no-cpu-baseline", "--workload", "configs1"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 64 and d["value"] > 0 and d["config"]["batch"] == 2048
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["config"]["batch"] == 2048
+    assert d["config"]["batches_per_step"] == 16 and d["multi_gpu"]["ranks"] == 2
 
 
 def _nccl_worker(port, q):

@@ -679,3 +679,56 @@ def test_launch_group_of_batches():
         except O.OracleError:
             want1.append(None)
     assert got1 == want1 and want1.count(True) >= 10 and False in want1
+
+
+def test_pipelined_groups_single_rank_flags_and_small_batches():
+    """PipelinedVerifier without a process group (what bench.py runs at N = 1): (a) groups of single-blob batches with
+    more batches than blobs - the finish must not regrow a workspace that holds live phase-2 sums (12 and 40 batches of
+    n = 1: 2 B > the 16-blob minimum capacity); (b) a batch with an invalid input does not abort the run - it comes back
+    as None (the reference's Err) and every other batch of every group keeps its own result."""
+    import torch
+    from kzg_rs_amd import synth
+    from kzg_rs_amd.distributed import HipBackend, PipelinedVerifier
+    n, B = 6, 5
+    blobs, cs, ps, st = synth.make_valid_batch(40, seed=78)
+    tau_g2 = synth.synthetic_setup()[1]
+    ost = O.Settings.from_tau_g2(tau_g2)
+    blobs = blobs.copy()
+    cs, ps = list(cs), list(ps)
+    ps[1 * n + 2] = O.g1_add(ps[1 * n + 2], G1_GEN)                       # batch 1 of the 6-blob view: wrong proof
+    blobs[2 * n + 3, 32 * 7: 32 * 7 + 32] = list(R.to_bytes(32, "big"))   # batch 2: non-canonical element -> Err
+    cs[3 * n + 1] = bytes([0x81]) + bytes(range(1, 48))                   # batch 3: junk commitment -> Err
+    d_b = torch.from_numpy(blobs).cuda()
+    d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).cuda()
+    d_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+
+    def want(n_, B_):
+        out = []
+        for b in range(B_):
+            bl = [blobs[i].tobytes() for i in range(b * n_, (b + 1) * n_)]
+            try:
+                out.append(O.verify_blob_kzg_proof_batch(bl, cs[b * n_:(b + 1) * n_], ps[b * n_:(b + 1) * n_], ost))
+            except O.OracleError:
+                out.append(None)
+        return out
+
+    handles = [st] + [KzgSettings.from_tau_g2(tau_g2) for _ in range(2)]
+    pipe = PipelinedVerifier([HipBackend(h) for h in handles], None, "cpu", (1, 0, 1))
+    ptrs = lambda n_: (d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n_)
+    plan = [(1, 12), (6, 5), (1, 40), (2, 20), (1, 9)]  # fresh handles see n = 1 groups first
+    got = pipe.run([(ptrs(n_), B_) for n_, B_ in plan])
+    for (n_, B_), g in zip(plan, got):
+        assert g == want(n_, B_), (n_, B_)
+    assert got[1] == [True, False, None, None, True]
+    assert got[2].count(None) == 2 and got[2].count(False) == 1
+
+
+def test_finish_without_matching_group_is_rejected(settings):
+    """kzg_shard_finish_launch with partials == NULL pairs the handle's OWN phase-2 sums: without a group in flight, or
+    with another batch count, it is a caller error - not a silent pairing of whatever the buffers hold."""
+    import ctypes as C
+    from kzg_rs_amd.distributed import HipBackend
+    st = KzgSettings.load_trusted_setup_file()
+    HipBackend(st)  # declares the argtypes
+    assert api.lib().kzg_shard_finish_launch(None, 1, 3, st._h) == api.KZG_BADARGS

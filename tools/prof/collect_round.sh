@@ -1,24 +1,25 @@
 #!/bin/bash
 # Collect the profile set of a round on the GPU box (run through gpurun from the repo root):
 #   tools/prof/collect_round.sh <tag> [group]
-# 1. rocprofv3 --kernel-trace --stats of the default bench.py            -> gpurun_out/<tag>_stats/
-# 2. PMC passes (each in its own run; single stream so dispatches do not overlap; one launch group):
+# 1. rocprofv3 --kernel-trace --stats of THE DRIVER'S COMMAND (python3 bench.py --gpus 1 --steps 20 --warmup 5)
+#                                                                          -> gpurun_out/<tag>_stats/
+# 2. PMC passes (each in its own run; single stream so dispatches do not overlap; ONE launch group of the bench's size):
 #      FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
-#    -> gpurun_out/<tag>_pmc_*/ ; tools/prof/pmc_to_json.py turns them into profiles/<tag>_pmc.json
-# 3. bench.py itself (with cpu_baseline)                                  -> gpurun_out/<tag>_bench.json
+#    -> gpurun_out/<tag>_pmc_*/ ; tools/prof/pmc_to_json.py turns them into gpurun_out/<tag>_pmc.json
+# 3. the same command itself (with cpu_baseline)                            -> gpurun_out/<tag>_bench.json
 set -u
-tag=$1; group=${2:-128}
+tag=$1; group=${2:-256}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 rm -rf gpurun_out/${tag}_stats; mkdir -p gpurun_out/${tag}_stats
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -o run --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -o run --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${tag}_stats.log 2>&1
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
     i=$((i+1))
     out=gpurun_out/${tag}_pmc_$i
     rm -rf $out; mkdir -p $out
-    KZG_SINGLE_STREAM=1 KZG_PMC_CALIBRATE=1 rocprofv3 --pmc $ctrs --kernel-trace -d $out -o run --output-format csv -- python3 bench.py --no-cpu-baseline --group $group --inflight 1 --steps $group --warmup 0 > $out.log 2>&1
+    KZG_SINGLE_STREAM=1 KZG_PMC_CALIBRATE=1 rocprofv3 --pmc $ctrs --kernel-trace -d $out -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-latency --group $group --inflight 1 --steps 1 --warmup 0 > $out.log 2>&1
 done
 python3 tools/prof/pmc_to_json.py gpurun_out/${tag}_pmc $group > gpurun_out/${tag}_pmc.json
-python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-tail -1 gpurun_out/${tag}_bench.json | cut -c1-300
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+tail -1 gpurun_out/${tag}_bench.json | cut -c1-400

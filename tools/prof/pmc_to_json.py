@@ -1,7 +1,9 @@
 """Merge the PMC passes of tools/prof/collect_round.sh into one JSON: per kernel, the counters of its largest dispatch
 (one launch group), HBM bytes corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 on gfx950: 128-byte requests
-are tallied at 64 bytes; WRITE_SIZE exact), with the correction checked in the same run on a 128 MiB device copy
-(bench.py under KZG_PMC_CALIBRATE=1)."""
+are tallied at 64 bytes; WRITE_SIZE exact), with the correction checked in the same run on a known-size dispatch:
+bench.py under KZG_PMC_CALIBRATE=1 runs ONE elementwise kernel that reads 128 MiB and writes 128 MiB (the only
+vectorized_elementwise_kernel of that grid in the process; a hipMemcpy would be ambiguous - device-to-host copies of the
+records use the same blit kernel and grid).  Expected: FETCH_SIZE ~ 65 536 KB (x2 = 131 072), WRITE_SIZE = 131 072 KB."""
 import csv, glob, json, sys
 
 prefix, group = sys.argv[1], int(sys.argv[2])
@@ -24,11 +26,11 @@ for d in sorted(glob.glob(prefix + "_*")):
         e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     for name, disp in per.items():
         did, v = max(disp.items(), key=lambda kv: (kv[1]["grid"], kv[1]["ms"] or 0))
-        if "copyBuffer" in name:
-            # calibration: the 128 MiB copy is the largest copy
+        if "vectorized_elementwise_kernel" in name:
+            # calibration: the 128 MiB -> 128 MiB elementwise add is the largest dispatch of this kernel
             for k, x in v.items():
                 if k in ("FETCH_SIZE", "WRITE_SIZE"):
-                    calib[k + "_KB_for_128MiB_copy"] = x
+                    calib[k + "_KB_for_128MiB_read_128MiB_write"] = x
             continue
         if not name.startswith("kzg::") and not name.startswith("k_"):
             continue
@@ -46,8 +48,8 @@ for name, o in kern.items():
     if "FETCH_SIZE" in o and "WRITE_SIZE" in o:
         o["hbm_bytes_corrected"] = round(2 * o["FETCH_SIZE"] * 1024 + o["WRITE_SIZE"] * 1024)
 print(json.dumps({
-    "method": "rocprofv3 --pmc, one counter set per run, KZG_SINGLE_STREAM=1, bench.py --group %d --inflight 1 --steps %d: one "
+    "method": "rocprofv3 --pmc, one counter set per run, KZG_SINGLE_STREAM=1, bench.py --group %d --inflight 1 --steps 1 --warmup 0: one "
               "launch group of %d batches x 1024 blobs; values are per launch of the kernel (its largest dispatch). FETCH_SIZE / "
               "WRITE_SIZE in KB as reported; hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
-              "MI355X_MICROARCH.md HBM section)." % (group, group, group),
+              "MI355X_MICROARCH.md HBM section); calibration = the same counters on a dispatch that reads 128 MiB and writes 128 MiB." % (group, group),
     "blobs_per_launch": 1024 * group, "calibration": calib, "kernels": kern}, indent=1))
