@@ -32,11 +32,12 @@ def build(force=False, verbose=False):
         subprocess.check_call([sys.executable, gens[1]])
     slp_dir = os.path.join(HERE, "slp")
     slp_src = [os.path.join(slp_dir, f) for f in ("trace.py", "schedule.py", "gen_pairing.py")]
-    if force or _newer(os.path.join(data, "slp_verify.bin"), slp_src) or _newer(os.path.join(data, "slp_prep.bin"), slp_src):
+    slp_src.append(os.path.join(slp_dir, "schedule2.py"))
+    if force or any(_newer(os.path.join(data, "slp_%s.bin" % nm), slp_src) for nm in ("verify", "prep", "verify2")):
         subprocess.check_call([sys.executable, "-m", "kzg_rs_amd.slp.gen_pairing"], cwd=ROOT)
     # 2. the library
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(data, "slp_prep.bin"),
-                                                               os.path.join(data, "slp_verify.bin"),
+                                                               os.path.join(data, "slp_verify.bin"), os.path.join(data, "slp_verify2.bin"),
                                                                os.path.join(ROOT, "include", "kzg_rs_amd.h")]
     if force or _newer(LIB, deps):
         cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wno-unused-result",

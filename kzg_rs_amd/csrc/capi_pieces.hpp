@@ -214,7 +214,7 @@ extern "C" KzgRet kzg_pairing_check(bool* ok, const uint8_t a[48], const uint8_t
     uint32_t* h = reinterpret_cast<uint32_t*>(w.h_buf);
     HIPCHK(hipMemcpyAsync(h, w.d_pflag, 8, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
-    if ((rc = run_program(s->verify, w.d_slp_in, s->d_prep, w.d_slp_out, 1, s->s1)) != KZG_OK) return rc;
+    if ((rc = run_verify(s, w.d_slp_in, w.d_slp_out, 1, s->s1)) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[4], s->s1));
     HIPCHK(hipMemcpyAsync(h + 2, w.d_slp_out, sizeof(Fp) * 6, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));

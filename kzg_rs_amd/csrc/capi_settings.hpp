@@ -7,7 +7,13 @@ struct DevProgram {
     void* blob = nullptr;  // device copy of the whole program
 };
 
+struct DevProgram2 {  // a latency program (slp2.hpp)
+    Slp2Program p{};
+    void* blob = nullptr;
+};
+
 constexpr size_t MAX_WORLD = 64;
+constexpr size_t LATENCY_PAIRING_MAX = 32;  // launches of up to this many pairing checks run the multi-wave latency program
 constexpr size_t MAX_BATCHES_PER_LAUNCH = 16384;
 constexpr unsigned MSM_MAX_SLICES = 32;
 constexpr size_t LATENCY_MAX_BLOBS = 4096;  // launches up to this size: CU-split stream pair + the latency MSM layout
@@ -53,6 +59,8 @@ struct KzgSettings {
     size_t n_g2 = 0;
     uint8_t g1_first[2][48] = {};     // g1_points[0], [1] of the FILE order, for the monomial-form check (build.rs:107-129)
     DevProgram prep, verify;
+    DevProgram2 verify2;            // VERIFY scheduled for one check at a time (kzg_rs_amd/slp/schedule2.py)
+    uint32_t* d_prep29 = nullptr;   // d_prep in the latency program's format (radix 2^29, 16 words per element)
     // s1 / s2: the two streams the current launch uses (challenge chain | point decode).  They point at the plain pair,
     // or - for a small launch (a single batch) - at a pair confined to disjoint halves of the CUs: the 16 two-wave
     // workgroups of the challenge chain and the 32 decode waves otherwise land on the same first CUs of every XCD and,
@@ -93,6 +101,44 @@ static KzgRet upload_program(DevProgram& dp, const unsigned char* begin, const u
     return KZG_OK;
 }
 
+static KzgRet upload_program2(DevProgram2& dp, const unsigned char* begin, const unsigned char* end) {
+    size_t len = (size_t)(end - begin);
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(begin);
+    if (len < 64 || w[0] != SLP2_MAGIC) return fail(KZG_ERROR, "embedded latency program is corrupt");
+    HIPCHK(hipMalloc(&dp.blob, len));
+    HIPCHK(hipMemcpy(dp.blob, begin, len, hipMemcpyHostToDevice));
+    Slp2Program& p = dp.p;
+    p.lanes = w[1]; p.n_slots = w[2]; p.n_steps = w[3]; p.n_const = w[4]; p.n_in = w[5]; p.n_set = w[6]; p.n_out = w[7];
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(dp.blob);
+    size_t off = 16;
+    p.consts = d + off;
+    off += (size_t)16 * p.n_const;
+    p.out_slots = d + off;
+    off += (p.n_out + 3) & ~3u;  // padded: the descriptors are read as 16-byte vectors
+    p.desc = reinterpret_cast<const Slp2Desc*>(d + off);
+    if ((off + (size_t)4 * p.lanes * p.n_steps) * 4 != len) return fail(KZG_ERROR, "embedded latency program has the wrong size");
+    if (p.lanes != 192) return fail(KZG_ERROR, "embedded latency program is not scheduled for 192 lanes");
+    return KZG_OK;
+}
+
+// the latency form: one workgroup of 3 wavefronts per instance
+static KzgRet run_program2(const DevProgram2& dp, const Fp* d_in, const uint32_t* d_set29, Fp* d_out, int instances, hipStream_t st) {
+    const size_t lds = (size_t)dp.p.n_slots * SLP2_SLOT_WORDS * 4 + (size_t)SLP2_GROUP * dp.p.lanes * sizeof(uint4);  // slots | descriptor ring
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp2_run<192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_slp2_run<192>, dim3(instances), dim3(192), lds, st, dp.p, d_in, d_set29, d_out);
+    HIPCHK(hipGetLastError());
+    return KZG_OK;
+}
+// which form runs a launch of `instances` checks: KZG_PAIRING=1 | 2 forces the one-wave / the latency program (A/B, cross-check)
+static bool pairing_latency_form(size_t instances) {
+    static const int forced = [] {
+        const char* e = getenv("KZG_PAIRING");
+        return e ? atoi(e) : 0;
+    }();
+    return forced == 2 || (forced != 1 && instances <= LATENCY_PAIRING_MAX);
+}
+static KzgRet run_verify(const KzgSettings* s, const Fp* d_in, Fp* d_out, int instances, hipStream_t st);
+
 static KzgRet run_program(const DevProgram& dp, const Fp* d_in, const Fp* d_set, Fp* d_out, int instances, hipStream_t st) {
     size_t lds = (size_t)dp.p.n_slots * 48 + (size_t)2 * SLP_GROUP * dp.p.lanes * sizeof(uint2);  // slots | descriptor ring
     if (dp.p.lanes == 64) {
@@ -104,6 +150,12 @@ static KzgRet run_program(const DevProgram& dp, const Fp* d_in, const Fp* d_set,
     }
     HIPCHK(hipGetLastError());
     return KZG_OK;
+}
+
+// the pairing check of `instances` (A, B) pairs against the handle's prepared lines, in the form that suits the launch size
+static KzgRet run_verify(const KzgSettings* s, const Fp* d_in, Fp* d_out, int instances, hipStream_t st) {
+    if (pairing_latency_form((size_t)instances)) return run_program2(s->verify2, d_in, s->d_prep29, d_out, instances, st);
+    return run_program(s->verify, d_in, s->d_prep, d_out, instances, st);
 }
 
 static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]);
@@ -151,6 +203,7 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
     KzgRet rc;
     if ((rc = upload_program(s->prep, kzg_slp_prep_begin, kzg_slp_prep_end)) != KZG_OK) return rc;
     if ((rc = upload_program(s->verify, kzg_slp_verify_begin, kzg_slp_verify_end)) != KZG_OK) return rc;
+    if ((rc = upload_program2(s->verify2, kzg_slp_verify2_begin, kzg_slp_verify2_end)) != KZG_OK) return rc;
     // decompress [tau]G2 on the device, then prepare the lines of [tau]G2 and of the generator
     DevTmp t_bytes, t_flag, t_q;  // released on every path out of this function
     HIPCHK(hipMalloc(&t_bytes.p, 96));
@@ -169,6 +222,12 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
     HIPCHK(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipMemcpyAsync(s->d_tau4, d_q, sizeof(Fp) * 4, hipMemcpyDeviceToDevice, s->s1));
     if ((rc = run_program(s->prep, d_q, nullptr, s->d_prep, 2, s->s1)) != KZG_OK) return rc;
+    {  // the same lines for the latency program
+        const int np = (int)(2 * s->prep.p.n_out);
+        HIPCHK(hipMalloc(&s->d_prep29, (size_t)64 * np));
+        hipLaunchKernelGGL(k_fp_to_fp29mem, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, s->s1, s->d_prep, s->d_prep29, np);
+        HIPCHK(hipGetLastError());
+    }
     {  // multiples of the generator (msm.hpp): the same for every batch
         DevTmp t_g, t_gf, t_gm;
         HIPCHK(hipMalloc(&t_g.p, sizeof(G1Aff)));
@@ -195,7 +254,8 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
     }
     HIPCHK(hipStreamSynchronize(s->s1));
     if (flag != G1_OK) return fail(KZG_BAD_SETUP, "g2_points[1] is not a valid (finite) compressed G2 point");
-    if (s->verify.p.n_set != 2 * s->prep.p.n_out || s->verify.p.n_in != 6 || s->prep.p.n_in != 4)
+    if (s->verify.p.n_set != 2 * s->prep.p.n_out || s->verify.p.n_in != 6 || s->prep.p.n_in != 4 || s->verify2.p.n_set != s->verify.p.n_set ||
+        s->verify2.p.n_in != 6 || s->verify2.p.n_out != s->verify.p.n_out)
         return fail(KZG_ERROR, "embedded SLP programs do not fit together");
     return KZG_OK;
 }
@@ -330,7 +390,7 @@ static void ws_free(Workspace& w) {
 extern "C" void kzg_settings_free(KzgSettings* s) {
     if (!s) return;
     ws_free(s->ws);
-    void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_eval_scratch, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob};
+    void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_eval_scratch, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob, s->verify2.blob, s->d_prep29};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (auto& e : s->ev)

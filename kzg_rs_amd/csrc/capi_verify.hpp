@@ -425,7 +425,7 @@ static KzgRet finish_launch_locked(const uint8_t* partials, size_t world, size_t
     hipLaunchKernelGGL(k_jac_to_slp, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_ab, w.d_slp_in);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[4], s->s1));
-    KzgRet rc = run_program(s->verify, w.d_slp_in, s->d_prep, w.d_slp_out, (int)B, s->s1);
+    KzgRet rc = run_verify(s, w.d_slp_in, w.d_slp_out, (int)B, s->s1);
     if (rc != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[9], s->s1));
     HIPCHK(hipMemcpyAsync(w.h_buf + w.off_out, w.d_slp_out, sizeof(Fp) * 6 * B, hipMemcpyDeviceToHost, s->s1));

@@ -21,6 +21,7 @@
 #include "g1.hpp"
 #include "msm.hpp"
 #include "slp.hpp"
+#include "slp2.hpp"
 
 using namespace kzg;
 
@@ -32,9 +33,12 @@ __asm__(".section .rodata\n"
         ".global kzg_slp_prep_end\nkzg_slp_prep_end:\n"
         ".balign 16\n.global kzg_slp_verify_begin\nkzg_slp_verify_begin:\n.incbin \"" KZG_DATA_DIR "/slp_verify.bin\"\n"
         ".global kzg_slp_verify_end\nkzg_slp_verify_end:\n"
+        ".balign 16\n.global kzg_slp_verify2_begin\nkzg_slp_verify2_begin:\n.incbin \"" KZG_DATA_DIR "/slp_verify2.bin\"\n"
+        ".global kzg_slp_verify2_end\nkzg_slp_verify2_end:\n"
         ".text\n");
 #endif
-extern "C" const unsigned char kzg_slp_prep_begin[], kzg_slp_prep_end[], kzg_slp_verify_begin[], kzg_slp_verify_end[];
+extern "C" const unsigned char kzg_slp_prep_begin[], kzg_slp_prep_end[], kzg_slp_verify_begin[], kzg_slp_verify_end[], kzg_slp_verify2_begin[],
+    kzg_slp_verify2_end[];
 
 // The library is ONE translation unit (device code and the host ABI share types and inline helpers); its parts, in
 // dependency order:

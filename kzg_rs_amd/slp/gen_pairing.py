@@ -24,7 +24,9 @@ Mathematics (checked numerically against an independent model in tests/test_slp_
 import os
 import sys
 
+from . import trace
 from .schedule import schedule
+from .schedule2 import schedule2
 from .trace import F2, F6, F12, Graph, f12_one, f2_const, P
 
 X_ABS = 0xD201000000010000
@@ -140,6 +142,20 @@ def build_verify(test_inputs=None, test_prep=None):
     return g
 
 
+LATENCY_LANES = 192  # three wavefronts: every product level of the schoolbook towers fits one step
+
+
+def build_verify_latency(test_inputs=None, test_prep=None):
+    """The same check traced with the schoolbook tower formulas (trace.TOWER): 2.2x the products, a quarter of the
+    dependent additions - the graph the latency scheduler (schedule2.py) is given."""
+    old = trace.TOWER
+    trace.TOWER = "schoolbook"
+    try:
+        return build_verify(test_inputs, test_prep)
+    finally:
+        trace.TOWER = old
+
+
 def main(lanes=64):
     os.makedirs(DATA, exist_ok=True)
     for name, graph, n_inst in (("prep", build_prep(), 4), ("verify", build_verify(), 6)):
@@ -148,6 +164,11 @@ def main(lanes=64):
         with open(path, "wb") as f:
             f.write(blob)
         print(name, stats)
+    # VERIFY once more for a single check at a time: several wavefronts per instance, radix-2^29 lazy arithmetic
+    blob, stats = schedule2(build_verify_latency(), lanes=LATENCY_LANES, n_instance_inputs=6)
+    with open(os.path.join(DATA, "slp_verify2.bin"), "wb") as f:
+        f.write(blob)
+    print("verify2", stats)
 
 
 if __name__ == "__main__":

@@ -17,6 +17,13 @@ P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB1
 # op kinds
 IN, CONST, MUL, ADD, SUB = "in", "const", "mul", "add", "sub"
 
+# Tower multiplication formulas.  "karatsuba": fewest Fp products (3 per Fp2, 6 Fp2 per Fp6, 3 Fp6 per Fp12 product) at
+# the price of ~11 dependent additions between two product levels - right for the one-wavefront interpreter whose
+# throughput matters (many instances side by side).  "schoolbook": 4 / 9 / 4 products, no pre-additions and short sums
+# after them (4 dependent binary additions per level, 2 after 4-input fusion) - right for the latency interpreter
+# (csrc/slp2.hpp), where the dependency depth is the running time and lanes are plentiful.
+TOWER = "karatsuba"
+
 
 class Graph:
     def __init__(self):
@@ -144,6 +151,8 @@ class F2:
         return F2(self.c0, -self.c1)
 
     def __mul__(self, o):
+        if TOWER == "schoolbook":
+            return F2(self.c0 * o.c0 - self.c1 * o.c1, self.c0 * o.c1 + self.c1 * o.c0)
         # Karatsuba: 3 Fp products
         t0 = self.c0 * o.c0
         t1 = self.c1 * o.c1
@@ -152,6 +161,8 @@ class F2:
 
     def sqr(self):
         m = self.c0 * self.c1
+        if TOWER == "schoolbook":
+            return F2(self.c0 * self.c0 - self.c1 * self.c1, m.dbl())
         return F2((self.c0 + self.c1) * (self.c0 - self.c1), m.dbl())
 
     def mul_fp(self, k):
@@ -201,6 +212,8 @@ class F6:
 
     def __mul__(self, o):
         a0, a1, a2, b0, b1, b2 = self.c0, self.c1, self.c2, o.c0, o.c1, o.c2
+        if TOWER == "schoolbook":
+            return F6(a0 * b0 + (a1 * b2 + a2 * b1).mul_xi(), a0 * b1 + a1 * b0 + (a2 * b2).mul_xi(), a0 * b2 + a1 * b1 + a2 * b0)
         v0, v1, v2 = a0 * b0, a1 * b1, a2 * b2
         c0 = ((a1 + a2) * (b1 + b2) - v1 - v2).mul_xi() + v0
         c1 = (a0 + a1) * (b0 + b1) - v0 - v1 + v2.mul_xi()
@@ -215,6 +228,8 @@ class F12:
         self.c0, self.c1 = c0, c1
 
     def __mul__(self, o):
+        if TOWER == "schoolbook":
+            return F12(self.c0 * o.c0 + (self.c1 * o.c1).mul_v(), self.c0 * o.c1 + self.c1 * o.c0)
         t0 = self.c0 * o.c0
         t1 = self.c1 * o.c1
         m = (self.c0 + self.c1) * (o.c0 + o.c1) - t0 - t1
@@ -222,6 +237,8 @@ class F12:
 
     def sqr(self):
         ab = self.c0 * self.c1
+        if TOWER == "schoolbook":
+            return F12(self.c0 * self.c0 + (self.c1 * self.c1).mul_v(), ab.dbl())
         m = (self.c0 + self.c1) * (self.c0 + self.c1.mul_v()) - ab - ab.mul_v()
         return F12(m, ab.dbl())
 

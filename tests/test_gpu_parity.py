@@ -459,6 +459,51 @@ def test_pairing_check(settings, osettings):
     assert outcomes == {True, False}
 
 
+@pytest.mark.parametrize("form", ["1", "2"])
+def test_pairing_forms_in_child_process(form):
+    """Both pairing programs on the GPU, each forced for a whole process (KZG_PAIRING=1: the one-wave throughput program
+    of slp.hpp; 2: the three-wave latency program of slp2.hpp - radix-2^29 lazy arithmetic, schoolbook towers): the same
+    pairing checks (both outcomes, identity inputs) and a launch group of batches, against the oracle.  The default
+    process picks by launch size, so without this test each form would see only one side of the threshold."""
+    import subprocess
+    import sys
+    code = (
+        "import random, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "import oracle_lib as O\n"
+        "from kzg_rs_amd import api, synth\n"
+        "G1_GEN = bytes.fromhex('97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb')\n"
+        "G1_INF = bytes([0xC0]) + bytes(47)\n"
+        "tau, tau_g2 = synth.synthetic_setup()\n"
+        "R = synth.R\n"
+        "st = api.KzgSettings.from_tau_g2(tau_g2)\n"
+        "ost = O.Settings.from_tau_g2(tau_g2)\n"
+        "rng = random.Random(5)\n"
+        "res = []\n"
+        "for i in range(12):\n"
+        "    k = rng.randrange(1, R)\n"
+        "    a = O.g1_mul(G1_GEN, k.to_bytes(32, 'big'))\n"
+        "    kb = k * tau %% R if i %% 3 else (k * tau + 1) %% R\n"
+        "    b = O.g1_mul(G1_GEN, kb.to_bytes(32, 'big'))\n"
+        "    want = O.pairings_verify(a, ost.g2(1), b, ost.g2(0))\n"
+        "    res.append(api.pairing_check(a, b, st) == want == bool(i %% 3))\n"
+        "for a, b in ((G1_INF, G1_INF), (G1_GEN, G1_INF), (G1_INF, G1_GEN)):\n"
+        "    res.append(api.pairing_check(a, b, st) == O.pairings_verify(a, ost.g2(1), b, ost.g2(0)))\n"
+        "n, B = 5, 40\n"
+        "blobs, cs, ps, st2 = synth.make_valid_batch(n * B, seed=91)\n"
+        "ps = list(ps)\n"
+        "for b in (3, 17, 39): ps[b * n + 2] = O.g1_add(ps[b * n + 2], G1_GEN)\n"
+        "d_b = torch.from_numpy(blobs).cuda(); d_c = torch.frombuffer(bytearray(b''.join(cs)), dtype=torch.uint8).cuda()\n"
+        "d_p = torch.frombuffer(bytearray(b''.join(ps)), dtype=torch.uint8).cuda(); torch.cuda.synchronize()\n"
+        "got = api.verify_blob_kzg_proof_batches_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, B, st2)\n"
+        "res.append(got == [b not in (3, 17, 39) for b in range(B)])\n"
+        "print('RESULT', all(res), len(res))\n" % (O.ROOT, os.path.join(O.ROOT, "tests")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_PAIRING=form), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "RESULT True 16" in out.stdout, out.stdout[-2000:]
+
+
 # ------------------------------------------------------------------ synthetic batches under a known tau
 def test_synthetic_batch_vs_oracle():
     from kzg_rs_amd import synth
