@@ -108,7 +108,8 @@ static KzgRet upload_program2(DevProgram2& dp, const unsigned char* begin, const
     HIPCHK(hipMalloc(&dp.blob, len));
     HIPCHK(hipMemcpy(dp.blob, begin, len, hipMemcpyHostToDevice));
     Slp2Program& p = dp.p;
-    p.lanes = w[1]; p.n_slots = w[2]; p.n_steps = w[3]; p.n_const = w[4]; p.n_in = w[5]; p.n_set = w[6]; p.n_out = w[7];
+    p.lanes = w[1]; p.n_slots = w[2]; p.n_steps = w[3]; p.n_const = w[4]; p.n_in = w[5]; p.n_set = w[6]; p.n_out = w[7]; p.n_load_steps = w[8];
+    if (p.n_load_steps >= p.n_steps) return fail(KZG_ERROR, "embedded latency program has no compute steps");
     const uint32_t* d = reinterpret_cast<const uint32_t*>(dp.blob);
     size_t off = 16;
     p.consts = d + off;
@@ -117,17 +118,23 @@ static KzgRet upload_program2(DevProgram2& dp, const unsigned char* begin, const
     off += (p.n_out + 3) & ~3u;  // padded: the descriptors are read as 16-byte vectors
     p.desc = reinterpret_cast<const Slp2Desc*>(d + off);
     if ((off + (size_t)4 * p.lanes * p.n_steps) * 4 != len) return fail(KZG_ERROR, "embedded latency program has the wrong size");
-    if (p.lanes != 192) return fail(KZG_ERROR, "embedded latency program is not scheduled for 192 lanes");
+    if (p.lanes != 128 && p.lanes != 192 && p.lanes != 256) return fail(KZG_ERROR, "embedded latency program: 128, 192 or 256 lanes expected");
     return KZG_OK;
 }
 
-// the latency form: one workgroup of 3 wavefronts per instance
-static KzgRet run_program2(const DevProgram2& dp, const Fp* d_in, const uint32_t* d_set29, Fp* d_out, int instances, hipStream_t st) {
-    const size_t lds = (size_t)dp.p.n_slots * SLP2_SLOT_WORDS * 4 + (size_t)SLP2_GROUP * dp.p.lanes * sizeof(uint4);  // slots | descriptor ring
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp2_run<192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_slp2_run<192>, dim3(instances), dim3(192), lds, st, dp.p, d_in, d_set29, d_out);
+// the latency form: one workgroup of 2 to 4 wavefronts per instance (what the program was scheduled for)
+template <int LANES>
+static KzgRet launch_program2(const DevProgram2& dp, const Fp* d_in, const uint32_t* d_set29, Fp* d_out, int instances, hipStream_t st) {
+    const size_t lds = (size_t)dp.p.n_slots * SLP2_SLOT_WORDS * 4 + (size_t)SLP2_GROUP * LANES * sizeof(uint4);  // slots | descriptor ring
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp2_run<LANES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_slp2_run<LANES>, dim3(instances), dim3(LANES), lds, st, dp.p, d_in, d_set29, d_out);
     HIPCHK(hipGetLastError());
     return KZG_OK;
+}
+static KzgRet run_program2(const DevProgram2& dp, const Fp* d_in, const uint32_t* d_set29, Fp* d_out, int instances, hipStream_t st) {
+    return dp.p.lanes == 128 ? launch_program2<128>(dp, d_in, d_set29, d_out, instances, st)
+         : dp.p.lanes == 192 ? launch_program2<192>(dp, d_in, d_set29, d_out, instances, st)
+                             : launch_program2<256>(dp, d_in, d_set29, d_out, instances, st);
 }
 // which form runs a launch of `instances` checks: KZG_PAIRING=1 | 2 forces the one-wave / the latency program (A/B, cross-check)
 static bool pairing_latency_form(size_t instances) {

@@ -33,7 +33,7 @@ struct Slp2Desc {
     uint32_t w0, w1, w2, w3;
 };
 struct Slp2Program {
-    uint32_t lanes, n_slots, n_steps, n_const, n_in, n_set, n_out;
+    uint32_t lanes, n_slots, n_steps, n_const, n_in, n_set, n_out, n_load_steps;
     const uint32_t* consts;     // [n_const][16]
     const uint32_t* out_slots;  // [n_out]
     const Slp2Desc* desc;       // [n_steps][lanes]
@@ -88,9 +88,9 @@ __device__ __forceinline__ void slp2_store(uint32_t* slots, uint32_t s, const Fp
     *reinterpret_cast<uint2*>(q + 12) = make_uint2(v.l[12], v.l[13]);
 }
 
-// one step for one lane.  The three kinds are wave-uniform branches (the kind is replicated into every descriptor).
-__device__ __forceinline__ void slp2_exec(uint32_t* slots, const uint4 d, const Slp2Program& prog, const Fp* my_in,
-                                          const uint32_t* __restrict__ settings_inputs) {
+// one LIN / MUL step for one lane.  The kind is replicated into every descriptor: a wave-uniform branch.  No global memory
+// access in here: the step loop then carries no vmcnt wait, and the descriptor prefetch really runs ahead.
+__device__ __forceinline__ void slp2_exec(uint32_t* slots, const uint4 d) {
     const uint32_t kind = __builtin_amdgcn_readfirstlane(d.w >> 30);
     const bool active = (d.w >> 29) & 1u;
     const uint32_t dst = d.z & 0xffffu;
@@ -99,31 +99,35 @@ __device__ __forceinline__ void slp2_exec(uint32_t* slots, const uint4 d, const 
         const Fp29 b1 = slp2_load(slots, d.y & 0xffffu), b2 = slp2_load(slots, d.y >> 16);
         const Fp29 r = slp2_mul(a1, a2, b1, b2);
         if (active) slp2_store(slots, dst, r);
-    } else if (kind == SLP2_LIN) {
+    } else {
         const Fp29 x0 = slp2_load(slots, d.x & 0xffffu), x1 = slp2_load(slots, d.x >> 16);
         const Fp29 x2 = slp2_load(slots, d.y & 0xffffu), x3 = slp2_load(slots, d.y >> 16);
         const Fp29 bias = slp2_load(slots, d.z >> 16);
         const Fp29 r = slp2_lin(x0, x1, x2, x3, bias, (d.w >> 16) & 15u);
         if (active) slp2_store(slots, dst, r);
-    } else {
-        if (active) {
-            const uint32_t src = (d.w >> 26) & 7u, idx = d.w & 0xffffu;
-            Fp29 r;
-            if (src == SLP2_SRC_INST) {
-                r = fp29_mul(fp29_from_words(my_in[idx].l), fp29_const(cp29::FP29_FROM_STD));  // 12x32 Montgomery -> x R''
-            } else {
-                const uint32_t* q = (src == SLP2_SRC_CONST ? prog.consts : settings_inputs) + 16 * (size_t)idx;
-                const uint4 a = *reinterpret_cast<const uint4*>(q), b = *reinterpret_cast<const uint4*>(q + 4), c = *reinterpret_cast<const uint4*>(q + 8);
-                const uint2 e = *reinterpret_cast<const uint2*>(q + 12);
-                r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-                r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-                r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
-                r.l[12] = e.x; r.l[13] = e.y;
-            }
-            slp2_store(slots, dst, r);
-        }
     }
     __syncthreads();  // step boundary: the next step's reads may come from another wavefront's writes
+}
+
+// one LOAD step for one lane (the first prog.n_load_steps steps of a program)
+__device__ __forceinline__ void slp2_exec_load(uint32_t* slots, const uint4 d, const Slp2Program& prog, const Fp* my_in,
+                                               const uint32_t* __restrict__ settings_inputs) {
+    if ((d.w >> 29) & 1u) {
+        const uint32_t src = (d.w >> 26) & 7u, idx = d.w & 0xffffu;
+        Fp29 r;
+        if (src == SLP2_SRC_INST) {
+            r = fp29_mul(fp29_from_words(my_in[idx].l), fp29_const(cp29::FP29_FROM_STD));  // 12x32 Montgomery -> x R''
+        } else {
+            const uint32_t* q = (src == SLP2_SRC_CONST ? prog.consts : settings_inputs) + 16 * (size_t)idx;
+            const uint4 a = *reinterpret_cast<const uint4*>(q), b = *reinterpret_cast<const uint4*>(q + 4), c = *reinterpret_cast<const uint4*>(q + 8);
+            const uint2 e = *reinterpret_cast<const uint2*>(q + 12);
+            r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+            r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+            r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
+            r.l[12] = e.x; r.l[13] = e.y;
+        }
+        slp2_store(slots, d.z & 0xffffu, r);
+    }
 }
 
 // inputs: [instances][n_in] Fp (12x32 Montgomery, as the MSM leaves them); settings_inputs: [n_set][16] words (radix 2^29,
@@ -131,45 +135,51 @@ __device__ __forceinline__ void slp2_exec(uint32_t* slots, const uint4 d, const 
 // 0 mod p and a 1 otherwise (the host only asks "all zero?").
 // Descriptor streaming as in slp.hpp: a group of steps ahead into registers, parked in a per-lane LDS ring at the group
 // boundary, read back one step ahead.  Dynamic LDS = slots | ring.
+// (one workgroup per CU whatever happens - the LDS footprint; a whole SIMD's registers are there for the taking, and the
+// prefetched descriptors must stay in them: spilled, the loads would be waited for at once)
 template <int LANES>
-__global__ __launch_bounds__(LANES) void k_slp2_run(Slp2Program prog, const Fp* __restrict__ inputs, const uint32_t* __restrict__ settings_inputs,
+__global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_slp2_run(Slp2Program prog, const Fp* __restrict__ inputs, const uint32_t* __restrict__ settings_inputs,
                                                     Fp* __restrict__ outputs) {
     extern __shared__ __attribute__((aligned(16))) uint32_t slots2[];
-    const uint32_t tid = threadIdx.x, inst = blockIdx.x, n_steps = prog.n_steps;
+    const uint32_t tid = threadIdx.x, inst = blockIdx.x, n_steps = prog.n_steps - prog.n_load_steps;
     uint4* ring = reinterpret_cast<uint4*>(slots2 + (size_t)SLP2_SLOT_WORDS * prog.n_slots);  // [SLP2_GROUP][LANES]
-    const uint4* desc = reinterpret_cast<const uint4*>(prog.desc);
     const Fp* my_in = inputs + (size_t)inst * prog.n_in;
-    const uint32_t last = n_steps - 1;
     if (tid < SLP2_SLOT_WORDS) slots2[tid] = 0u;  // slot 0: the constant zero
-    uint4 r[SLP2_GROUP];
+    // the LOAD prefix (a handful of steps; independent of one another: one barrier after the last)
+    for (uint32_t st = 0; st < prog.n_load_steps; st++)
+        slp2_exec_load(slots2, reinterpret_cast<const uint4*>(prog.desc)[(size_t)st * LANES + tid], prog, my_in, settings_inputs);
+    const uint4* desc = reinterpret_cast<const uint4*>(prog.desc) + (size_t)prog.n_load_steps * LANES;  // the LIN / MUL steps
+    const uint32_t last = n_steps - 1;
+    // the first group's descriptors go straight into the ring; from then on a group is requested while the one before it
+    // runs.  Named registers, not an array: the compiler keeps an indexed array of loaded values in scratch, and a
+    // scratch store waits for its load on the spot - which is the opposite of a prefetch.
+    static_assert(SLP2_GROUP == 8, "eight named prefetch registers below");
+#define SLP2_DESC_AT(k) desc[(size_t)((base_next + (k)) < last ? (base_next + (k)) : last) * LANES + tid]
+    {
+        const uint32_t base_next = 0;
 #pragma unroll
-    for (int k = 0; k < SLP2_GROUP; k++) {
-        const uint32_t st = (uint32_t)k < last ? (uint32_t)k : last;
-        ring[(size_t)k * LANES + tid] = desc[(size_t)st * LANES + tid];
+        for (int k = 0; k < SLP2_GROUP; k++) ring[(size_t)k * LANES + tid] = SLP2_DESC_AT(k);
     }
     __syncthreads();
     const uint32_t n_groups = (n_steps + SLP2_GROUP - 1) / SLP2_GROUP;
     for (uint32_t g = 0; g < n_groups; g++) {
-        const uint32_t base = g * SLP2_GROUP;
-#pragma unroll
-        for (int k = 0; k < SLP2_GROUP; k++) {  // the next group's descriptors (clamped: always SLP2_GROUP loads)
-            uint32_t st = base + SLP2_GROUP + k;
-            st = st < last ? st : last;
-            r[k] = desc[(size_t)st * LANES + tid];
-        }
+        const uint32_t base = g * SLP2_GROUP, base_next = base + SLP2_GROUP;
+        const uint4 r0 = SLP2_DESC_AT(0), r1 = SLP2_DESC_AT(1), r2 = SLP2_DESC_AT(2), r3 = SLP2_DESC_AT(3);
+        const uint4 r4 = SLP2_DESC_AT(4), r5 = SLP2_DESC_AT(5), r6 = SLP2_DESC_AT(6), r7 = SLP2_DESC_AT(7);
         const uint4* cur = ring + tid;
         const uint32_t cnt = n_steps - base < (uint32_t)SLP2_GROUP ? n_steps - base : (uint32_t)SLP2_GROUP;
         uint4 d = cur[0];
 #pragma unroll 1
         for (uint32_t k = 0; k < cnt; k++) {
             const uint4 dn = cur[(size_t)(k + 1 < (uint32_t)SLP2_GROUP ? k + 1 : k) * LANES];
-            slp2_exec(slots2, d, prog, my_in, settings_inputs);
+            slp2_exec(slots2, d);
             d = dn;
         }
         // every read of this group's ring entries has been issued (LDS is in order per wave; entries are per lane)
-#pragma unroll
-        for (int k = 0; k < SLP2_GROUP; k++) ring[(size_t)k * LANES + tid] = r[k];
+        ring[(size_t)0 * LANES + tid] = r0; ring[(size_t)1 * LANES + tid] = r1; ring[(size_t)2 * LANES + tid] = r2; ring[(size_t)3 * LANES + tid] = r3;
+        ring[(size_t)4 * LANES + tid] = r4; ring[(size_t)5 * LANES + tid] = r5; ring[(size_t)6 * LANES + tid] = r6; ring[(size_t)7 * LANES + tid] = r7;
     }
+#undef SLP2_DESC_AT
     if (tid < prog.n_out) {
         const bool z = slp2_is_zero(slp2_load(slots2, prog.out_slots[tid]));
         Fp o;
