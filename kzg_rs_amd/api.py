@@ -85,6 +85,7 @@ def lib():
         L.kzg_verify_blob_kzg_proof_batch.argtypes = [bp, u8, u8, u8, sz, vp]
         L.kzg_verify_blob_kzg_proof_batch_device.argtypes = [bp, vp, vp, vp, sz, vp]
         L.kzg_verify_blob_kzg_proof_batches_device.argtypes = [bp, u8, vp, vp, vp, sz, sz, vp]
+        L.kzg_verify_blob_kzg_proof_batches.argtypes = [bp, u8, vp, vp, vp, sz, sz, vp]
         L.kzg_compute_challenges.argtypes = [u8, u8, u8, sz, vp]
         L.kzg_evaluate_polynomials.argtypes = [u8, u8, u8, sz, vp]
         L.kzg_evaluate_polynomials_device.argtypes = [vp, vp, vp, sz, vp]
@@ -328,6 +329,16 @@ def verify_blob_kzg_proof_batches_device(d_blobs, d_commitments, d_proofs, n, n_
     err = C.create_string_buffer(n_batches)
     _chk(lib().kzg_verify_blob_kzg_proof_batches_device(ok, err, d_blobs, d_commitments, d_proofs, n, n_batches,
                                                         kzg_settings._h))
+    return [None if err.raw[b] else bool(ok[b]) for b in range(n_batches)]
+
+
+def verify_blob_kzg_proof_batches(blobs, commitments, proofs, n, n_batches, kzg_settings):
+    """The host-memory form: n_batches batches of n blobs each, back to back in host memory (bytes, or a host address as
+    an int); copies overlap verification.  Returns True / False / None (Err) per batch."""
+    ok = (C.c_bool * n_batches)()
+    err = C.create_string_buffer(n_batches)
+    ptr = lambda x: C.c_void_p(x) if isinstance(x, int) else C.cast(C.c_char_p(x), C.c_void_p)
+    _chk(lib().kzg_verify_blob_kzg_proof_batches(ok, err, ptr(blobs), ptr(commitments), ptr(proofs), n, n_batches, kzg_settings._h))
     return [None if err.raw[b] else bool(ok[b]) for b in range(n_batches)]
 
 

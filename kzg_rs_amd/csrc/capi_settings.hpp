@@ -35,6 +35,10 @@ struct Workspace {
     bool mult_affine = false;      // format of d_mult as the last decode left it
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
     uint8_t *d_stage_blobs = nullptr, *d_stage_cp = nullptr, *d_bytes = nullptr, *d_records = nullptr;
+    // host-fed stream of batches (kzg_verify_blob_kzg_proof_batches): two staging sets, each [blobs | commitments | proofs]
+    // of one chunk, filled on the copy stream while the other one is verified
+    uint8_t* d_hstage[2] = {nullptr, nullptr};
+    size_t cap_hstage = 0;  // blobs per staging set
     // pinned host mirrors
     uint8_t* h_buf = nullptr;
     size_t h_cap = 0;
@@ -71,6 +75,8 @@ struct KzgSettings {
     mutable hipStream_t s_half[2] = {nullptr, nullptr};
     mutable bool s_half_tried = false;
     hipEvent_t ev[12] = {};
+    mutable hipStream_t s_copy = nullptr;  // host -> device staging copies of the host-fed stream (made on first use)
+    mutable hipEvent_t ev_copy[2] = {nullptr, nullptr};
     mutable std::mutex mu;
     mutable Workspace ws;
     mutable uint32_t* d_eval_scratch = nullptr;  // between the three evaluation kernels (launch_evaluate)
@@ -387,7 +393,7 @@ extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
                     w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_mult, w.d_jtmp, w.d_ktime, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
-                    w.d_records};
+                    w.d_records, w.d_hstage[0], w.d_hstage[1]};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w.h_buf) (void)hipHostFree(w.h_buf);
@@ -402,7 +408,9 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
         if (p) (void)hipFree(p);
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t st : {s->s_plain[0], s->s_plain[1], s->s_half[0], s->s_half[1]})
+    for (auto& e : s->ev_copy)
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {s->s_plain[0], s->s_plain[1], s->s_half[0], s->s_half[1], s->s_copy})
         if (st) (void)hipStreamDestroy(st);
     delete s;
 }

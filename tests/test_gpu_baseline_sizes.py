@@ -137,6 +137,92 @@ def test_config5_shard_size_single_batch():
         run(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n)
 
 
+def _partial_to_affine(part144):
+    """144 bytes of a partial sum (Jacobian X, Y, Z as 12 x u32 little-endian Montgomery limbs, radix 2^384) -> affine
+    (x, y) integers, or None for the identity."""
+    P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    rinv = pow(1 << 384, -1, P)
+    X, Y, Z = (int.from_bytes(part144[48 * i: 48 * i + 48], "little") * rinv % P for i in range(3))
+    if Z == 0:
+        return None
+    zi = pow(Z, -1, P)
+    return X * zi * zi % P, Y * zi * zi * zi % P
+
+
+def test_config5_full_shard_of_262144_blob_batch():
+    """BASELINE configs[4] at its real sizes, one rank at a time: ONE batch of 262 144 blobs sharded over 8 GPUs = 32 768
+    blobs (4 GiB) per rank.  The test box has one GPU, so it plays every rank in turn on the same shard contents (1 024
+    distinct valid tuples tiled x32 in a random order; the global transcript is that shard's records tiled x8):
+      * phase 1 on the full 32 768-blob shard - its records equal the oracle's (z, y) on a sample of blobs;
+      * the batch challenge of the 42 MB transcript (kzg_batch_challenges, hashed once) equals the oracle's compute_r;
+      * phase 2 with n_total = 262 144 and offset = k 32 768 for k = 0 and k = 7: the partial sums (A_k, B_k) equal the
+        oracle's MSMs with the scalars r^(offset + i) (collapsed onto the 1 024 distinct points);
+      * all 8 partials folded + one pairing: true; with rank 5's B replaced by rank 4's B: false."""
+    import numpy as np
+    import torch
+    from kzg_rs_amd import synth
+    from kzg_rs_amd.distributed import HipBackend
+    P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    G1_GEN = bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+    m, tile, world = 1024, 32, 8
+    n_local, n_total = m * tile, m * tile * world
+    blobs, cs, ps, st = synth.make_valid_batch(m, seed=56, chunk=1024)
+    ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])
+    rng = np.random.Generator(np.random.PCG64(5))
+    order = np.concatenate([rng.permutation(m) for _ in range(tile)])  # shard position i holds distinct tuple order[i]
+    idx = torch.from_numpy(order).cuda()
+    d_blobs = torch.from_numpy(blobs).cuda()[idx].contiguous()  # 4 GiB
+    d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).cuda().view(m, 48)[idx].contiguous()
+    d_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).cuda().view(m, 48)[idx].contiguous()
+    torch.cuda.synchronize()
+    be = HipBackend(st)
+    recs = be.phase1((d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n_local))
+    assert len(recs) == 160 * n_local
+    for i in (0, 1, 777, n_local - 1):
+        j = int(order[i])
+        z = O.compute_challenge(blobs[j].tobytes(), cs[j])
+        y = O.evaluate_polynomial_in_evaluation_form(blobs[j].tobytes(), z, ost)
+        assert recs[160 * i: 160 * i + 160] == cs[j] + z[::-1] + y[::-1] + ps[j]
+    transcript = recs * world  # every rank holds the same shard contents in this test
+    r_le = be.batch_challenges(transcript, 0, 1, n_total)
+    rec = [transcript[160 * i: 160 * i + 160] for i in range(n_local)] * world
+    r_want = O.compute_r(b"".join(x[:48] for x in rec), b"".join(x[48:80][::-1] for x in rec), b"".join(x[80:112][::-1] for x in rec),
+                         b"".join(x[112:] for x in rec), n_total)
+    assert r_le[::-1] == r_want
+    r = int.from_bytes(r_want, "big")
+    zs = [int.from_bytes(recs[160 * i + 48: 160 * i + 80], "little") for i in range(n_local)]
+    ys = [int.from_bytes(recs[160 * i + 80: 160 * i + 112], "little") for i in range(n_local)]
+    parts = []
+    for k in range(world):
+        part = be.phase2_r(r_le, n_total, k * n_local, n_local)
+        parts.append(part)
+        if k not in (0, 7):
+            continue
+        sa, sb, g = [0] * m, [0] * m, 0  # scalars collapsed onto the distinct tuples
+        rp = pow(r, k * n_local, R)
+        for i in range(n_local):
+            j = int(order[i])
+            sa[j] = (sa[j] + rp) % R
+            sb[j] = (sb[j] + rp * zs[i]) % R
+            g = (g + rp * ys[i]) % R
+            rp = rp * r % R
+        A = O.g1_msm(b"".join(ps), b"".join(x.to_bytes(32, "big") for x in sa), m)
+        Bc = O.g1_msm(b"".join(cs), b"".join(x.to_bytes(32, "big") for x in sa), m)
+        Bp = O.g1_msm(b"".join(ps), b"".join(x.to_bytes(32, "big") for x in sb), m)
+        Bw = O.g1_add(O.g1_add(Bc, Bp), O.g1_mul(G1_GEN, ((R - g) % R).to_bytes(32, "big")))
+        for got, want in ((part[:144], A), (part[144:], Bw)):
+            xy, inf = O.g1_decompress(want)
+            aff = _partial_to_affine(got)
+            assert (aff is None) == inf
+            if aff:
+                assert aff[0].to_bytes(48, "big") + aff[1].to_bytes(48, "big") == xy, k
+    assert be.finish(b"".join(parts), world) is True
+    # every partial is a valid relation on its own (an RLC of valid tuples), so swapping whole partials changes nothing:
+    assert be.finish(b"".join(parts[:5] + [parts[4]] + parts[6:]), world) is True
+    # ... but rank 5's A with rank 4's B does not pair up
+    assert be.finish(b"".join(parts[:5] + [parts[5][:144] + parts[4][144:]] + parts[6:]), world) is False
+
+
 @pytest.mark.parametrize("n,B", [(1024, 8), (512, 40), (3000, 3)])
 def test_mid_size_launch_groups(n, B):
     """Launch groups between the single-batch latency path and the bench's large groups: the producer/consumer challenge

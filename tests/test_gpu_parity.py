@@ -777,3 +777,66 @@ def test_finish_without_matching_group_is_rejected(settings):
     st = KzgSettings.load_trusted_setup_file()
     HipBackend(st)  # declares the argtypes
     assert api.lib().kzg_shard_finish_launch(None, 1, 3, st._h) == api.KZG_BADARGS
+
+
+def test_host_fed_stream_of_batches():
+    """kzg_verify_blob_kzg_proof_batches: batches in HOST memory, copied in chunks on a copy stream while the previous chunk is
+    verified.  Same results as the oracle batch by batch - a wrong proof, an invalid blob and an invalid commitment among
+    valid batches - in one chunk (5 batches of 6), across five chunks (40 batches of 1: chunks of 8), and with KZG_HOST_CHUNK-independent layout; then a second call with a larger chunk on the same handle
+    (staging sets regrown)."""
+    from kzg_rs_amd import synth
+    n, B = 6, 5
+    blobs, cs, ps, st = synth.make_valid_batch(40, seed=79)
+    ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])
+    blobs = blobs.copy()
+    cs, ps = list(cs), list(ps)
+    ps[1 * n + 2] = O.g1_add(ps[1 * n + 2], G1_GEN)
+    blobs[2 * n + 3, 32 * 7: 32 * 7 + 32] = list(R.to_bytes(32, "big"))
+    cs[3 * n + 1] = bytes([0x81]) + bytes(range(1, 48))
+    hb, hc, hp = blobs.tobytes(), b"".join(cs), b"".join(ps)
+
+    def want(n_, B_):
+        out = []
+        for b in range(B_):
+            bl = [blobs[i].tobytes() for i in range(b * n_, (b + 1) * n_)]
+            try:
+                out.append(O.verify_blob_kzg_proof_batch(bl, cs[b * n_:(b + 1) * n_], ps[b * n_:(b + 1) * n_], ost))
+            except O.OracleError:
+                out.append(None)
+        return out
+
+    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 1, 40, st) == want(1, 40)   # five chunks of 8
+    w65 = want(6, 5)
+    assert w65 == [True, False, None, None, True]
+    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 6, 5, st) == w65            # one chunk, larger staging sets
+    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 2, 20, st) == want(2, 20)    # three chunks: 8, 8, 4
+
+
+def test_host_entry_full_size_batch():
+    """The reference's signature at BASELINE configs[1] size: ONE verify_blob_kzg_proof_batch of 1 024 blobs handed over in
+    host memory (kzg_verify_blob_kzg_proof_batch, a Vec<Blob>'s layout) - valid, then with one proof corrupted, then
+    with one non-canonical field element (Err) - and the same three batches as a host-fed stream."""
+    import ctypes as C
+    from kzg_rs_amd import synth
+    n = 1024
+    blobs, cs, ps, st = synth.make_valid_batch(n, seed=80, chunk=1024)
+    hc, hp = b"".join(cs), b"".join(ps)
+    bad_p = list(ps)
+    bad_p[777] = O.g1_add(ps[777], G1_GEN)
+    hbp = b"".join(bad_p)
+    bad_blobs = blobs.copy()
+    bad_blobs[1000, 32 * 4095: 32 * 4096] = list(R.to_bytes(32, "big"))
+    L = api.lib()
+
+    def call(bl, c, p):
+        ok = C.c_bool(False)
+        rc = L.kzg_verify_blob_kzg_proof_batch(C.byref(ok), bl.ctypes.data_as(C.c_char_p), c, p, n, st._h)
+        return None if rc == api.KZG_BADARGS else bool(ok.value) if rc == api.KZG_OK else "rc%d" % rc
+
+    assert call(blobs, hc, hp) is True
+    assert call(blobs, hc, hbp) is False
+    assert call(bad_blobs, hc, hp) is None
+    import numpy as np
+    three = np.concatenate([blobs, blobs, bad_blobs])
+    got = api.verify_blob_kzg_proof_batches(three.ctypes.data, hc + hc + hc, hp + hbp + hp, n, 3, st)
+    assert got == [True, False, None]
