@@ -108,6 +108,62 @@ FP29_FN G1Jac29 g1j29_add_affine(const G1Jac29& p, const G1Aff29& q) {
     return r;
 }
 
+// ---- the additions in two halves, for the MSM kernel's loops.  The complete formulas above return from five places; inlined
+// into a loop the compiler merges those exits through memory (the bucket accumulator lived in scratch: 112 bytes loaded and
+// stored per addition, 1.5 GB of HBM writes per launch group).  Here `head` computes everything the special cases are
+// decided on, the caller branches (rare cases: out of the loop), and `tail` is straight-line code.  Same bounds as above.
+struct G1MaddHead {
+    Fp29 S2, H, HH;  // HH = 0 mod p: same x (P + P or P - P), or p at infinity - the complete formula must be used
+};
+FP29_FN G1MaddHead g1j29_madd_head(const G1Jac29& p, const G1Aff29& q) {
+    G1MaddHead h;
+    const Fp29 Z1Z1 = fp29_sqr(p.z);
+    const Fp29 U2 = fp29_mul(q.x, Z1Z1);
+    h.S2 = fp29_mul(fp29_mul(q.y, p.z), Z1Z1);
+    h.H = fp29_sub<9>(U2, p.x);  // < 514p
+    h.HH = fp29_sqr(h.H);
+    return h;
+}
+FP29_FN bool g1j29_madd_special(const G1MaddHead& h) { return fp29_is_zero_mod_p(h.HH); }
+// p + q for g1j29_madd_special(h) == false (p finite, different x): X < 14p, Y < 6p, Z < 2p
+FP29_FN G1Jac29 g1j29_madd_tail(const G1Jac29& p, const G1MaddHead& h) {
+    G1Jac29 r;
+    r.z = fp29_mul(p.z, h.H);                                                         // < 2p
+    const Fp29 HHH = fp29_mul(h.H, h.HH), V = fp29_mul(p.x, h.HH);
+    const Fp29 Rr = fp29_sub<9>(h.S2, p.y);                                           // < 514p
+    r.x = fp29_sub<3>(fp29_sub<2>(fp29_sqr(Rr), HHH), fp29_dbl(V));                   // < 14p
+    const Fp29 T = fp29_mul(p.y, HHH);
+    r.y = fp29_sub<2>(fp29_mul(Rr, fp29_sub<5>(V, r.x)), T);                          // < 6p
+    return r;
+}
+struct G1AddHead {
+    Fp29 U1, S1, S2, H, HH;
+    bool p_inf, q_inf;
+};
+FP29_FN G1AddHead g1j29_add_head(const G1Jac29& p, const G1Jac29& q) {
+    G1AddHead h;
+    const Fp29 Z1Z1 = fp29_sqr(p.z), Z2Z2 = fp29_sqr(q.z);
+    h.p_inf = fp29_is_zero_mod_p(Z1Z1);
+    h.q_inf = fp29_is_zero_mod_p(Z2Z2);
+    h.U1 = fp29_mul(p.x, Z2Z2);
+    h.H = fp29_sub<2>(fp29_mul(q.x, Z1Z1), h.U1);  // < 6p
+    h.S1 = fp29_mul(fp29_mul(p.y, q.z), Z2Z2);
+    h.S2 = fp29_mul(fp29_mul(q.y, p.z), Z1Z1);
+    h.HH = fp29_sqr(h.H);
+    return h;
+}
+// p + q for both finite and different x (neither h.p_inf nor h.q_inf, h.HH != 0 mod p)
+FP29_FN G1Jac29 g1j29_add_tail(const G1Jac29& p, const G1Jac29& q, const G1AddHead& h) {
+    G1Jac29 r;
+    r.z = fp29_mul(fp29_mul(p.z, q.z), h.H);                                          // < 2p
+    const Fp29 HHH = fp29_mul(h.H, h.HH), V = fp29_mul(h.U1, h.HH);
+    const Fp29 Rr = fp29_sub<2>(h.S2, h.S1);                                          // < 6p
+    r.x = fp29_sub<3>(fp29_sub<2>(fp29_sqr(Rr), HHH), fp29_dbl(V));                   // < 14p
+    const Fp29 T = fp29_mul(h.S1, HHH);
+    r.y = fp29_sub<2>(fp29_mul(Rr, fp29_sub<5>(V, r.x)), T);                          // < 6p
+    return r;
+}
+
 // -phi(P) = (beta x, -y, z); y below 64p in, below 128p out
 FP29_FN G1Jac29 g1j29_neg_phi(const G1Jac29& p) {
     G1Jac29 r;

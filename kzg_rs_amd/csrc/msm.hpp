@@ -391,6 +391,7 @@ struct Curve32 {
     using Mem = G1Jac;
     using Entry = G1Jac;
     static constexpr int WORDS = 36;
+    static constexpr bool SPLIT = false;  // the 12x32 A/B variant keeps the complete formulas in its loops
     __device__ static __forceinline__ Pt add_entry(const Pt& a, const Entry& b) { return g1_add(a, b); }
     __device__ static __forceinline__ Pt identity() { return g1_identity(); }
     __device__ static __forceinline__ Pt add(const Pt& a, const Pt& b) { return g1_add(a, b); }
@@ -405,6 +406,13 @@ struct Curve29 {
     using Mem = G1Jac29Mem;
     using Entry = G1Jac29;
     static constexpr int WORDS = 42;
+    // the additions of the loops in two halves (g1_29_formulas.hpp): special(h) -> the pair needs the complete formula
+    static constexpr bool SPLIT = true;
+    using EntryHead = G1AddHead;
+    __device__ static __forceinline__ EntryHead entry_head(const Pt& a, const Entry& b) { return g1j29_add_head(a, b); }
+    __device__ static __forceinline__ bool entry_special(const EntryHead& h) { return h.p_inf | h.q_inf | fp29_is_zero_mod_p(h.HH); }
+    __device__ static __forceinline__ Pt entry_tail(const Pt& a, const Entry& b, const EntryHead& h) { return g1j29_add_tail(a, b, h); }
+    __device__ static __forceinline__ Pt from_entry(const Entry& b) { return b; }
     __device__ static __forceinline__ Pt add_entry(const Pt& a, const Entry& b) { return g1j29_add(a, b); }
     __device__ static __forceinline__ Pt identity() { return g1j29_identity(); }
     __device__ static __forceinline__ Pt add(const Pt& a, const Pt& b) { return g1j29_add(a, b); }
@@ -419,6 +427,17 @@ struct Curve29 {
 struct Curve29Aff : Curve29 {
     using Mem = G1Aff29Mem;
     using Entry = G1Aff29;
+    using EntryHead = G1MaddHead;
+    __device__ static __forceinline__ EntryHead entry_head(const Pt& a, const Entry& b) { return g1j29_madd_head(a, b); }
+    __device__ static __forceinline__ bool entry_special(const EntryHead& h) { return g1j29_madd_special(h); }
+    __device__ static __forceinline__ Pt entry_tail(const Pt& a, const Entry&, const EntryHead& h) { return g1j29_madd_tail(a, h); }
+    __device__ static __forceinline__ Pt from_entry(const Entry& b) {
+        Pt r;
+        r.x = b.x;
+        r.y = b.y;
+        r.z = fp29_const(cp29::FP29_ONE);
+        return r;
+    }
     __device__ static __forceinline__ Pt add_entry(const Pt& a, const Entry& b) { return g1j29_add_affine(a, b); }
     __device__ static __forceinline__ Entry load(const Mem& m) { return g1a29_load(m); }
 };
@@ -490,7 +509,31 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     const int bucket = cur[tid];
     const typename CV::Mem* mult = static_cast<const typename CV::Mem*>(d.mult);
     Pt acc = CV::identity();
-    if (bucket > 0) {
+    if constexpr (CV::SPLIT) {
+        // The common addition (accumulator finite, different x) is straight-line code; a pair that needs the complete
+        // formula - a repeated point (P + P) or its negative - is not added here: its entry moves to the front of the
+        // bucket's own list and the loop below, outside the hot one, takes care of it.  (Inlined, the complete formula's
+        // five exits kept the accumulator in scratch memory: 112 bytes loaded and stored per addition.)
+        uint32_t k = bucket > 0 ? off[bucket] : 0u, w = k;
+        const uint32_t kend = bucket > 0 ? off[bucket + 1] : 0u;
+        if (k < kend) {  // the first entry of a bucket is a copy, not an addition to the identity
+            const uint32_t e = sorted[k++];
+            acc = CV::from_entry(CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
+            w = k;
+        }
+        for (; k < kend; k++) {
+            const uint32_t e = sorted[k];
+            const typename CV::Entry q = CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]);
+            const typename CV::EntryHead h = CV::entry_head(acc, q);
+            if (CV::entry_special(h)) sorted[w++] = e;  // w <= k: only this thread reads or writes its bucket's list
+            else acc = CV::entry_tail(acc, q, h);
+        }
+        const uint32_t first = bucket > 0 ? off[bucket] + 1 : 0u;
+        for (uint32_t j = first; j < w; j++) {  // rare
+            const uint32_t e = sorted[j];
+            acc = CV::add_entry(acc, CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
+        }
+    } else if (bucket > 0) {
         for (uint32_t k = off[bucket]; k < off[bucket + 1]; k++) {
             const uint32_t e = sorted[k];
             acc = CV::add_entry(acc, CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
@@ -553,7 +596,17 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
             y = CV::lds_load(pts, src);
         }
         __syncthreads();  // scan levels read a slot that its owner rewrites in the same level
-        if (active) CV::lds_store(pts, dst, CV::add(x, y));
+        if constexpr (CV::SPLIT) {
+            // every path ends in its own store: no point value is merged across the paths (see the bucket loop)
+            if (active) {
+                const G1AddHead h = g1j29_add_head(x, y);
+                if (h.p_inf | h.q_inf) CV::lds_store(pts, dst, h.p_inf ? y : x);  // empty buckets: common in small batches
+                else if (fp29_is_zero_mod_p(h.HH)) CV::lds_store(pts, dst, CV::add(x, y));
+                else CV::lds_store(pts, dst, g1j29_add_tail(x, y, h));
+            }
+        } else {
+            if (active) CV::lds_store(pts, dst, CV::add(x, y));
+        }
         __syncthreads();
     }
     if (tid == 0) {

@@ -13,6 +13,24 @@ void h_g1_add_affine(uint32_t* o, const uint32_t* p, const uint32_t* q) {
     G1Aff29 a; a.x = ld(q); a.y = ld(q + 14);
     stj(o, g1j29_add_affine(ldj(p), a));
 }
+// the two-halves forms (what the MSM window kernel's loops run): returns 1 when the caller must use the complete formula
+// (nothing is written then), 2 when an identity operand was passed through
+int h_g1_add_split(uint32_t* o, const uint32_t* pp, const uint32_t* qq) {
+    const G1Jac29 p = ldj(pp), q = ldj(qq);
+    const G1AddHead h = g1j29_add_head(p, q);
+    if (h.p_inf || h.q_inf) { stj(o, h.p_inf ? q : p); return 2; }
+    if (fp29_is_zero_mod_p(h.HH)) return 1;
+    stj(o, g1j29_add_tail(p, q, h));
+    return 0;
+}
+int h_g1_madd_split(uint32_t* o, const uint32_t* pp, const uint32_t* qq) {
+    const G1Jac29 p = ldj(pp);
+    G1Aff29 a; a.x = ld(qq); a.y = ld(qq + 14);
+    const G1MaddHead h = g1j29_madd_head(p, a);
+    if (g1j29_madd_special(h)) return 1;
+    stj(o, g1j29_madd_tail(p, h));
+    return 0;
+}
 void h_g1_neg_phi(uint32_t* o, const uint32_t* p) { stj(o, g1j29_neg_phi(ldj(p))); }
 void h_g1_identity(uint32_t* o) { stj(o, g1j29_identity()); }
 }

@@ -163,6 +163,47 @@ def test_mixed_addition_and_special_cases(lib):
             check_bounds(w, 14, 6, 2)
 
 
+def test_two_halves_forms(lib):
+    """g1j29_madd_head / _tail and g1j29_add_head / _tail (what the MSM window kernel's loops run): equal to the complete
+    formulas whenever they do not send the caller to them, which they do exactly for P + P, P - P and - in the mixed
+    form - an accumulator at infinity; the general form passes identity operands (Z = 0, p, 2p) through."""
+    rng = random.Random(6)
+
+    def run_flag(f, *args):
+        o = (C.c_uint32 * 42)()
+        flag = f(o, *[(C.c_uint32 * len(a))(*a) for a in args])
+        return list(o), flag
+
+    for i in range(800):
+        a, b = rand_point(rng), rand_point(rng)
+        kind = i % 8
+        if kind == 5:
+            a = b
+        elif kind == 6:
+            a = (b[0], P - b[1])
+        elif kind == 7:
+            a = None
+        wa = to_jac(rng, a, 256, 256, 1024)
+        if a is None:  # the kernel's identity: (0, 1, 0) in any representation of zero
+            wa = limbs(rng.choice([0, P])) + wa[14:]
+        wq = limbs(lift(rng, b[0] * RP, 8)) + limbs(lift(rng, b[1] * RP, 8))
+        w, flag = run_flag(lib.h_g1_madd_split, wa, wq)
+        assert flag == (1 if kind in (5, 6, 7) else 0)
+        if not flag:
+            assert from_jac(w) == ec_add(a, b)
+            check_bounds(w, 14, 6, 2)
+        wb = to_jac(rng, b, 1024, 1024, 1024)
+        wa2 = to_jac(rng, a, 1024, 1024, 1024)
+        for x, y in ((wa2, wb), (wb, wa2)):
+            w, flag = run_flag(lib.h_g1_add_split, x, y)
+            assert flag == (1 if kind in (5, 6) else 2 if kind == 7 else 0)
+            if flag != 1:
+                assert from_jac(w) == ec_add(a, b)
+        if kind == 7:  # identity + identity
+            w, flag = run_flag(lib.h_g1_add_split, wa2, to_jac(rng, None, 1024, 1024, 3))
+            assert flag == 2 and from_jac(w) is None
+
+
 def test_chains_feed_back(lib):
     """what the kernels do: outputs of one formula are the inputs of the next, never reduced in between"""
     rng = random.Random(4)
