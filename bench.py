@@ -41,9 +41,9 @@ ALG_BYTES = {
     "k_slp_run(pairing)": 0,
 }
 PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge", "k_blob_evaluate": "kzg::k_blob_evaluate",
-            "k_g1_decode_multiples": "kzg::k_g1_decode_multiples29<4, true>", "k_msm": "kzg::k_msm_window<kzg::Curve29Aff>",
+            "k_g1_decode_multiples": "kzg::k_g1_decode_multiples29<4, true>", "k_msm": "kzg::k_msm_window<kzg::Curve29Aff, true>",
             "k_slp_run(pairing)": "kzg::k_slp_run<false>"}
-PMC_FILES = ("r2_pmc.json", "r1h_pmc.json")  # newest first; the first that exists is used
+PMC_FILES = ("r2_pmc.json",)  # newest first; the first that exists is used (kernel names must match PMC_NAME)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
 
 

@@ -28,6 +28,8 @@ struct Workspace {
     uint32_t *d_status = nullptr, *d_pflag = nullptr, *d_term_point = nullptr, *d_term_scalar = nullptr, *d_sorted = nullptr;
     G1Aff* d_points = nullptr;
     G1Jac *d_window = nullptr, *d_window_sl = nullptr, *d_ab = nullptr, *d_parts = nullptr;
+    uint32_t* d_msm_save = nullptr;  // the window kernel's bucket sums between its row and column trees (msm.hpp MsmDesc::save)
+    size_t cap_msm_save = 0;         // bytes
     void* d_mult = nullptr;  // MSM tables: G1Jac29Mem / G1Aff29Mem / G1Jac entries (fp29_enabled(), msm_affine_enabled())
     unsigned long long* d_ktime = nullptr;  // execution interval of the last throughput-form challenge kernel (fr_kernels.hpp)
     bool ktime_valid = false;
@@ -291,7 +293,7 @@ static KzgRet settings_load_points(KzgSettings* s, const std::vector<uint8_t>& g
     HIPCHK(hipMemcpyAsync(d_bytes, g1b.data(), g1b.size(), hipMemcpyHostToDevice, s->s1));
     hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, s->d_g1, s->d_g1_flag, N, 0);
     if (fp29_enabled())
-        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
+        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3((unsigned)((N + 63) / 64)), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s1, d_bytes, d_bytes, N, d_tmp,
                            d_flag2, s->d_g1_mult, (G1Jac29Mem*)nullptr, N, N);
     else
         hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
@@ -393,7 +395,7 @@ extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
                     w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_mult, w.d_jtmp, w.d_ktime, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
-                    w.d_records, w.d_hstage[0], w.d_hstage[1]};
+                    w.d_records, w.d_hstage[0], w.d_hstage[1], w.d_msm_save};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w.h_buf) (void)hipHostFree(w.h_buf);

@@ -138,6 +138,22 @@ static int msm_chunks_per_block(size_t B) {
     return B >= 32 ? 4 : B >= 16 ? 2 : 1;
 }
 
+// The window kernel's save area (msm.hpp MsmDesc::save): grow-only, one z-layer at least, 512 MiB at most - a larger grid
+// is launched in z-pieces by msm_window_launch.
+static KzgRet msm_save_reserve(const KzgSettings* s, unsigned gx, unsigned gy, unsigned gz) {
+    Workspace& w = s->ws;
+    const size_t layer = msm_save_layer_bytes(gx, gy, fp29_enabled() ? Curve29::WORDS : Curve32::WORDS);
+    const size_t want = std::max(layer, std::min(layer * gz, (size_t)512 << 20));
+    if (want > w.cap_msm_save) {
+        if (w.d_msm_save) (void)hipFree(w.d_msm_save);
+        w.d_msm_save = nullptr;
+        w.cap_msm_save = 0;
+        HIPCHK(hipMalloc(&w.d_msm_save, want));
+        w.cap_msm_save = want;
+    }
+    return KZG_OK;
+}
+
 // ---------------------------------------------------------------- the tail: MSM + pairing
 // Group of B batches of n blobs (T = B n).  scalars of batch b at b(2n+1): a [0,n), b [n,2n), g at 2n;
 // points: C [0,T), pi [T,2T), G at 2T, multiples with stride 2T+1.  Leaves (A, B) of batch b in ws.d_ab[2b..].
@@ -164,15 +180,31 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     // one large batch: slice the terms of an output over several workgroups until the launch has ~1000 of them
     // (each slice keeps >= 1024 terms of the smaller output)
     unsigned S = 1;
-    while (S < MSM_MAX_SLICES && W * slots * 2 * B * S < 768 && n / (2 * S) >= 1024) S *= 2;
+    while (S < MSM_MAX_SLICES && W * slots * 2 * B * S < 768 && n / (2 * S) >= 1024 && 2 * S * B <= 128) S *= 2;
+    // ... and until a block's sorted term list fits in LDS (msm.hpp LDSSORT): the global list costs a line of HBM write
+    // traffic per 4-byte entry once the launch outgrows the L2
+    const size_t lds_cap = fp29_enabled() ? msm_lds_sort_capacity<Curve29>() : msm_lds_sort_capacity<Curve32>();
+    auto slice_terms = [&](unsigned S_) { return ((size_t)mt + S_ - 1) / S_ * (size_t)d.chunks_per_block; };
+    while (S < MSM_MAX_SLICES && slice_terms(S) > lds_cap && n / (2 * S) >= 1024 && 2 * S * B <= 128) S *= 2;  // (d_window_sl holds S B <= 128 slice sets)
+    const bool lds_sort = slice_terms(S) + 1 <= lds_cap;  // (+1: slice boundaries round either way)
     d.slices = (int)S;
     d.window_sums = S > 1 ? w.d_window_sl : w.d_window;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     const int nsc = (int)(B * (2 * n + 1));
     hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc);
-    if (w.mult_affine) hipLaunchKernelGGL(k_msm_window<Curve29Aff>, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
-    else if (fp29_enabled()) hipLaunchKernelGGL(k_msm_window<Curve29>, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
-    else hipLaunchKernelGGL(k_msm_window<Curve32>, dim3(W, slots, (unsigned)(2 * B * S)), dim3(256), 0, s->s1, d);
+    const unsigned gz = (unsigned)(2 * B * S);
+    KzgRet rc_save = msm_save_reserve(s, W, slots, gz);
+    if (rc_save != KZG_OK) return rc_save;
+    if (w.mult_affine) {
+        if (lds_sort) msm_window_launch<Curve29Aff, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
+        else msm_window_launch<Curve29Aff, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
+    } else if (fp29_enabled()) {
+        if (lds_sort) msm_window_launch<Curve29, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
+        else msm_window_launch<Curve29, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
+    } else {
+        if (lds_sort) msm_window_launch<Curve32, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
+        else msm_window_launch<Curve32, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
+    }
     if (S > 1)
         hipLaunchKernelGGL(k_msm_fold_slices, dim3((unsigned)(2 * B * slots * W)), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, (int)W);
     if (2 * B >= 64)  // enough outputs to fill wavefronts with one lane each
@@ -200,7 +232,7 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
         // affine tables: rows 0 and 2 straight from the decode pass, rows 1 and 3 from 2^64 P through one inversion per 16 points
         G1Aff29Mem* mult = (G1Aff29Mem*)w.d_mult;
         // 256-thread workgroups: their four waves are dealt one to each SIMD of a CU (single-wave workgroups are placed unevenly)
-        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, true>), dim3((unsigned)((2 * T + 255) / 256)), dim3(256), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, w.d_jtmp, n2, np);
+        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, true>), dim3((unsigned)((2 * T + 255) / 256)), dim3(256), 256 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, w.d_jtmp, n2, np);
         const unsigned conv_blocks = (unsigned)((n2 + 64 * AFFINE_BATCH - 1) / (64 * AFFINE_BATCH));
         hipLaunchKernelGGL(k_mult_to_affine29, dim3(conv_blocks), dim3(64), 0, s->s2, w.d_jtmp, w.d_pflag, mult, n2, np);
         HIPCHK(hipEventRecord(s->ev[10], s->s2));
@@ -209,9 +241,9 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
     } else if (fp29_enabled()) {
         G1Jac29Mem* mult = (G1Jac29Mem*)w.d_mult;
         if (w.chunks == MSM_CHUNKS_LATENCY)
-            hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS_LATENCY, false>), dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
+            hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS_LATENCY, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
         else
-            hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
+            hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
         HIPCHK(hipEventRecord(s->ev[10], s->s2));
         hipLaunchKernelGGL(k_set_generator_multiples<G1Jac29Mem>, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, mult,
                            (const G1Jac29Mem*)s->d_gen_mult + gen_off, n2, np, w.chunks);

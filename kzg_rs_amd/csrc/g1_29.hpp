@@ -88,6 +88,75 @@ __device__ __forceinline__ G1Jac g1j29_to_std(const G1Jac29& p) {
     return r;
 }
 
+// A per-thread parking place in LDS for values that are idle across a long chain of doublings: the decode pass holds
+// the point (x, y), the running sum q and the chain value r at once, the doubling needs ~120 registers of its own, and
+// at 256 VGPRs the allocator spilled q, x and y to scratch inside the chains (4.4 KB of HBM writes per point).  LDS is
+// there for the taking (the kernel uses none otherwise): 18 uint4 per thread, element e of thread t at [e * stride + t]
+// (one ds_write_b128 per element, conflict-free).
+struct LdsPark {
+    uint4* base;      // already offset by the thread index
+    unsigned stride;  // threads per workgroup
+};
+constexpr int PARK_UINT4_PER_THREAD = 18;  // (x, y): 7, a Jacobian point: 11
+template <int NWORDS>
+__device__ __forceinline__ void park_store(const LdsPark& pk, int at, const uint32_t (&w)[NWORDS]) {
+#pragma unroll
+    for (int e = 0; e < (NWORDS + 3) / 4; e++)
+        pk.base[(at + e) * pk.stride] = make_uint4(w[4 * e], 4 * e + 1 < NWORDS ? w[4 * e + 1] : 0u, 4 * e + 2 < NWORDS ? w[4 * e + 2] : 0u,
+                                                  4 * e + 3 < NWORDS ? w[4 * e + 3] : 0u);
+}
+template <int NWORDS>
+__device__ __forceinline__ void park_load(const LdsPark& pk, int at, uint32_t (&w)[NWORDS]) {
+#pragma unroll
+    for (int e = 0; e < (NWORDS + 3) / 4; e++) {
+        const uint4 v = pk.base[(at + e) * pk.stride];
+        w[4 * e] = v.x;
+        if (4 * e + 1 < NWORDS) w[4 * e + 1] = v.y;
+        if (4 * e + 2 < NWORDS) w[4 * e + 2] = v.z;
+        if (4 * e + 3 < NWORDS) w[4 * e + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void park_xy(const LdsPark& pk, const Fp29& x, const Fp29& y) {
+    uint32_t w[28];
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        w[i] = x.l[i];
+        w[14 + i] = y.l[i];
+    }
+    park_store<28>(pk, 0, w);
+}
+__device__ __forceinline__ void unpark_xy(const LdsPark& pk, Fp29& x, Fp29& y) {
+    uint32_t w[28];
+    park_load<28>(pk, 0, w);
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        x.l[i] = w[i];
+        y.l[i] = w[14 + i];
+    }
+}
+__device__ __forceinline__ void park_point(const LdsPark& pk, const G1Jac29& p) {
+    uint32_t w[42];
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        w[i] = p.x.l[i];
+        w[14 + i] = p.y.l[i];
+        w[28 + i] = p.z.l[i];
+    }
+    park_store<42>(pk, 7, w);
+}
+__device__ __forceinline__ G1Jac29 unpark_point(const LdsPark& pk) {
+    uint32_t w[42];
+    park_load<42>(pk, 7, w);
+    G1Jac29 p;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        p.x.l[i] = w[i];
+        p.y.l[i] = w[14 + i];
+        p.z.l[i] = w[28 + i];
+    }
+    return p;
+}
+
 // [|x|]P left to right (63 doublings + 5 additions)
 __device__ inline G1Jac29 g1j29_mul_xabs(const G1Jac29& p) {
     G1Jac29 acc = p;
@@ -98,20 +167,34 @@ __device__ inline G1Jac29 g1j29_mul_xabs(const G1Jac29& p) {
     }
     return acc;
 }
+// the same with P parked (unpark_point(pk)): it is needed five times in 63 iterations
+__device__ inline G1Jac29 g1j29_mul_xabs_parked(const LdsPark& pk) {
+    G1Jac29 acc = unpark_point(pk);
+#pragma unroll 1
+    for (int i = 62; i >= 0; i--) {
+        acc = g1j29_dbl(acc);
+        if ((BLS_X_ABS >> i) & 1) acc = g1j29_add(acc, unpark_point(pk));
+    }
+    return acc;
+}
 
 // The subgroup test of g1.hpp (phi(P) = -[x^2]P) with the multiples 2^(STEP k) P emitted on the way, in this field.
-// x, y: the affine point (x R'', y R'', below 2p).
+// x, y: the affine point (x R'', y R'', below 2p); they are parked in pk on return (unpark_xy), as is nothing else.
 template <int STEP, class Emit>
-__device__ inline bool g1j29_in_subgroup_with_multiples(const Fp29& x, const Fp29& y, Emit emit) {
+__device__ inline bool g1j29_in_subgroup_with_multiples(const Fp29& x, const Fp29& y, const LdsPark& pk, Emit emit) {
     G1Jac29 r;
     r.x = x;
     r.y = y;
     r.z = fp29_const(cp29::FP29_ONE);
-    G1Jac29 q = r;  // overwritten at bit 16, the lowest set bit of |x|
+    park_xy(pk, x, y);
+    // q = [|x|]P accumulated right to left lives in the parking place: it is touched at the six set bits of |x| only
 #pragma unroll 1
     for (int i = 0; i < 64; i++) {
         if (i && i % STEP == 0) emit(i / STEP, r);
-        if ((BLS_X_ABS >> i) & 1) q = (i == 16) ? r : g1j29_add(q, r);
+        if ((BLS_X_ABS >> i) & 1) {
+            if (i == 16) park_point(pk, r);  // the lowest set bit of |x|
+            else park_point(pk, g1j29_add(unpark_point(pk), r));
+        }
         r = g1j29_dbl(r);
     }
 #pragma unroll 1
@@ -120,14 +203,16 @@ __device__ inline bool g1j29_in_subgroup_with_multiples(const Fp29& x, const Fp2
         if (i + STEP >= 128) break;
         r = g1j29_dbl(r);
     }
-    q = g1j29_mul_xabs(q);
+    const G1Jac29 q = g1j29_mul_xabs_parked(pk);
     const Fp29 zz = fp29_sqr(q.z);
     if (fp29_is_zero_mod_p(zz)) return false;
+    Fp29 xx, yy;
+    unpark_xy(pk, xx, yy);
     const Fp29 zzz = fp29_mul(zz, q.z), one = fp29_const(cp29::FP29_ONE);
-    const Fp29 bx = fp29_mul(x, fp29_const(cp29::FP29_BETA_MONT));
+    const Fp29 bx = fp29_mul(xx, fp29_const(cp29::FP29_BETA_MONT));
     // phi(P) == -q  <=>  X = beta x Z^2  and  Y + y Z^3 = 0; differences go through one more product to be testable
     const Fp29 dx = fp29_mul(fp29_sub<2>(q.x, fp29_mul(bx, zz)), one);
-    const Fp29 dy = fp29_mul(fp29_add(q.y, fp29_mul(y, zzz)), one);
+    const Fp29 dy = fp29_mul(fp29_add(q.y, fp29_mul(yy, zzz)), one);
     return fp29_is_zero_mod_p(dx) && fp29_is_zero_mod_p(dy);
 }
 

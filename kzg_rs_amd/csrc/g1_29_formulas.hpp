@@ -136,15 +136,23 @@ FP29_FN G1Jac29 g1j29_madd_tail(const G1Jac29& p, const G1MaddHead& h) {
     r.y = fp29_sub<2>(fp29_mul(Rr, fp29_sub<5>(V, r.x)), T);                          // < 6p
     return r;
 }
+// General addition for the reduction trees, in a form whose later stages need NOTHING of the operands: the head leaves
+// U1 = X1 Z2^2, S1 = Y1 Z2^3, S2, H, HH and ZZ = Z1 Z2; the tail works from those, and so does the rare same-x case -
+// (U1, S1, ZZ) is the point p itself in another Jacobian representation (scaled by Z2), so P + P is its doubling.
+// Caller's order: infinity flags first (pass the other operand through), then the head, then one of the two endings.
+FP29_FN void g1j29_inf_flags(const G1Jac29& p, const G1Jac29& q, Fp29& Z1Z1, Fp29& Z2Z2, bool& p_inf, bool& q_inf) {
+    Z1Z1 = fp29_sqr(p.z);
+    Z2Z2 = fp29_sqr(q.z);
+    p_inf = fp29_is_zero_mod_p(Z1Z1);
+    q_inf = fp29_is_zero_mod_p(Z2Z2);
+}
 struct G1AddHead {
-    Fp29 U1, S1, S2, H, HH;
-    bool p_inf, q_inf;
+    Fp29 U1, S1, S2, H, HH, ZZ;
 };
-FP29_FN G1AddHead g1j29_add_head(const G1Jac29& p, const G1Jac29& q) {
+// p, q finite
+FP29_FN G1AddHead g1j29_add_head(const G1Jac29& p, const G1Jac29& q, const Fp29& Z1Z1, const Fp29& Z2Z2) {
     G1AddHead h;
-    const Fp29 Z1Z1 = fp29_sqr(p.z), Z2Z2 = fp29_sqr(q.z);
-    h.p_inf = fp29_is_zero_mod_p(Z1Z1);
-    h.q_inf = fp29_is_zero_mod_p(Z2Z2);
+    h.ZZ = fp29_mul(p.z, q.z);
     h.U1 = fp29_mul(p.x, Z2Z2);
     h.H = fp29_sub<2>(fp29_mul(q.x, Z1Z1), h.U1);  // < 6p
     h.S1 = fp29_mul(fp29_mul(p.y, q.z), Z2Z2);
@@ -152,16 +160,27 @@ FP29_FN G1AddHead g1j29_add_head(const G1Jac29& p, const G1Jac29& q) {
     h.HH = fp29_sqr(h.H);
     return h;
 }
-// p + q for both finite and different x (neither h.p_inf nor h.q_inf, h.HH != 0 mod p)
-FP29_FN G1Jac29 g1j29_add_tail(const G1Jac29& p, const G1Jac29& q, const G1AddHead& h) {
+FP29_FN bool g1j29_add_same_x(const G1AddHead& h) { return fp29_is_zero_mod_p(h.HH); }
+// different x: X < 14p, Y < 6p, Z < 2p
+FP29_FN G1Jac29 g1j29_add_tail(const G1AddHead& h) {
     G1Jac29 r;
-    r.z = fp29_mul(fp29_mul(p.z, q.z), h.H);                                          // < 2p
+    r.z = fp29_mul(h.ZZ, h.H);                                                        // < 2p
     const Fp29 HHH = fp29_mul(h.H, h.HH), V = fp29_mul(h.U1, h.HH);
     const Fp29 Rr = fp29_sub<2>(h.S2, h.S1);                                          // < 6p
     r.x = fp29_sub<3>(fp29_sub<2>(fp29_sqr(Rr), HHH), fp29_dbl(V));                   // < 14p
     const Fp29 T = fp29_mul(h.S1, HHH);
     r.y = fp29_sub<2>(fp29_mul(Rr, fp29_sub<5>(V, r.x)), T);                          // < 6p
     return r;
+}
+// same x: P + P (the doubling of p = (U1, S1, ZZ)) or P - P (the identity)
+FP29_FN G1Jac29 g1j29_add_same_x_result(const G1AddHead& h) {
+    const Fp29 Rr = fp29_sub<2>(h.S2, h.S1);
+    if (!fp29_is_zero_mod_p(fp29_sqr(Rr))) return g1j29_identity();
+    G1Jac29 t;
+    t.x = h.U1;
+    t.y = h.S1;
+    t.z = h.ZZ;
+    return g1j29_dbl(t);
 }
 
 // -phi(P) = (beta x, -y, z); y below 64p in, below 128p out

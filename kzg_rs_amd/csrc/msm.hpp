@@ -19,6 +19,7 @@
 //   3. sum_b b*B_b through row / column sums of the 16 x 16 bucket matrix (Jacobian points staged in LDS);
 // then k_msm_combine folds the chunk sums and the 8 windows (Horner, 8 doublings per window).
 #pragma once
+#include <algorithm>
 #include "g1.hpp"
 #include "g1_29.hpp"
 
@@ -167,6 +168,8 @@ __global__ __launch_bounds__(256, KZG_DECODE_OCC) void k_g1_decode_multiples29(c
                                                                  void* __restrict__ mult_, G1Jac29Mem* __restrict__ jtmp, int n, int stride) {
     static_assert(!AFF || CHUNKS == 4, "the affine layout has one Jacobian multiple per point");
     constexpr int HALF = CHUNKS / 2, STEP = 256 / CHUNKS;
+    extern __shared__ __attribute__((aligned(16))) uint4 park4[];  // PARK_UINT4_PER_THREAD per thread (g1_29.hpp LdsPark)
+    const LdsPark pk{park4 + threadIdx.x, blockDim.x};
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t* src = i < n0 ? bytes0 + (size_t)i * 48 : bytes1 + (size_t)(i - n0) * 48;
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, KZG_DECODE_OCC) void k_g1_decode_multiples29(c
             G1Aff29Mem* mult = static_cast<G1Aff29Mem*>(mult_);
             g1a29_store(mult[i], x, y);
             g1a29_store(mult[(size_t)HALF * stride + i], fp29_mul(x, fp29_const(cp29::FP29_BETA_MONT)), fp29_neg<3>(y));  // y < 4p
-            in = g1j29_in_subgroup_with_multiples<STEP>(x, y, [&](int, const G1Jac29& m) { g1j29_store(jtmp[i], m); });
+            in = g1j29_in_subgroup_with_multiples<STEP>(x, y, pk, [&](int, const G1Jac29& m) { g1j29_store(jtmp[i], m); });
         } else {
             G1Jac29Mem* mult = static_cast<G1Jac29Mem*>(mult_);
             G1Jac29 p;
@@ -190,12 +193,13 @@ __global__ __launch_bounds__(256, KZG_DECODE_OCC) void k_g1_decode_multiples29(c
             p.z = fp29_const(cp29::FP29_ONE);
             g1j29_store(mult[i], p);
             g1j29_store(mult[(size_t)HALF * stride + i], g1j29_neg_phi(p));
-            in = g1j29_in_subgroup_with_multiples<STEP>(x, y, [&](int k, const G1Jac29& m) {
+            in = g1j29_in_subgroup_with_multiples<STEP>(x, y, pk, [&](int k, const G1Jac29& m) {
                 g1j29_store(mult[(size_t)k * stride + i], m);
                 g1j29_store(mult[(size_t)(HALF + k) * stride + i], g1j29_neg_phi(m));
             });
         }
         if (in) {
+            unpark_xy(pk, x, y);  // (x, y) were parked across the chains, not kept in registers
             a.x = fp29_to_std(x);
             a.y = fp29_to_std(y);
         } else {
@@ -335,6 +339,11 @@ struct MsmDesc {
                                   // [2B][slots][slices][W], folded by k_msm_fold_slices - what keeps ONE large batch
                                   // (tens of thousands of terms per output) from running on a few dozen workgroups
     int chunks;                   // MSM_CHUNKS or MSM_CHUNKS_LATENCY; windows per chunk = 32 / chunks = gridDim.x
+    uint32_t* save;               // [blocks of this launch][WORDS][256] words: the block's bucket sums between the row and the
+                                  // column trees of the reduction (kept in registers they were spilled: 2.7 KB of scratch
+                                  // writes per thread)
+    int z0;                       // logical blockIdx.z of this launch's first z-layer (a grid too large for the save area
+                                  // is launched in pieces)
     int chunks_per_block;         // 1: a block per (window, chunk) - most parallel, lowest latency;  4: a block per window
                                   // sums the four chunks' terms into ONE bucket set - a quarter of the reductions and
                                   // fuller, better balanced buckets (throughput mode).  gridDim.y = chunks / chunks_per_block
@@ -409,9 +418,18 @@ struct Curve29 {
     // the additions of the loops in two halves (g1_29_formulas.hpp): special(h) -> the pair needs the complete formula
     static constexpr bool SPLIT = true;
     using EntryHead = G1AddHead;
-    __device__ static __forceinline__ EntryHead entry_head(const Pt& a, const Entry& b) { return g1j29_add_head(a, b); }
-    __device__ static __forceinline__ bool entry_special(const EntryHead& h) { return h.p_inf | h.q_inf | fp29_is_zero_mod_p(h.HH); }
-    __device__ static __forceinline__ Pt entry_tail(const Pt& a, const Entry& b, const EntryHead& h) { return g1j29_add_tail(a, b, h); }
+    // (accumulator and table entries are finite in the bucket loop; an accumulator that a P - P turned into the identity
+    // has Z = 0, hence H = 0 - U1 ... not necessarily 0: the flags are part of "special")
+    __device__ static __forceinline__ EntryHead entry_head(const Pt& a, const Entry& b) {
+        Fp29 Z1Z1, Z2Z2;
+        bool p_inf, q_inf;
+        g1j29_inf_flags(a, b, Z1Z1, Z2Z2, p_inf, q_inf);
+        EntryHead h = g1j29_add_head(a, b, Z1Z1, Z2Z2);
+        if (p_inf | q_inf) h.HH = fp29_zero();  // -> special
+        return h;
+    }
+    __device__ static __forceinline__ bool entry_special(const EntryHead& h) { return g1j29_add_same_x(h); }
+    __device__ static __forceinline__ Pt entry_tail(const Pt&, const Entry&, const EntryHead& h) { return g1j29_add_tail(h); }
     __device__ static __forceinline__ Pt from_entry(const Entry& b) { return b; }
     __device__ static __forceinline__ Pt add_entry(const Pt& a, const Entry& b) { return g1j29_add(a, b); }
     __device__ static __forceinline__ Pt identity() { return g1j29_identity(); }
@@ -445,11 +463,18 @@ struct Curve29Aff : Curve29 {
 #ifndef KZG_MSM_OCC
 #define KZG_MSM_OCC 3
 #endif
+// LDSSORT: the sorted term list of the block lives in LDS, in the region that holds the bucket points afterwards
+// (256 x WORDS words; the host picks it when chunks_per_block x the block's terms fit: msm_lds_sort_fits).  The global
+// list is the general form (one large batch in few slices): its 4-byte scattered stores each cost a whole line of HBM
+// write traffic once the launch's lists outgrow the L2 (measured: 25 M stores -> 3.2 GB written per launch group).
 template <class CV>
+constexpr int msm_lds_sort_capacity() { return MSM_BUCKETS * CV::WORDS; }
+template <class CV, bool LDSSORT = false>
 __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     using Pt = typename CV::Pt;
     // blockIdx.z = (2*batch + output) * slices + slice
-    const int S = d.slices, bo = blockIdx.z / S, slice = blockIdx.z % S;
+    const int zz = (int)blockIdx.z + d.z0;  // logical z: (2 batch + output) * slices + slice
+    const int S = d.slices, bo = zz / S, slice = zz % S;
     const int w = blockIdx.x, o = bo & 1, tid = threadIdx.x;
     const int cpb = d.chunks_per_block, j0 = blockIdx.y * cpb;
     const int W = gridDim.x;                                              // windows (digit bytes) per chunk
@@ -458,9 +483,10 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     const uint32_t* tp = d.term_point + (size_t)bo * d.max_terms + t0;
     const uint32_t* tsc = d.term_scalar + (size_t)bo * d.max_terms + t0;
     // scratch of this block: the (window, chunk group) region of its output, then the slice's share of it
-    uint32_t* sorted = d.sorted + ((size_t)(bo * gridDim.y + blockIdx.y) * W + w) * cpb * d.max_terms + (size_t)cpb * t0;
     __shared__ uint32_t cnt[MSM_BUCKETS], off[MSM_BUCKETS + 1], cur[MSM_BUCKETS];
     __shared__ uint32_t pts[MSM_BUCKETS * CV::WORDS];  // 36 / 42 KiB: one Jacobian point per thread
+    uint32_t* const sorted_global = d.sorted + ((size_t)(bo * gridDim.y + blockIdx.y) * W + w) * cpb * d.max_terms + (size_t)cpb * t0;
+    // (compile-time choice: an LDS pointer or a global one, never a flat one)
     cnt[tid] = 0;
     cur[tid] = 0;
     __syncthreads();
@@ -488,7 +514,8 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
         for (int t = tid; t < nt; t += 256) {
             uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
             uint32_t pos = atomicAdd(&cur[dig], 1u);
-            sorted[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << 28;
+            if constexpr (LDSSORT) pts[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << 28;
+            else sorted_global[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << 28;
         }
     }
     __threadfence_block();
@@ -508,6 +535,14 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     __syncthreads();
     const int bucket = cur[tid];
     const typename CV::Mem* mult = static_cast<const typename CV::Mem*>(d.mult);
+    auto sorted_at = [&](uint32_t k) -> uint32_t {
+        if constexpr (LDSSORT) return pts[k];
+        else return sorted_global[k];
+    };
+    auto sorted_put = [&](uint32_t k, uint32_t v) {
+        if constexpr (LDSSORT) pts[k] = v;
+        else sorted_global[k] = v;
+    };
     Pt acc = CV::identity();
     if constexpr (CV::SPLIT) {
         // The common addition (accumulator finite, different x) is straight-line code; a pair that needs the complete
@@ -517,25 +552,25 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
         uint32_t k = bucket > 0 ? off[bucket] : 0u, w = k;
         const uint32_t kend = bucket > 0 ? off[bucket + 1] : 0u;
         if (k < kend) {  // the first entry of a bucket is a copy, not an addition to the identity
-            const uint32_t e = sorted[k++];
+            const uint32_t e = sorted_at(k++);
             acc = CV::from_entry(CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
             w = k;
         }
         for (; k < kend; k++) {
-            const uint32_t e = sorted[k];
+            const uint32_t e = sorted_at(k);
             const typename CV::Entry q = CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]);
             const typename CV::EntryHead h = CV::entry_head(acc, q);
-            if (CV::entry_special(h)) sorted[w++] = e;  // w <= k: only this thread reads or writes its bucket's list
+            if (CV::entry_special(h)) sorted_put(w++, e);  // w <= k: only this thread reads or writes its bucket's list
             else acc = CV::entry_tail(acc, q, h);
         }
         const uint32_t first = bucket > 0 ? off[bucket] + 1 : 0u;
         for (uint32_t j = first; j < w; j++) {  // rare
-            const uint32_t e = sorted[j];
+            const uint32_t e = sorted_at(j);
             acc = CV::add_entry(acc, CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
         }
     } else if (bucket > 0) {
         for (uint32_t k = off[bucket]; k < off[bucket + 1]; k++) {
-            const uint32_t e = sorted[k];
+            const uint32_t e = sorted_at(k);
             acc = CV::add_entry(acc, CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
         }
     }
@@ -549,27 +584,33 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     //      kind 1 cols  : dst = 16 (2 s k) + lo, src = dst + 16 s     (ops = 128 / s)   on a fresh copy of the buckets
     //      kind 2 scan  : suffix scan over the two 16-element vectors R (slots 0..15) and C (slots 16..31)
     //      kind 3 tree  : tree sum of the two scanned vectors (slot 0 / 16 of each zeroed first)
+    if constexpr (LDSSORT) __syncthreads();  // every list has been read: the region becomes the bucket points
     CV::lds_store(pts, bucket, acc);
     __syncthreads();
-    acc = CV::lds_load(pts, tid);  // from here on thread tid holds bucket tid again
-    Pt keep = CV::identity();  // threads 0..15: R_tid, threads 16..31: C_(tid-16)
+    // From here on thread tid looks after bucket tid.  The row trees run in place and destroy the bucket sums the column
+    // trees need: a copy waits in global memory (d.save; word-major, so a wavefront writes and reads whole lines).
+    // R and C get their own small LDS vectors for the scans.
+    __shared__ uint32_t rc[32 * CV::WORDS];  // R_0..R_15 | C_0..C_15
+    uint32_t* const save = d.save + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * CV::WORDS) * 256 + tid;
+#pragma unroll
+    for (int i = 0; i < CV::WORDS; i++) save[(size_t)i * 256] = pts[tid * CV::WORDS + i];
 #pragma unroll 1
     for (int lvl = 0; lvl < 16; lvl++) {
         const int kind = lvl >> 2, s = kind == 3 ? (8 >> (lvl & 3)) : (1 << (lvl & 3));
-        if (lvl == 4) {  // rows done: save R, restore the buckets for the column trees
-            if (tid < 16) keep = CV::lds_load(pts, 16 * tid);
+        if (lvl == 4) {  // rows done: R to its vector, the buckets back for the column trees
+            if (tid < 16) CV::lds_store(rc, tid, CV::lds_load(pts, 16 * tid));
             __syncthreads();
-            CV::lds_store(pts, tid, acc);
+#pragma unroll
+            for (int i = 0; i < CV::WORDS; i++) pts[tid * CV::WORDS + i] = save[(size_t)i * 256];
             __syncthreads();
-        } else if (lvl == 8) {  // columns done: lay out R | C for the scans
-            if (tid >= 16 && tid < 32) keep = CV::lds_load(pts, tid - 16);
-            __syncthreads();
-            if (tid < 32) CV::lds_store(pts, tid, keep);
+        } else if (lvl == 8) {  // columns done: C beside R
+            if (tid >= 16 && tid < 32) CV::lds_store(rc, tid, CV::lds_load(pts, tid - 16));
             __syncthreads();
         } else if (lvl == 12) {  // scans done: S_0 is not part of sum_{k>=1} S_k
-            if (tid < 32 && (tid & 15) == 0) CV::lds_store(pts, tid, CV::identity());
+            if (tid < 32 && (tid & 15) == 0) CV::lds_store(rc, tid, CV::identity());
             __syncthreads();
         }
+        uint32_t* const arr = kind < 2 ? pts : rc;
         bool active;
         int dst, src;
         if (kind == 0) {
@@ -592,30 +633,49 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
         }
         Pt x = CV::identity(), y = CV::identity();
         if (active) {
-            x = CV::lds_load(pts, dst);
-            y = CV::lds_load(pts, src);
+            x = CV::lds_load(arr, dst);
+            y = CV::lds_load(arr, src);
         }
         __syncthreads();  // scan levels read a slot that its owner rewrites in the same level
         if constexpr (CV::SPLIT) {
             // every path ends in its own store: no point value is merged across the paths (see the bucket loop)
             if (active) {
-                const G1AddHead h = g1j29_add_head(x, y);
-                if (h.p_inf | h.q_inf) CV::lds_store(pts, dst, h.p_inf ? y : x);  // empty buckets: common in small batches
-                else if (fp29_is_zero_mod_p(h.HH)) CV::lds_store(pts, dst, CV::add(x, y));
-                else CV::lds_store(pts, dst, g1j29_add_tail(x, y, h));
+                Fp29 Z1Z1, Z2Z2;
+                bool p_inf, q_inf;
+                g1j29_inf_flags(x, y, Z1Z1, Z2Z2, p_inf, q_inf);
+                if (p_inf | q_inf) {
+                    CV::lds_store(arr, dst, p_inf ? y : x);  // empty buckets: common in small batches
+                } else {
+                    const G1AddHead h = g1j29_add_head(x, y, Z1Z1, Z2Z2);  // x and y are dead from here
+                    if (g1j29_add_same_x(h)) CV::lds_store(arr, dst, g1j29_add_same_x_result(h));
+                    else CV::lds_store(arr, dst, g1j29_add_tail(h));
+                }
             }
         } else {
-            if (active) CV::lds_store(pts, dst, CV::add(x, y));
+            if (active) CV::lds_store(arr, dst, CV::add(x, y));
         }
         __syncthreads();
     }
     if (tid == 0) {
-        Pt r = CV::lds_load(pts, 0);  // sum hi * R_hi
+        Pt r = CV::lds_load(rc, 0);  // sum hi * R_hi
 #pragma unroll 1
         for (int k = 0; k < 4; k++) r = CV::dbl(r);
-        d.window_sums[wi] = CV::to_std(CV::add(r, CV::lds_load(pts, 16)));
+        d.window_sums[wi] = CV::to_std(CV::add(r, CV::lds_load(rc, 16)));
     }
 }
+
+// Host side: launch the window kernel over grid (gx, gy, gz) in z-pieces that fit the save area (save_bytes >= one z-layer).
+template <class CV, bool LDSSORT>
+inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, uint32_t* save, size_t save_bytes, hipStream_t st) {
+    const size_t layer = (size_t)gx * gy * 256 * CV::WORDS * 4;
+    unsigned per = (unsigned)std::min<size_t>(gz, std::max<size_t>(1, save_bytes / layer));
+    d.save = save;
+    for (unsigned z = 0; z < gz; z += per) {
+        d.z0 = (int)z;
+        hipLaunchKernelGGL((k_msm_window<CV, LDSSORT>), dim3(gx, gy, std::min(per, gz - z)), dim3(256), 0, st, d);
+    }
+}
+constexpr size_t msm_save_layer_bytes(unsigned gx, unsigned gy, int words) { return (size_t)gx * gy * 256 * words * 4; }
 
 // sums[(g * slices + k) * W + w] over the slices k -> out[g * W + w]; one 64-thread workgroup per (g, w) of every output
 __global__ __launch_bounds__(64) void k_msm_fold_slices(const G1Jac* __restrict__ sums, G1Jac* __restrict__ out, int slices, int W) {

@@ -13,14 +13,18 @@ void h_g1_add_affine(uint32_t* o, const uint32_t* p, const uint32_t* q) {
     G1Aff29 a; a.x = ld(q); a.y = ld(q + 14);
     stj(o, g1j29_add_affine(ldj(p), a));
 }
-// the two-halves forms (what the MSM window kernel's loops run): returns 1 when the caller must use the complete formula
-// (nothing is written then), 2 when an identity operand was passed through
+// the staged forms (what the MSM window kernel's loops run).  h_g1_add_split: always the complete result; returns 1 for the
+// same-x ending, 2 when an identity operand was passed through.  h_g1_madd_split: returns 1 when the caller must use the
+// complete formula (nothing is written then)
 int h_g1_add_split(uint32_t* o, const uint32_t* pp, const uint32_t* qq) {
     const G1Jac29 p = ldj(pp), q = ldj(qq);
-    const G1AddHead h = g1j29_add_head(p, q);
-    if (h.p_inf || h.q_inf) { stj(o, h.p_inf ? q : p); return 2; }
-    if (fp29_is_zero_mod_p(h.HH)) return 1;
-    stj(o, g1j29_add_tail(p, q, h));
+    Fp29 Z1Z1, Z2Z2;
+    bool p_inf, q_inf;
+    g1j29_inf_flags(p, q, Z1Z1, Z2Z2, p_inf, q_inf);
+    if (p_inf || q_inf) { stj(o, p_inf ? q : p); return 2; }
+    const G1AddHead h = g1j29_add_head(p, q, Z1Z1, Z2Z2);
+    if (g1j29_add_same_x(h)) { stj(o, g1j29_add_same_x_result(h)); return 1; }
+    stj(o, g1j29_add_tail(h));
     return 0;
 }
 int h_g1_madd_split(uint32_t* o, const uint32_t* pp, const uint32_t* qq) {

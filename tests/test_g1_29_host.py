@@ -164,9 +164,10 @@ def test_mixed_addition_and_special_cases(lib):
 
 
 def test_two_halves_forms(lib):
-    """g1j29_madd_head / _tail and g1j29_add_head / _tail (what the MSM window kernel's loops run): equal to the complete
-    formulas whenever they do not send the caller to them, which they do exactly for P + P, P - P and - in the mixed
-    form - an accumulator at infinity; the general form passes identity operands (Z = 0, p, 2p) through."""
+    """g1j29_madd_head / _tail (bucket loop) and g1j29_inf_flags / _add_head / _add_tail / _add_same_x_result (reduction
+    trees) - what the MSM window kernel's loops run.  The mixed form sends the caller to the complete formula exactly for
+    P + P, P - P and an accumulator at infinity; the general form is complete in stages: identity operands (Z = 0, p, 2p)
+    pass through, and the same-x ending (P + P as the doubling of (U1, S1, Z1 Z2); P - P) needs nothing but the head."""
     rng = random.Random(6)
 
     def run_flag(f, *args):
@@ -197,8 +198,9 @@ def test_two_halves_forms(lib):
         for x, y in ((wa2, wb), (wb, wa2)):
             w, flag = run_flag(lib.h_g1_add_split, x, y)
             assert flag == (1 if kind in (5, 6) else 2 if kind == 7 else 0)
-            if flag != 1:
-                assert from_jac(w) == ec_add(a, b)
+            assert from_jac(w) == ec_add(a, b)  # the same-x ending is computed from the head alone
+            if flag == 0:
+                check_bounds(w, 14, 6, 2)
         if kind == 7:  # identity + identity
             w, flag = run_flag(lib.h_g1_add_split, wa2, to_jac(rng, None, 1024, 1024, 3))
             assert flag == 2 and from_jac(w) is None
