@@ -2,12 +2,15 @@
 // Part of the single translation unit kzg_capi.hip; not a stand-alone header.
 
 // ---------------------------------------------------------------- host helpers
+// (SHA-256, big-endian scalar helpers, the trusted-setup text parser and the transcript hash live in host_only.hpp: plain C++
+// without HIP, so that they also build with g++ -fsanitize=address,undefined - tests/test_host_only_sanitized.py)
 static thread_local std::string g_err;
 static KzgRet fail(KzgRet rc, const std::string& msg) {
     g_err = msg;
     return rc;
 }
 extern "C" const char* kzg_last_error(void) { return g_err.c_str(); }
+#include "host_only.hpp"
 
 #define HIPCHK(expr)                                                                                       \
     do {                                                                                                   \
@@ -26,118 +29,6 @@ static void elapsed(float* out, hipEvent_t a, hipEvent_t b) {
         (void)hipGetLastError();
         *out = 0.f;
     }
-}
-
-// SHA-256 (FIPS 180-4) for the batch transcript - host code, independent of the device kernel
-namespace hostsha {
-alignas(16) static const uint32_t K[64] = {
-    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
-    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
-    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
-    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
-    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
-    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
-    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
-static inline uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
-static void block(uint32_t st[8], const uint8_t* p) {
-    uint32_t w[64];
-    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
-    for (int i = 16; i < 64; i++) {
-        uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10);
-        w[i] = w[i - 16] + s0 + w[i - 7] + s1;
-    }
-    uint32_t a = st[0], b = st[1], c = st[2], d = st[3], e = st[4], f = st[5], g = st[6], h = st[7];
-    for (int i = 0; i < 64; i++) {
-        uint32_t t1 = h + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
-        uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
-        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-    }
-    st[0] += a; st[1] += b; st[2] += c; st[3] += d; st[4] += e; st[5] += f; st[6] += g; st[7] += h;
-}
-#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
-}  // namespace hostsha
-#include <immintrin.h>
-namespace hostsha {
-// x86 SHA extensions (runtime-detected): the batch transcript is one serial chain, so per-block latency is
-// what matters; sha256rnds2 does it at ~1.5 GB/s per core.
-__attribute__((target("sha,sse4.1,ssse3"))) static void blocks_ni(uint32_t st[8], const uint8_t* data, size_t nblocks) {
-    const __m128i MASK = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
-    __m128i TMP = _mm_loadu_si128((const __m128i*)&st[0]);
-    __m128i STATE1 = _mm_loadu_si128((const __m128i*)&st[4]);
-    TMP = _mm_shuffle_epi32(TMP, 0xB1);
-    STATE1 = _mm_shuffle_epi32(STATE1, 0x1B);
-    __m128i STATE0 = _mm_alignr_epi8(TMP, STATE1, 8);
-    STATE1 = _mm_blend_epi16(STATE1, TMP, 0xF0);
-    while (nblocks--) {
-        const __m128i ABEF = STATE0, CDGH = STATE1;
-        __m128i M[4];
-        for (int g = 0; g < 16; g++) {
-            if (g < 4) M[g] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(data + 16 * g)), MASK);
-            __m128i msg = _mm_add_epi32(M[g & 3], _mm_loadu_si128((const __m128i*)&K[4 * g]));
-            STATE1 = _mm_sha256rnds2_epu32(STATE1, STATE0, msg);
-            if (g >= 3 && g < 15) {
-                __m128i t = _mm_alignr_epi8(M[g & 3], M[(g - 1) & 3], 4);
-                M[(g + 1) & 3] = _mm_sha256msg2_epu32(_mm_add_epi32(M[(g + 1) & 3], t), M[g & 3]);
-            }
-            msg = _mm_shuffle_epi32(msg, 0x0E);
-            STATE0 = _mm_sha256rnds2_epu32(STATE0, STATE1, msg);
-            if (g >= 1 && g < 13) M[(g - 1) & 3] = _mm_sha256msg1_epu32(M[(g - 1) & 3], M[g & 3]);
-        }
-        STATE0 = _mm_add_epi32(STATE0, ABEF);
-        STATE1 = _mm_add_epi32(STATE1, CDGH);
-        data += 64;
-    }
-    TMP = _mm_shuffle_epi32(STATE0, 0x1B);
-    STATE1 = _mm_shuffle_epi32(STATE1, 0xB1);
-    STATE0 = _mm_blend_epi16(TMP, STATE1, 0xF0);
-    STATE1 = _mm_alignr_epi8(STATE1, TMP, 8);
-    _mm_storeu_si128((__m128i*)&st[0], STATE0);
-    _mm_storeu_si128((__m128i*)&st[4], STATE1);
-}
-static bool have_ni() {
-    static const bool v = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") && __builtin_cpu_supports("ssse3");
-    return v;
-}
-#else
-static bool have_ni() { return false; }
-static void blocks_ni(uint32_t*, const uint8_t*, size_t) {}
-#endif
-static void digest(uint8_t out[32], const uint8_t* data, size_t len) {
-    uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-    size_t full = len / 64;
-    if (have_ni()) blocks_ni(st, data, full);
-    else
-        for (size_t i = 0; i < full; i++) block(st, data + 64 * i);
-    uint8_t tail[128] = {0};
-    size_t rem = len - 64 * full;
-    memcpy(tail, data + 64 * full, rem);
-    tail[rem] = 0x80;
-    size_t tl = rem + 9 <= 64 ? 64 : 128;
-    uint64_t bits = (uint64_t)len * 8;
-    for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
-    block(st, tail);
-    if (tl == 128) block(st, tail + 64);
-    for (int i = 0; i < 8; i++) {
-        out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16);
-        out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i];
-    }
-}
-}  // namespace hostsha
-
-// r (big-endian) and helpers on 32-byte big-endian integers
-static const uint8_t R_BE[32] = {0x73, 0xed, 0xa7, 0x53, 0x29, 0x9d, 0x7d, 0x48, 0x33, 0x39, 0xd8, 0x08, 0x09, 0xa1, 0xd8, 0x05,
-                                 0x53, 0xbd, 0xa4, 0x02, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0xff, 0xff, 0xff, 0x00, 0x00, 0x00, 0x01};
-static bool be_geq_r(const uint8_t v[32]) { return memcmp(v, R_BE, 32) >= 0; }
-static void be_sub_r(uint8_t v[32]) {
-    int borrow = 0;
-    for (int i = 31; i >= 0; i--) {
-        int d = (int)v[i] - R_BE[i] - borrow;
-        borrow = d < 0;
-        v[i] = (uint8_t)(d + (borrow << 8));
-    }
-}
-static void reverse32(uint8_t* dst, const uint8_t* src) {
-    for (int i = 0; i < 32; i++) dst[i] = src[31 - i];
 }
 
 // a scratch device allocation of one call: released on every path out of the function (hipFree waits for the work that

@@ -323,54 +323,13 @@ static KzgRet settings_load_points(KzgSettings* s, const std::vector<uint8_t>& g
     return KZG_OK;
 }
 
-static int hexnib(int c) {
-    if (c >= '0' && c <= '9') return c - '0';
-    if (c >= 'a' && c <= 'f') return c - 'a' + 10;
-    if (c >= 'A' && c <= 'F') return c - 'A' + 10;
-    return -1;
-}
-
 extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char* txt, size_t len) {
     if (!out || !txt) return fail(KZG_BADARGS, "null argument");
-    // line-oriented parse of build.rs:23-56
-    std::vector<std::pair<const char*, size_t>> lines;
-    const char *p = txt, *end = txt + len;
-    while (p < end) {
-        const char* q = (const char*)memchr(p, '\n', (size_t)(end - p));
-        if (!q) q = end;
-        size_t l = (size_t)(q - p);
-        if (l && p[l - 1] == '\r') l--;
-        lines.emplace_back(p, l);
-        p = q + 1;
-    }
-    if (lines.size() < 2) return fail(KZG_BAD_SETUP, "trusted setup: missing header lines");
-    long n1 = strtol(std::string(lines[0].first, lines[0].second).c_str(), nullptr, 10);
-    long n2 = strtol(std::string(lines[1].first, lines[1].second).c_str(), nullptr, 10);
-    if (n1 != FE_PER_BLOB) return fail(KZG_BAD_SETUP, "trusted setup: expected 4096 G1 points");
-    if (n2 < 2 || (long)lines.size() < 2 + n1 + n2) return fail(KZG_BAD_SETUP, "trusted setup: truncated file");
-    // hex -> bytes for every point line (hex_to_bytes, build.rs:15-21: KzgError::InvalidHexFormat)
-    auto unhex = [&](uint8_t* dst, const std::pair<const char*, size_t>& ln, size_t nbytes) {
-        if (ln.second != 2 * nbytes) return false;
-        for (size_t i = 0; i < nbytes; i++) {
-            int a = hexnib(ln.first[2 * i]), b = hexnib(ln.first[2 * i + 1]);
-            if (a < 0 || b < 0) return false;
-            dst[i] = (uint8_t)(a << 4 | b);
-        }
-        return true;
-    };
-    std::vector<uint8_t> g1b(48 * (size_t)n1), g2b(96 * (size_t)n2);
+    std::vector<uint8_t> g1b, g2b;
     uint8_t first[2][48];
-    for (long i = 0; i < n1; i++) {
-        // stored bit-reversal permuted (build.rs:79,89-105): file line i -> slot brp(i)
-        uint8_t tmp[48];
-        if (!unhex(tmp, lines[2 + i], 48)) return fail(KZG_BAD_SETUP, "trusted setup: bad G1 line");
-        if (i < 2) memcpy(first[i], tmp, 48);
-        uint32_t r = 0;
-        for (int k = 0; k < 12; k++) r |= ((uint32_t)(i >> k) & 1u) << (11 - k);
-        memcpy(g1b.data() + 48 * (size_t)r, tmp, 48);
-    }
-    for (long i = 0; i < n2; i++)
-        if (!unhex(g2b.data() + 96 * (size_t)i, lines[2 + n1 + i], 96)) return fail(KZG_BAD_SETUP, "trusted setup: bad G2 line");
+    long n1 = 0, n2 = 0;
+    std::string perr;
+    if (!hostparse::trusted_setup_text(txt, len, g1b, g2b, first, n1, n2, perr)) return fail(KZG_BAD_SETUP, perr);
     KzgRet rc = settings_common(out, g2b.data() + 96);
     if (rc != KZG_OK) return rc;
     KzgSettings* s = *out;

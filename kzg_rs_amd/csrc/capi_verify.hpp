@@ -364,46 +364,6 @@ static KzgRet phase1_wait_locked(uint8_t* records_out, uint8_t* bad_out, const K
     return KZG_OK;
 }
 
-// compute_r_powers' hash (src/kzg_proof.rs:291-348) for B batches: r_b = SHA-256(domain || degree || n_total || records of batch b) mod r,
-// written as 32 little-endian bytes (= Scalar::to_bytes(), the device limb layout) to r_out + 32 b.  Pure host code (SHA-NI):
-// one serial chain of 160 n_total + 32 bytes per batch - hopeless on a GPU lane, ~2 GB/s on a CPU core - and the batches are
-// independent, so they are spread over a few host threads (KZG_HOST_THREADS, default 16).  Record layouts:
-//   world == 0 : [B][n_total]       every batch's records in global blob order
-//   world  > 0 : [world][B][n]      as an all-gather / all-to-all of equal shards leaves them (n_total = world n)
-static void host_batch_challenges(uint8_t* r_out, const uint8_t* all_records, size_t B, size_t n, size_t n_total, size_t world) {
-    auto digest_range = [&](size_t b0, size_t b1) {
-        std::vector<uint8_t> t(32 + 160 * n_total);
-        memcpy(t.data(), "RCKZGBATCH___V1_", 16);
-        memset(t.data() + 16, 0, 16);
-        t[22] = (uint8_t)(FE_PER_BLOB >> 8);
-        t[23] = (uint8_t)(FE_PER_BLOB & 0xff);
-        for (int k = 0; k < 8; k++) t[24 + k] = (uint8_t)((uint64_t)n_total >> (56 - 8 * k));
-        for (size_t b = b0; b < b1; b++) {
-            if (world == 0) memcpy(t.data() + 32, all_records + 160 * n_total * b, 160 * n_total);
-            else
-                for (size_t k = 0; k < world; k++) memcpy(t.data() + 32 + 160 * n * k, all_records + 160 * n * (k * B + b), 160 * n);
-            uint8_t dg[32];
-            hostsha::digest(dg, t.data(), t.size());
-            while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r: at most two subtractions (2^256 < 3r)
-            reverse32(r_out + 32 * b, dg);
-        }
-    };
-    static const size_t host_threads = [] {
-        const char* e = getenv("KZG_HOST_THREADS");
-        long v = e ? atol(e) : 16;
-        return (size_t)(v < 1 ? 1 : v > 64 ? 64 : v);
-    }();
-    const size_t nthr = std::min(host_threads, std::min(B, (B * 160 * n_total) / (512 * 1024) + 1));
-    if (nthr <= 1) {
-        digest_range(0, B);
-    } else {
-        std::vector<std::thread> pool;
-        for (size_t k = 1; k < nthr; k++) pool.emplace_back(digest_range, B * k / nthr, B * (k + 1) / nthr);
-        digest_range(0, B / nthr);
-        for (auto& th : pool) th.join();
-    }
-}
-
 // Phase 2: per batch b, this shard's scalars r_b^(offset+i) and its partial sums (A, B)_b.  Requires phase 1 of the same group on
 // this handle.  r_b comes from the batch's FULL transcript, in one of four ways:
 //   r_le != NULL                      : given by the caller, B x 32 little-endian bytes (kzg_batch_challenges on some rank)
@@ -641,17 +601,21 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
 // the GPU: the rate is the link's (~56 GB/s measured on MI355X = ~0.43 M blobs/s), not copy + compute.  A pageable
 // hipMemcpyAsync holds the calling thread until the data has left (measured: 2.4 ms per 128 MiB either way), so each chunk's
 // copy is issued in two halves around the host-side steps of the chunk in flight (flags, transcript hashes, launches).
-// KZG_HOST_CHUNK = batches per chunk (default 8: 2 x 1 GiB of staging at n = 1024).
+// KZG_HOST_CHUNK = batches per chunk (default: half the stream, at most 32).
 extern "C" KzgRet kzg_verify_blob_kzg_proof_batches(bool* ok_out, uint8_t* err_out, const uint8_t* blobs, const uint8_t* commitments,
                                                     const uint8_t* proofs, size_t n, size_t n_batches, const KzgSettings* s) {
     KZG_ENTER(s && ok_out && blobs && commitments && proofs && n && n_batches);
-    static const size_t chunk_pref = [] {
+    static const size_t chunk_forced = [] {
         const char* e = getenv("KZG_HOST_CHUNK");
-        long v = e ? atol(e) : 8;
-        return (size_t)(v < 1 ? 1 : v > 4096 ? 4096 : v);
+        long v = e ? atol(e) : 0;
+        return (size_t)(v < 0 ? 0 : v > 4096 ? 4096 : v);
     }();
-    // chunk: whole batches, ~8 Ki blobs by default (a short first copy and a short last verification: nothing overlaps those), never more than one launch group can hold
-    size_t G = std::min(std::min(chunk_pref, n_batches), (size_t)MAX_BATCHES_PER_LAUNCH);
+    // chunk: whole batches.  Large chunks on purpose: the driver pins and unpins the pageable source around every copy
+    // (~0.6 ms per 128 MiB on top of the 2.3 ms of DMA: measured 47-49 GB/s for 2-4 GiB copies, 38 GB/s for 0.5 GiB ones),
+    // and a chunk must outlast the latency-bound phases of the chunk before it (~6 ms) to hide them.  Half the stream, 32
+    // batches at most (2 x 4 GiB of staging at n = 1024).
+    size_t G = chunk_forced ? chunk_forced : std::max<size_t>(1, std::min<size_t>(32, (n_batches + 1) / 2));
+    G = std::min(std::min(G, n_batches), (size_t)MAX_BATCHES_PER_LAUNCH);
     while (G > 1 && G * n > (size_t)1 << 17) G /= 2;  // <= 128 Ki blobs (16 GiB) per staging set
     Workspace& w = s->ws;
     KzgRet rc = ws_reserve(s, G * n, G, STAGE_NONE);

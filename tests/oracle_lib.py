@@ -5,7 +5,8 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+# KZG_ORACLE_LIB: another build of the same sources (the ASan one, tests/test_host_only_sanitized.py)
+LIB = os.environ.get("KZG_ORACLE_LIB") or os.path.join(ORACLE_DIR, "liboracle.so")
 
 OK, BADARGS, ERROR, INVALID_LENGTH = 0, 1, 2, 4
 

@@ -782,7 +782,7 @@ def test_finish_without_matching_group_is_rejected(settings):
 def test_host_fed_stream_of_batches():
     """kzg_verify_blob_kzg_proof_batches: batches in HOST memory, copied in chunks on a copy stream while the previous chunk is
     verified.  Same results as the oracle batch by batch - a wrong proof, an invalid blob and an invalid commitment among
-    valid batches - in one chunk (5 batches of 6), across five chunks (40 batches of 1: chunks of 8), and with KZG_HOST_CHUNK-independent layout; then a second call with a larger chunk on the same handle
+    valid batches - in chunks of 3 + 2 (5 batches of 6) and 20 + 20 (40 batches of 1), and with KZG_HOST_CHUNK-independent layout; then a second call with a larger chunk on the same handle
     (staging sets regrown)."""
     from kzg_rs_amd import synth
     n, B = 6, 5
@@ -805,11 +805,12 @@ def test_host_fed_stream_of_batches():
                 out.append(None)
         return out
 
-    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 1, 40, st) == want(1, 40)   # five chunks of 8
+    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 1, 40, st) == want(1, 40)   # two chunks of 20
     w65 = want(6, 5)
     assert w65 == [True, False, None, None, True]
     assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 6, 5, st) == w65            # one chunk, larger staging sets
-    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 2, 20, st) == want(2, 20)    # three chunks: 8, 8, 4
+    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 2, 19, st) == want(2, 19)    # two uneven chunks: 10, 9
+    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 1, 1, st) == want(1, 1)      # a stream of one
 
 
 def test_host_entry_full_size_batch():
@@ -840,3 +841,42 @@ def test_host_entry_full_size_batch():
     three = np.concatenate([blobs, blobs, bad_blobs])
     got = api.verify_blob_kzg_proof_batches(three.ctypes.data, hc + hc + hc, hp + hbp + hp, n, 3, st)
     assert got == [True, False, None]
+
+
+def test_handles_release_device_memory_and_oom_is_malloc():
+    """(a) 50 settings handles created, used (so that each grows its workspace) and freed: the device's free memory returns
+    to where it was (no leak in the handle, its streams, tables or workspace).  (b) a request the device cannot hold is
+    KZG_MALLOC - c-kzg-4844's C_KZG_MALLOC, not a generic error - and the handle keeps working afterwards."""
+    import ctypes as C
+    import torch
+    from kzg_rs_amd import synth
+    from kzg_rs_amd.distributed import HipBackend
+    tau_g2 = synth.synthetic_setup()[1]
+    blobs, cs, ps, st0 = synth.make_valid_batch(4, seed=81)
+    d_b = torch.from_numpy(blobs).cuda()
+    d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).cuda()
+    d_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+
+    def cycle(k):
+        for _ in range(k):
+            h = KzgSettings.from_tau_g2(tau_g2)
+            assert KzgProof.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 4, h) is True
+            assert api.pairing_check(G1_GEN, G1_INF, h) is False
+            h.close()
+
+    cycle(3)  # first-use allocations of the runtime itself (code objects, stream pools) happen here
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    cycle(50)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < (8 << 20), "device memory not returned: %d bytes" % (free0 - free1)
+    # (b) a launch group of 2^24 blobs needs terabytes of workspace
+    HipBackend(st0)  # declares the argtypes
+    rc = api.lib().kzg_shard_phase1_launch(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 1 << 24, 1, st0._h)
+    assert rc == api.KZG_MALLOC, (rc, api.lib().kzg_last_error())
+    assert KzgProof.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 4, st0) is True
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free1 - free2 < (64 << 20)  # the failed reservation left nothing behind
