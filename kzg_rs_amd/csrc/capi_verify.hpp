@@ -28,31 +28,34 @@ static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const F
     return KZG_OK;
 }
 
-// The challenge kernel over T blobs on stream s1: the producer/consumer form (half the serial chain, lowest latency)
-// while every pair of waves can have a CU to itself, the one-lane-per-blob form (highest throughput) beyond that.
-// KZG_CHALLENGE_KERNEL = lane | split forces one of them (A/B measurement, cross-check in the tests).
+// The challenge kernel over T blobs on stream s1: a producer / consumer form (the serial chain split over wavefronts, lowest
+// latency) while every workgroup can have a CU to itself, the one-lane-per-blob form (highest throughput) beyond that.
+// The latency form has two lanes per blob on the consumer side (k_blob_challenge_split2); KZG_CHALLENGE_KERNEL = lane |
+// split | split2 forces a form (A/B measurement, cross-check in the tests).
 static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const void* d_commitments, Fr* d_z, size_t T) {
     static const int forced = [] {
         const char* e = getenv("KZG_CHALLENGE_KERNEL");
-        return !e ? 0 : strcmp(e, "lane") == 0 ? 1 : strcmp(e, "split") == 0 ? 2 : 0;
+        return !e ? 0 : strcmp(e, "lane") == 0 ? 1 : strcmp(e, "split") == 0 ? 2 : strcmp(e, "split2") == 0 ? 3 : 0;
     }();
     const uint8_t *bl = (const uint8_t*)d_blobs, *cm = (const uint8_t*)d_commitments;
-    const bool lane = forced ? forced == 1 : T > 64 * 256;
+    const int form = forced ? forced : T > 64 * 256 ? 1 : 3;
     s->ws.ktime_valid = false;
-    if (lane) {
+    if (form == 1) {
         unsigned long long* kt = s->ws.d_ktime;  // null for callers that never reserved the workspace
         if (kt) {
             HIPCHK(hipMemsetAsync(kt, 0, 16, s->s1));
             s->ws.ktime_valid = true;
         }
         hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s->s1, bl, cm, d_z, (int)T, kt);
-    } else
+    } else if (form == 2) {
         hipLaunchKernelGGL(k_blob_challenge_split, dim3((unsigned)((T + 63) / 64)), dim3(128), 0, s->s1, bl, cm, d_z, (int)T);
+    } else {
+        hipLaunchKernelGGL(k_blob_challenge_split2, dim3((unsigned)((T + 63) / 64)), dim3(192), 0, s->s1, bl, cm, d_z, (int)T);
+    }
     HIPCHK(hipGetLastError());
     return KZG_OK;
 }
 
-// Workspace for a launch group of B batches with T blobs in total (B = 1 for the single-call entry points).
 // stage: host-input staging wanted - STAGE_BLOBS (T blobs + their commitments / proofs) or STAGE_CP (commitments / proofs only)
 enum { STAGE_NONE = 0, STAGE_BLOBS = 1, STAGE_CP = 2 };
 static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, int stage) {

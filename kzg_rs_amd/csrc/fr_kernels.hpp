@@ -270,6 +270,128 @@ __global__ __launch_bounds__(128) void k_blob_challenge_split(const uint8_t* __r
     }
 }
 
+// The same with TWO LANES PER BLOB on the consumer side (sha256.hpp: sha256_round_2lane): a workgroup of three wavefronts
+// serves 64 blobs - wave 2 is the producer (one lane per blob, as above), waves 0 and 1 run the rounds for 32 blobs each,
+// the even lane of a pair on the a-chain, the odd lane on the e-chain.  ~735 instructions per block on the serial chain
+// instead of ~930.  The (K + W) tile is read by both lanes of a pair at the same address; the even lanes read a row of
+// zeros instead (their sum takes no message word).
+__global__ __launch_bounds__(192) void k_blob_challenge_split2(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
+                                                               Fr* __restrict__ z_out, int n) {
+    __shared__ uint4 tile[CHALLENGE_TILE_U4];
+    __shared__ uint4 zero_row[64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0, 1 consumers; 2 producer
+    constexpr int NBLK = 2050;
+    if (threadIdx.x < 64) zero_row[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    if (wave == 2) {
+        int i = blockIdx.x * 64 + lane;
+        if (i >= n) i = n - 1;  // redundant work keeps the barriers uniform
+        const uint4* blob = reinterpret_cast<const uint4*>(blobs + (size_t)i * BLOB_BYTES);
+        const uint4* cm = reinterpret_cast<const uint4*>(commitments + (size_t)i * 48);
+        // expand the 16 message words of transcript block b, hand (W + K)[0..64) to the consumer
+        auto emit = [=](uint32_t (&w)[16], int b) {
+            uint32_t kw[64];
+            sha256_schedule_kw(kw, w);
+            uint4* dst = tile + (b & 1) * (16 * 64) + lane;
+#pragma unroll
+            for (int t = 0; t < 16; t++) dst[t * 64] = make_uint4(kw[4 * t], kw[4 * t + 1], kw[4 * t + 2], kw[4 * t + 3]);
+            __syncthreads();  // block b is ready; the consumer is done with block b - 1, whose buffer block b + 1 reuses
+        };
+        // The transcript is a 32-byte header followed by the blob, so its 64-byte blocks straddle the blob's 128-byte
+        // cache lines: line m = blob bytes [128 m, 128 m + 128) feeds block 2m = (32 bytes carried over | L0 L1),
+        // block 2m + 1 = (L2 .. L5) and carries (L6 L7) on.  A lane fetches a WHOLE line with eight back-to-back
+        // 16-byte loads and then lives on it for two blocks: every lane of the wave streams a different blob, so a
+        // load instruction touches 64 different lines, and fetching a line 16 bytes at a time over two blocks re-reads
+        // it from L2 up to eight times once the CU's producers outrun the 32 KiB L1.
+        uint4 L[8], c0, c1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) L[j] = blob[j];
+#pragma unroll 1
+        for (int m = 0; m < 1024; m++) {
+            uint32_t w[16];
+            if (m == 0) {
+                w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;  // "FSBLOBVERIFY_V1_"
+                w[4] = 0; w[5] = 0; w[6] = 0; w[7] = FE_PER_BLOB;                            // u64_be(0) | u64_be(4096)
+            } else {
+                bswap4(w, c0);
+                bswap4(w + 4, c1);
+            }
+            bswap4(w + 8, L[0]);
+            bswap4(w + 12, L[1]);
+            emit(w, 2 * m);
+            bswap4(w, L[2]); bswap4(w + 4, L[3]); bswap4(w + 8, L[4]); bswap4(w + 12, L[5]);
+            c0 = L[6];
+            c1 = L[7];
+            if (m + 1 < 1024) {  // the next line, in flight while block 2m + 1 is expanded
+                const uint4* p = blob + 8 * (m + 1);
+#pragma unroll
+                for (int j = 0; j < 8; j++) L[j] = p[j];
+            } else {
+                L[0] = cm[0]; L[1] = cm[1]; L[2] = cm[2];
+            }
+            emit(w, 2 * m + 1);
+        }
+        {
+            uint32_t w[16];
+            bswap4(w, c0); bswap4(w + 4, c1); bswap4(w + 8, L[0]); bswap4(w + 12, L[1]);  // blob tail | commitment[0..32)
+            emit(w, 2048);
+            bswap4(w, L[2]);  // commitment[32..48) + 0x80 pad + bit length
+            w[4] = 0x80000000u;
+#pragma unroll
+            for (int k = 5; k < 15; k++) w[k] = 0;
+            w[15] = 131152u * 8u;
+            emit(w, 2049);
+        }
+        __syncthreads();
+    } else {
+        const int blob_in_block = 32 * wave + (lane >> 1);
+        int i = blockIdx.x * 64 + blob_in_block;
+        const bool live = i < n;
+        const bool a_lane = (lane & 1) == 0;
+        Sha2LaneConsts c;
+        c.n1 = a_lane ? 2u : 6u;
+        c.n2 = a_lane ? 13u : 11u;
+        c.n3 = a_lane ? 22u : 25u;
+        c.m = a_lane ? 0xffffffffu : 0u;
+        // this lane's half of the state: h0..h3 (a-chain) or h4..h7 (e-chain)
+        uint32_t H0 = a_lane ? 0x6a09e667u : 0x510e527fu, H1 = a_lane ? 0xbb67ae85u : 0x9b05688cu, H2 = a_lane ? 0x3c6ef372u : 0x1f83d9abu,
+                 H3 = a_lane ? 0xa54ff53au : 0x5be0cd19u;
+        __syncthreads();
+#pragma unroll 1
+        for (int b = 0; b < NBLK; b++) {
+            uint32_t x0 = H0, x1 = H1, x2 = H2, dd = H3;
+            // all 16 LDS reads of the block at once (they pipeline); the even lanes read zeros
+            const uint4* src = a_lane ? zero_row + lane : tile + (b & 1) * (16 * 64) + blob_in_block;
+            const int stride = a_lane ? 0 : 64;
+            uint4 kw[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) kw[t] = src[t * stride];
+            uint32_t hk = (H3 & ~c.m) + kw[0].x;  // x3 + kw of round 0
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                asm volatile("" : "+v"(kw[t].x), "+v"(kw[t].y), "+v"(kw[t].z), "+v"(kw[t].w));  // keep the reads hoisted
+                sha256_rounds4_2lane(x0, x1, x2, hk, dd, kw[t], t < 15 ? kw[t + 1].x : 0u, c);
+            }
+            // after the last round hk = x3 + 0: h on the odd lanes, 0 on the even ones
+            H0 += x0;
+            H1 += x1;
+            H2 += x2;
+            H3 += a_lane ? dd : hk;  // d sits in dd on the even lanes, h in hk on the odd ones
+            __syncthreads();
+        }
+        // the odd lane's words to the even lane, which reduces the digest and writes z
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H0, 0xB1, 0xF, 0xF, true), e1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H1, 0xB1, 0xF, 0xF, true);
+        const uint32_t e2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H2, 0xB1, 0xF, 0xF, true), e3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H3, 0xB1, 0xF, 0xF, true);
+        if (live && a_lane) {
+            const uint32_t hh[8] = {H0, H1, H2, H3, e0, e1, e2, e3};
+            Fr dgst;
+#pragma unroll
+            for (int k = 0; k < 8; k++) dgst.l[k] = hh[7 - k];
+            z_out[i] = FrF::from_mont(FrF::to_mont(dgst));
+        }
+    }
+}
+
 // ---------------------------------------------------------------- evaluation (one wavefront per blob)
 __device__ __forceinline__ Fr fr_shfl_xor(const Fr& a, int mask) {
     Fr r;

@@ -92,4 +92,51 @@ __device__ __forceinline__ void sha256_rounds4(uint32_t& a, uint32_t& b, uint32_
     }
 }
 
+// ---- two lanes per hash state (the latency form of the challenge kernel, fr_kernels.hpp: k_blob_challenge_split2).
+// A wavefront issues at most one instruction every ~4.3 cycles whatever it is, so ONE blob's serial chain is as fast as its
+// instruction count per block allows: the even lane of a pair carries (a, b, c) and d, the odd lane (e, f, g, h), and one
+// uniform instruction stream serves both - 11 instructions per round instead of 14.5:
+//   x0..x2 : a, b, c | e, f, g         x3 : 0 | h          dd : d | -
+//   Sigma  : three v_alignbit with the rotation amounts in a VGPR (2, 13, 22 | 6, 11, 25) + one xor3
+//   F      : Maj(a, b, c) = Ch(~(a ^ b), b, c) | Ch(e, f, g): u = bitop3(x0, x1, m) (m = ~0 | 0), F = bitop3(u, x1, x2, Ch)
+//   w      : Sigma + F + hk,  hk = x3 + kw  =  T2 | T1   (kw reads as zero on the even lanes; hk is prepared a round ahead)
+//   x0'    : w + swap(y),  y = dd | w  (one v_cndmask; a DPP bank mask selects groups of four lanes, not odd lanes),
+//            swap = quad_perm [1,0,3,2]:  T2 + T1 | T1 + d
+//   x3'    : x2 & ~m  (0 | g),  dd' = x2
+struct Sha2LaneConsts {
+    uint32_t n1, n2, n3;  // rotation amounts of this lane's Sigma
+    uint32_t m;           // ~0 on the even (a-chain) lanes, 0 on the odd (e-chain) lanes
+};
+// hk = x3 + kw of THIS round (prepared during the previous one); kw_next = the next round's message word.  The two
+// instructions that prepare the next round sit between the select that writes y and the DPP add that reads it across
+// lanes (a VALU write followed by a DPP read needs two wait states: an s_nop otherwise, one issue slot per round).
+__device__ __forceinline__ void sha256_round_2lane(uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& hk, uint32_t& dd, uint32_t kw_next,
+                                                   const Sha2LaneConsts& c) {
+    const uint32_t S = xor3(__builtin_amdgcn_alignbit(x0, x0, c.n1), __builtin_amdgcn_alignbit(x0, x0, c.n2), __builtin_amdgcn_alignbit(x0, x0, c.n3));
+    const uint32_t u = __builtin_amdgcn_bitop3_b32(x0, x1, c.m, 0xD2);  // m ? ~(x0 ^ x1) : x0
+    const uint32_t F = sha_ch(u, x1, x2);
+    const uint32_t w = S + F + hk;
+    const uint32_t y = c.m ? dd : w;  // even lanes: d, odd lanes: T1
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t x3n = x2 & ~c.m;   // next round's h (odd lanes) / 0 (even lanes)
+    uint32_t hkn = x3n + kw_next;
+    asm volatile("" : "+v"(hkn));     // (keeps the addition here: reassociation would sink it into the next round's sum)
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0xB1, 0xF, 0xF, true);  // the pair's other lane
+    const uint32_t nx = w + t;
+    dd = x2;
+    hk = hkn;
+    x2 = x1;
+    x1 = x0;
+    x0 = nx;
+}
+// four rounds; kwz = this quad's message words (zero on the even lanes), kw_after = the first word of the next quad
+__device__ __forceinline__ void sha256_rounds4_2lane(uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& hk, uint32_t& dd, const uint4& kwz,
+                                                     uint32_t kw_after, const Sha2LaneConsts& c) {
+    sha256_round_2lane(x0, x1, x2, hk, dd, kwz.y, c);
+    sha256_round_2lane(x0, x1, x2, hk, dd, kwz.z, c);
+    sha256_round_2lane(x0, x1, x2, hk, dd, kwz.w, c);
+    sha256_round_2lane(x0, x1, x2, hk, dd, kw_after, c);
+}
+
 }  // namespace kzg

@@ -296,10 +296,11 @@ def test_challenge_and_evaluate_random(settings, osettings):
     assert ys == [O.evaluate_polynomial_in_evaluation_form(b, z, osettings) for b, z in zip(blobs, pts)]
 
 
-@pytest.mark.parametrize("form", ["lane", "split"])
+@pytest.mark.parametrize("form", ["lane", "split", "split2"])
 def test_challenge_kernel_forms(form):
-    """Both forms of the challenge kernel (fr_kernels.hpp: one lane per blob = the throughput form, producer/consumer =
-    the latency form; the library picks by launch size) on the same 130 blobs, each in a child process that forces it."""
+    """All forms of the challenge kernel (fr_kernels.hpp: one lane per blob = the throughput form; producer / consumer with one
+    lane per blob; producer / consumer with two lanes per blob = the latency form; the library picks by launch size) on the
+    same 130 blobs, each in a child process that forces it."""
     import subprocess
     import sys
     code = (
