@@ -184,6 +184,9 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     // (each slice keeps >= 1024 terms of the smaller output)
     unsigned S = 1;
     while (S < MSM_MAX_SLICES && W * slots * 2 * B * S < 768 && n / (2 * S) >= 1024 && 2 * S * B <= 128) S *= 2;
+    // a small launch (the latency layout: one batch, 64 blocks) is bound by its fullest bucket - ~18 of 2 049 terms, 15 us
+    // a Jacobian addition at lone-wave speed: four slices quarter that chain for one more short fold
+    if (d.chunks == MSM_CHUNKS_LATENCY && S == 1 && n >= 256 && B <= 4) S = 4;
     // ... and until a block's sorted term list fits in LDS (msm.hpp LDSSORT): the global list costs a line of HBM write
     // traffic per 4-byte entry once the launch outgrows the L2
     const size_t lds_cap = fp29_enabled() ? msm_lds_sort_capacity<Curve29>() : msm_lds_sort_capacity<Curve32>();
