@@ -201,8 +201,11 @@ def main():
     if W:
         run_groups(W)
     K = args.steps
+    warm_sum5, warm_cnt = 0.0, 0
     for h in handles:
-        h.timing_totals(reset=True)  # the warm-up groups do not count
+        t, c = h.timing_totals(reset=True)  # the warm-up groups do not count (kept apart for the profiler cross-check below)
+        warm_sum5 += t[5]
+        warm_cnt += c
     elapsed, _ = timed(lambda: run_groups(K))
     # kernel times: on the library's own streams, AVERAGED over every launch group of the timed region (all handles)
     # - the quantity rocprofv3 --stats reports as the kernel's average duration for the same command
@@ -342,9 +345,12 @@ def main():
                      "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                      "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": ALG_BYTES[dom] * units,
+                     "launch_ms_incl_warmup": round((sums[5] + warm_sum5) / max(cnt + warm_cnt, 1), 4) if dom == "k_blob_challenge" else None,
                      "launch_ms_source": ("live: the kernel's own execution interval, stamped inside the kernel with s_memrealtime (first wavefront in, last "
-                                          "wavefront out) and averaged over the %d launch groups of the timed region; rocprofv3 --kernel-trace --stats of this "
-                                          "same command reports the same quantity as the kernel's AverageNs" % cnt) if dom == "k_blob_challenge" else
+                                          "wavefront out) and averaged over the %d launch groups of the timed region; launch_ms_incl_warmup averages the %d "
+                                          "warm-up groups in as well (the pipeline is still filling during the first ones: shorter intervals) - that is the "
+                                          "population rocprofv3 --kernel-trace --stats of this same command averages into the kernel's AverageNs"
+                                          % (cnt, warm_cnt)) if dom == "k_blob_challenge" else
                                          "live: HIP events on the kernel's stream (includes waiting behind the other launch groups' kernels)",
                      "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 5)"},
         "valu": valu,

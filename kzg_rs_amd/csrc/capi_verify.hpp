@@ -30,15 +30,19 @@ static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const F
 
 // The challenge kernel over T blobs on stream s1: a producer / consumer form (the serial chain split over wavefronts, lowest
 // latency) while every workgroup can have a CU to itself, the one-lane-per-blob form (highest throughput) beyond that.
-// The latency form has two lanes per blob on the consumer side (k_blob_challenge_split2); KZG_CHALLENGE_KERNEL = lane |
-// split | split2 forces a form (A/B measurement, cross-check in the tests).
+// Small launches take the form with two lanes per blob on the consumer side (k_blob_challenge_split2), mid-size ones the
+// one-lane consumer (k_blob_challenge_split); KZG_CHALLENGE_KERNEL = lane | split | split2 forces a form (A/B
+// measurement, cross-check in the tests).
 static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const void* d_commitments, Fr* d_z, size_t T) {
     static const int forced = [] {
         const char* e = getenv("KZG_CHALLENGE_KERNEL");
         return !e ? 0 : strcmp(e, "lane") == 0 ? 1 : strcmp(e, "split") == 0 ? 2 : strcmp(e, "split2") == 0 ? 3 : 0;
     }();
     const uint8_t *bl = (const uint8_t*)d_blobs, *cm = (const uint8_t*)d_commitments;
-    const int form = forced ? forced : T > 64 * 256 ? 1 : 3;
+    // measured on MI355X (tools/prof/challenge_forms_rate.py, ms for 1 024 / 16 384 / 32 768 / 49 152 blobs): lane 5.2 / 6.5 / 6.9 / 12.0,
+    // split 3.5 / 5.0 / 5.4 / 8.8, split2 2.9 / 4.4 / 7.2 / 13.3 - three waves per 64 blobs stop paying once the CUs hold more
+    // than one workgroup each; the one-lane-per-blob form wins when the launch fills every SIMD several times over
+    const int form = forced ? forced : T <= 16384 ? 3 : T <= 49152 ? 2 : 1;
     s->ws.ktime_valid = false;
     if (form == 1) {
         unsigned long long* kt = s->ws.d_ktime;  // null for callers that never reserved the workspace

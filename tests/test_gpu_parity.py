@@ -867,6 +867,7 @@ def test_handles_release_device_memory_and_oom_is_malloc():
             h.close()
 
     cycle(3)  # first-use allocations of the runtime itself (code objects, stream pools) happen here
+    assert KzgProof.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 4, st0) is True  # st0's own workspace
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()
     cycle(50)
