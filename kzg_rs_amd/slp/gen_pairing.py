@@ -88,10 +88,14 @@ def exp_x(a):
     return acc
 
 
-def build_verify(test_inputs=None, test_prep=None):
+def build_verify(test_inputs=None, test_prep=None, group=1):
     """Inputs (per instance): A.X A.Y A.Z B.X B.Y B.Z (Jacobian, Montgomery on the GPU).
     Settings inputs: prepared lines of Q1 = [tau]G2 then of Q2 = G2 generator (2 x 408 Fp).
-    Outputs: the 6 Fp coefficients of the w-odd half of s; all zero <=> e(A,Q1) == e(B,Q2)."""
+    Outputs: the 6 Fp coefficients of the w-odd half of s; all zero <=> e(A,Q1) == e(B,Q2).
+    group: Miller-loop bits taken together.  One bit is f <- f^2 T_i (T_i = the product of the bit's lines): two dependent
+    Fp12 levels.  k bits at once are f <- f^(2^k) M with M = (..(T_1^2 T_2)^2 ..)^2 T_k, which depends on the lines only and
+    is computed beside the main chain: k + 1 dependent levels instead of 2k, for a few more products (the latency program
+    takes group = 4: 432 product levels instead of 480; the throughput program keeps the fewest products)."""
     g = Graph()
     ti = test_inputs or [0, 1, 0, 0, 1, 0]
     AX, AY, AZ, BX, BY, BZ = [g.inp(v) for v in ti]
@@ -117,13 +121,31 @@ def build_verify(test_inputs=None, test_prep=None):
 
     f = f12_one(g)
     i = 0
-    for bit in x_bits():
-        f = f.sqr()
-        f = f * (line(0, i) * line(1, i))
-        i += 1
-        if bit == "1":
+    if group <= 1:
+        for bit in x_bits():
+            f = f.sqr()
             f = f * (line(0, i) * line(1, i))
             i += 1
+            if bit == "1":
+                f = f * (line(0, i) * line(1, i))
+                i += 1
+    else:
+        factors = []  # T_i per bit
+        for bit in x_bits():
+            t = line(0, i) * line(1, i)
+            i += 1
+            if bit == "1":
+                t = t * (line(0, i) * line(1, i))
+                i += 1
+            factors.append(t)
+        for pos in range(0, len(factors), group):
+            grp = factors[pos: pos + group]
+            m = grp[0]
+            for t in grp[1:]:
+                m = m.sqr() * t
+            for _ in grp:
+                f = f.sqr()
+            f = f * m
     assert i == N_LINES
     # inversion-free final test
     u = f.frobenius(2, g) * f
@@ -147,12 +169,13 @@ LATENCY_LANES = 256  # four wavefronts, one per SIMD of a CU: every product leve
 
 
 def build_verify_latency(test_inputs=None, test_prep=None):
-    """The same check traced with the schoolbook tower formulas (trace.TOWER): 2.2x the products, a quarter of the
-    dependent additions - the graph the latency scheduler (schedule2.py) is given."""
+    """The same check traced with the schoolbook tower formulas (trace.TOWER: 2.2x the products, a quarter of the
+    dependent additions) and four Miller-loop bits per step of the main chain - the graph the latency scheduler
+    (schedule2.py) is given."""
     old = trace.TOWER
     trace.TOWER = "schoolbook"
     try:
-        return build_verify(test_inputs, test_prep)
+        return build_verify(test_inputs, test_prep, group=4)
     finally:
         trace.TOWER = old
 
