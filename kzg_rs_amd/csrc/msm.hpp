@@ -93,12 +93,16 @@ __global__ void k_finish_g(const Fr* __restrict__ partial, int nparts, Fr* __res
 // Points must lie in G1 (all callers decode with the subgroup check).
 //
 // Two layouts.  CHUNKS = 4 (64-bit chunks, 8 windows each) is the default: the 2^64 multiple falls out of the decode
-// pass for free and the window combine is 56 doublings.  CHUNKS = 16 (16-bit chunks, 2 windows each: multiples
-// 2^16 P .. 2^112 P and their -phi images) costs 48 more doublings per point in the decode pass - which runs beside the
-// longer SHA-256 chain when a single batch is verified - and cuts the serial combine to 8 doublings: the LATENCY
-// layout, used for small launches only (it would add a fifth to the decode work of a throughput launch).
+// pass for free and the window combine is 56 doublings.  CHUNKS = 32 (8-bit chunks, ONE window each: multiples
+// 2^8 P .. 2^120 P and their -phi images) costs 56 more doublings per point in the decode pass - which runs beside the
+// longer SHA-256 chain when a single batch is verified - and leaves the combine no doubling at all, a tree over the 32
+// chunk sums: the LATENCY layout, used for small launches only (it would add a quarter to the decode work of a
+// throughput launch and its tables are 32 x 192 bytes per point).  (Round 1 had 16 chunks of 16 bits: 8 doublings in
+// the combine, ~0.1 ms of a single batch.)
 constexpr int MSM_CHUNKS = 4;
-constexpr int MSM_CHUNKS_LATENCY = 16;
+constexpr int MSM_CHUNKS_LATENCY = 32;
+constexpr int MSM_ENTRY_CHUNK_SHIFT = 27;  // a sorted-list entry: chunk << 27 | point index
+constexpr uint32_t MSM_ENTRY_POINT_MASK = (1u << MSM_ENTRY_CHUNK_SHIFT) - 1;
 __device__ __forceinline__ G1Jac g1_neg_phi(const G1Jac& p) {
     G1Jac r;
     r.x = fp_mul(p.x, fp_const(consts::FP_BETA_MONT));
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     cur[tid] = 0;
     __syncthreads();
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(d.scalars);
-    // 1. counting sort by digit of the cpb * nt (chunk, term) pairs; entry = chunk << 28 | point index
+    // 1. counting sort by digit of the cpb * nt (chunk, term) pairs; entry = chunk << 27 | point index (32 chunks at most, 2^27 points)
     for (int c = 0; c < cpb; c++) {
         const int byte = W * (j0 + c) + w;
         for (int t = tid; t < nt; t += 256) {
@@ -514,8 +518,8 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
         for (int t = tid; t < nt; t += 256) {
             uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
             uint32_t pos = atomicAdd(&cur[dig], 1u);
-            if constexpr (LDSSORT) pts[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << 28;
-            else sorted_global[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << 28;
+            if constexpr (LDSSORT) pts[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << MSM_ENTRY_CHUNK_SHIFT;
+            else sorted_global[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << MSM_ENTRY_CHUNK_SHIFT;
         }
     }
     __threadfence_block();
@@ -553,12 +557,12 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
         const uint32_t kend = bucket > 0 ? off[bucket + 1] : 0u;
         if (k < kend) {  // the first entry of a bucket is a copy, not an addition to the identity
             const uint32_t e = sorted_at(k++);
-            acc = CV::from_entry(CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
+            acc = CV::from_entry(CV::load(mult[(size_t)(e >> MSM_ENTRY_CHUNK_SHIFT) * d.stride + (e & MSM_ENTRY_POINT_MASK)]));
             w = k;
         }
         for (; k < kend; k++) {
             const uint32_t e = sorted_at(k);
-            const typename CV::Entry q = CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]);
+            const typename CV::Entry q = CV::load(mult[(size_t)(e >> MSM_ENTRY_CHUNK_SHIFT) * d.stride + (e & MSM_ENTRY_POINT_MASK)]);
             const typename CV::EntryHead h = CV::entry_head(acc, q);
             if (CV::entry_special(h)) sorted_put(w++, e);  // w <= k: only this thread reads or writes its bucket's list
             else acc = CV::entry_tail(acc, q, h);
@@ -566,12 +570,12 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
         const uint32_t first = bucket > 0 ? off[bucket] + 1 : 0u;
         for (uint32_t j = first; j < w; j++) {  // rare
             const uint32_t e = sorted_at(j);
-            acc = CV::add_entry(acc, CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
+            acc = CV::add_entry(acc, CV::load(mult[(size_t)(e >> MSM_ENTRY_CHUNK_SHIFT) * d.stride + (e & MSM_ENTRY_POINT_MASK)]));
         }
     } else if (bucket > 0) {
         for (uint32_t k = off[bucket]; k < off[bucket + 1]; k++) {
             const uint32_t e = sorted_at(k);
-            acc = CV::add_entry(acc, CV::load(mult[(size_t)(e >> 28) * d.stride + (e & 0x0FFFFFFFu)]));
+            acc = CV::add_entry(acc, CV::load(mult[(size_t)(e >> MSM_ENTRY_CHUNK_SHIFT) * d.stride + (e & MSM_ENTRY_POINT_MASK)]));
         }
     }
     // 3. sum_b b*B_b with b = 16 hi + lo:   16 * sum_hi hi*R_hi + sum_lo lo*C_lo,
