@@ -54,7 +54,7 @@ struct KzgSettings {
     uint32_t* d_eval_c = nullptr;
     Fp* d_tau4 = nullptr;   // [tau]G2 affine (x.c0 x.c1 y.c0 y.c1), Montgomery
     Fp* d_prep = nullptr;   // prepared lines: [tau]G2 then generator (2 * 408 Fp)
-    void* d_gen_mult = nullptr;   // the generator's MSM tables: [0, 4) the default layout, [4, 20) the latency layout (msm.hpp)
+    void* d_gen_mult = nullptr;   // the generator's MSM tables: [0, 4) the default layout, [4, 36) the latency layout, [36, 52) the proofs layout (msm.hpp)
     G1Aff29Mem* d_gen_mult_aff = nullptr;  // [0, 4) as affine entries
     // full trusted setup (kzg_settings_load_trusted_setup only; not needed by verification):
     G1Aff* d_g1 = nullptr;            // g1_points, bit-reversal permuted (build.rs:79,89-105), 4096 entries
@@ -247,7 +247,7 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
         DevTmp t_g, t_gf, t_gm;
         HIPCHK(hipMalloc(&t_g.p, sizeof(G1Aff)));
         HIPCHK(hipMalloc(&t_gf.p, 4));
-        constexpr int NG = MSM_CHUNKS + MSM_CHUNKS_LATENCY;
+        constexpr int NG = MSM_CHUNKS + MSM_CHUNKS_LATENCY + MSM_CHUNKS_PROOFS;
         HIPCHK(hipMalloc(&t_gm.p, sizeof(G1Jac) * NG));
         G1Aff* d_g = t_g.as<G1Aff>();
         uint32_t* d_gf = t_gf.as<uint32_t>();
@@ -255,6 +255,7 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
         hipLaunchKernelGGL(k_set_generator, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, 0);
         hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, d_gm, 1, 1, MSM_CHUNKS);
         hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, d_gm + MSM_CHUNKS, 1, 1, MSM_CHUNKS_LATENCY);
+        hipLaunchKernelGGL(k_g1_multiples, dim3(1), dim3(64), 0, s->s1, d_g, d_gf, d_gm + MSM_CHUNKS + MSM_CHUNKS_LATENCY, 1, 1, MSM_CHUNKS_PROOFS);
         if (fp29_enabled()) {
             HIPCHK(hipMalloc(&s->d_gen_mult, sizeof(G1Jac29Mem) * NG));
             hipLaunchKernelGGL(k_jac_to_jac29, dim3(1), dim3(64), 0, s->s1, d_gm, (G1Jac29Mem*)s->d_gen_mult, NG);

@@ -190,7 +190,7 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     while (S < MSM_MAX_SLICES && W * slots * 2 * B * S < 768 && n / (2 * S) >= 1024 && 2 * S * B <= 128) S *= 2;
     // a small launch (the latency layout: one batch, 64 blocks) is bound by its fullest bucket - ~18 of 2 049 terms, 15 us
     // a Jacobian addition at lone-wave speed: four slices quarter that chain for one more short fold
-    if (d.chunks == MSM_CHUNKS_LATENCY && S == 1 && n >= 256 && B <= 4) S = 4;
+    if (d.chunks != MSM_CHUNKS && S == 1 && n >= 256 && B <= 4) S = 4;
     // ... and until a block's sorted term list fits in LDS (msm.hpp LDSSORT): the global list costs a line of HBM write
     // traffic per 4-byte entry once the launch outgrows the L2
     const size_t lds_cap = fp29_enabled() ? msm_lds_sort_capacity<Curve29>() : msm_lds_sort_capacity<Curve32>();
@@ -228,15 +228,15 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
 
 // decode 2T points (all C then all pi) into ws.d_points / d_pflag together with their 2^(64j) multiples, generator
 // (precomputed multiples) as point 2T - all on stream s2, beside the SHA-256 chain
-static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, const void* d_proofs, size_t T) {
+static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, const void* d_proofs, size_t T, bool behind_sha = true) {
     Workspace& w = s->ws;
     const int np = (int)(2 * T + 1);
     unsigned blocks = (unsigned)((2 * T + 63) / 64);
     static const bool no_latency_layout = getenv("KZG_MSM_LATENCY_LAYOUT") && getenv("KZG_MSM_LATENCY_LAYOUT")[0] == '0';
-    w.chunks = (T <= LATENCY_MAX_BLOBS && !no_latency_layout) ? MSM_CHUNKS_LATENCY : MSM_CHUNKS;
+    w.chunks = (T <= LATENCY_MAX_BLOBS && !no_latency_layout) ? (behind_sha ? MSM_CHUNKS_LATENCY : MSM_CHUNKS_PROOFS) : MSM_CHUNKS;
     const uint8_t *c = (const uint8_t*)d_commitments, *p = (const uint8_t*)d_proofs;
     const int n2 = (int)(2 * T);
-    const size_t gen_off = w.chunks == MSM_CHUNKS ? 0 : MSM_CHUNKS;
+    const size_t gen_off = w.chunks == MSM_CHUNKS ? 0 : w.chunks == MSM_CHUNKS_LATENCY ? MSM_CHUNKS : MSM_CHUNKS + MSM_CHUNKS_LATENCY;
     w.mult_affine = msm_affine_enabled() && w.chunks == MSM_CHUNKS;
     if (w.mult_affine) {
         // affine tables: rows 0 and 2 straight from the decode pass, rows 1 and 3 from 2^64 P through one inversion per 16 points
@@ -252,6 +252,8 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
         G1Jac29Mem* mult = (G1Jac29Mem*)w.d_mult;
         if (w.chunks == MSM_CHUNKS_LATENCY)
             hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS_LATENCY, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
+        else if (w.chunks == MSM_CHUNKS_PROOFS)
+            hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS_PROOFS, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
         else
             hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
         HIPCHK(hipEventRecord(s->ev[10], s->s2));
@@ -261,6 +263,8 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
         G1Jac* mult = (G1Jac*)w.d_mult;
         if (w.chunks == MSM_CHUNKS_LATENCY)
             hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
+        else if (w.chunks == MSM_CHUNKS_PROOFS)
+            hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS_PROOFS>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
         else
             hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
         HIPCHK(hipEventRecord(s->ev[10], s->s2));
@@ -738,7 +742,7 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
     HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
     HIPCHK(hipMemcpyAsync(w.d_stage_cp + 48 * n, proofs, 48 * n, hipMemcpyHostToDevice, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
-    if ((rc = launch_decode(s, w.d_stage_cp, w.d_stage_cp + 48 * n, n)) != KZG_OK) return rc;
+    if ((rc = launch_decode(s, w.d_stage_cp, w.d_stage_cp + 48 * n, n, /*behind_sha=*/false)) != KZG_OK) return rc;
     uint32_t* h_pflag = reinterpret_cast<uint32_t*>(w.h_buf + 64 * n);
     HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * n, hipMemcpyDeviceToHost, s->s2));
     HIPCHK(hipStreamSynchronize(s->s2));
