@@ -668,21 +668,32 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batches(bool* ok_out, uint8_t* err_o
         }
         return KZG_OK;
     };
-    if ((rc = copy_part(0, 0)) != KZG_OK || (rc = copy_part(0, 1)) != KZG_OK) return rc;
+    // any failure leaves copies and kernels in flight that read the caller's memory and the staging sets: drain both
+    // streams before the error goes back (the first message is kept)
+    auto drained = [&](KzgRet code) {
+        const std::string msg = g_err;
+        (void)hipStreamSynchronize(s->s_copy);
+        (void)hipStreamSynchronize(s->s1);
+        (void)hipStreamSynchronize(s->s2);
+        (void)hipGetLastError();
+        g_err = msg;
+        return code;
+    };
+    if ((rc = copy_part(0, 0)) != KZG_OK || (rc = copy_part(0, 1)) != KZG_OK) return drained(rc);
     for (size_t c = 0; c < n_chunks; c++) {
         const size_t B = batches_of(c);
         uint8_t* st = w.d_hstage[c & 1];
         select_streams(s, B * n);
-        HIPCHK(hipStreamWaitEvent(s->s1, s->ev_copy[c & 1], 0));  // this chunk has landed
-        if ((rc = phase1_launch_locked(st, st + cap_set * (size_t)BLOB_BYTES, st + cap_set * ((size_t)BLOB_BYTES + 48), n, B, s)) != KZG_OK) return rc;
+        if (hipStreamWaitEvent(s->s1, s->ev_copy[c & 1], 0) != hipSuccess) return drained(fail(KZG_ERROR, "HIP: hipStreamWaitEvent"));  // this chunk has landed
+        if ((rc = phase1_launch_locked(st, st + cap_set * (size_t)BLOB_BYTES, st + cap_set * ((size_t)BLOB_BYTES + 48), n, B, s)) != KZG_OK) return drained(rc);
         // the other staging set is free: its chunk (c - 1) was waited for to the end in the previous iteration
-        if (c + 1 < n_chunks && (rc = copy_part(c + 1, 0)) != KZG_OK) return rc;
+        if (c + 1 < n_chunks && (rc = copy_part(c + 1, 0)) != KZG_OK) return drained(rc);
         uint8_t* err = err_out ? err_out + c * G : nullptr;
-        if ((rc = phase1_wait_locked(nullptr, err, s)) != KZG_OK) return rc;
-        if ((rc = phase2_launch_locked(nullptr, n, 0, s)) != KZG_OK) return rc;
-        if ((rc = finish_launch_locked(nullptr, 1, B, s)) != KZG_OK) return rc;
-        if (c + 1 < n_chunks && (rc = copy_part(c + 1, 1)) != KZG_OK) return rc;
-        if ((rc = finish_wait_locked(ok_out + c * G, s)) != KZG_OK) return rc;
+        if ((rc = phase1_wait_locked(nullptr, err, s)) != KZG_OK) return drained(rc);
+        if ((rc = phase2_launch_locked(nullptr, n, 0, s)) != KZG_OK) return drained(rc);
+        if ((rc = finish_launch_locked(nullptr, 1, B, s)) != KZG_OK) return drained(rc);
+        if (c + 1 < n_chunks && (rc = copy_part(c + 1, 1)) != KZG_OK) return drained(rc);
+        if ((rc = finish_wait_locked(ok_out + c * G, s)) != KZG_OK) return drained(rc);
         if (err)
             for (size_t b = 0; b < B; b++)
                 if (err[b]) ok_out[c * G + b] = false;
