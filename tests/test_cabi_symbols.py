@@ -64,3 +64,39 @@ def test_host_sha256_both_paths():
         padded = data + b"\x80" + bytes(55) + (8 * n).to_bytes(8, "big")
         assert L.kzg_debug_host_sha256(out, padded, len(padded), 1) == 0
         assert out.raw == hashlib.sha256(data).digest(), n
+
+
+def test_batch_challenges_is_host_code_and_matches_the_oracle():
+    """kzg_batch_challenges (the hash half of compute_r_powers, src/kzg_proof.rs:291-334) needs neither a handle nor a GPU:
+    both record layouts against the oracle's compute_r on canonical random records, n = 1 included."""
+    import ctypes as C
+    import random
+
+    import oracle_lib as O
+    from kzg_rs_amd import api
+
+    L = C.CDLL(api.LIB_PATH)
+    L.kzg_batch_challenges.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t]
+    rng = random.Random(11)
+    for world, B, n in ((0, 3, 5), (0, 1, 1), (2, 4, 3), (3, 2, 7)):
+        n_total = (world or 1) * n
+        # records of batch b in global order: C(48) || z(32 LE) || y(32 LE) || pi(48); z, y canonical (top byte 0)
+        flat = []
+        for b in range(B):
+            recs = []
+            for _ in range(n_total):
+                z, y = bytearray(rng.randbytes(32)), bytearray(rng.randbytes(32))
+                z[31] = y[31] = 0
+                recs.append(rng.randbytes(48) + bytes(z) + bytes(y) + rng.randbytes(48))
+            flat.append(recs)
+        if world == 0:
+            buf = b"".join(b"".join(r) for r in flat)
+        else:  # [world][B][n]
+            buf = b"".join(b"".join(flat[b][k * n:(k + 1) * n]) for k in range(world) for b in range(B))
+        out = C.create_string_buffer(32 * B)
+        assert L.kzg_batch_challenges(out, buf, world, B, n) == 0
+        for b in range(B):
+            rec = flat[b]
+            want = O.compute_r(b"".join(x[:48] for x in rec), b"".join(x[48:80][::-1] for x in rec), b"".join(x[80:112][::-1] for x in rec),
+                               b"".join(x[112:] for x in rec), n_total)
+            assert out.raw[32 * b: 32 * b + 32][::-1] == want, (world, B, n, b)
