@@ -272,17 +272,15 @@ __global__ __launch_bounds__(128) void k_blob_challenge_split(const uint8_t* __r
 
 // The same with TWO LANES PER BLOB on the consumer side (sha256.hpp: sha256_round_2lane): a workgroup of three wavefronts
 // serves 64 blobs - wave 2 is the producer (one lane per blob, as above), waves 0 and 1 run the rounds for 32 blobs each,
-// the even lane of a pair on the a-chain, the odd lane on the e-chain.  ~735 instructions per block on the serial chain
-// instead of ~930.  The (K + W) tile is read by both lanes of a pair at the same address; the even lanes read a row of
+// one lane of a pair on the a-chain, the lane four further on the e-chain.  ~690 instructions per block on the serial
+// chain instead of ~930.  The (K + W) tile is read by both lanes of a pair at the same address; the even lanes read a row of
 // zeros instead (their sum takes no message word).
 __global__ __launch_bounds__(192) void k_blob_challenge_split2(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
                                                                Fr* __restrict__ z_out, int n) {
     __shared__ uint4 tile[CHALLENGE_TILE_U4];
-    __shared__ uint4 zero_row[64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0, 1 consumers; 2 producer
     constexpr int NBLK = 2050;
-    if (threadIdx.x < 64) zero_row[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
     if (wave == 2) {
         int i = blockIdx.x * 64 + lane;
         if (i >= n) i = n - 1;  // redundant work keeps the barriers uniform
@@ -344,10 +342,11 @@ __global__ __launch_bounds__(192) void k_blob_challenge_split2(const uint8_t* __
         }
         __syncthreads();
     } else {
-        const int blob_in_block = 32 * wave + (lane >> 1);
+        // lanes 0-3 of every eight: the a-chains of four blobs, lanes 4-7: their e-chains (DPP bank masks work on groups of four)
+        const int blob_in_block = 32 * wave + 4 * (lane >> 3) + (lane & 3);
         int i = blockIdx.x * 64 + blob_in_block;
         const bool live = i < n;
-        const bool a_lane = (lane & 1) == 0;
+        const bool a_lane = (lane & 4) == 0;
         Sha2LaneConsts c;
         c.n1 = a_lane ? 2u : 6u;
         c.n2 = a_lane ? 13u : 11u;
@@ -359,29 +358,34 @@ __global__ __launch_bounds__(192) void k_blob_challenge_split2(const uint8_t* __
         __syncthreads();
 #pragma unroll 1
         for (int b = 0; b < NBLK; b++) {
-            uint32_t x0 = H0, x1 = H1, x2 = H2, dd = H3;
-            // all 16 LDS reads of the block at once (they pipeline); the even lanes read zeros
-            const uint4* src = a_lane ? zero_row + lane : tile + (b & 1) * (16 * 64) + blob_in_block;
-            const int stride = a_lane ? 0 : 64;
-            uint4 kw[16];
-#pragma unroll
-            for (int t = 0; t < 16; t++) kw[t] = src[t * stride];
-            uint32_t hk = (H3 & ~c.m) + kw[0].x;  // x3 + kw of round 0
+            // all 16 LDS reads of the block at once (they pipeline); the a-lanes read their e-lanes' words too and never
+            // use them (the additions of kw are masked to the e-lanes)
+            const uint4* src = tile + (b & 1) * (16 * 64) + blob_in_block;
+            constexpr int stride = 64;
+            uint32_t kw[65];
 #pragma unroll
             for (int t = 0; t < 16; t++) {
-                asm volatile("" : "+v"(kw[t].x), "+v"(kw[t].y), "+v"(kw[t].z), "+v"(kw[t].w));  // keep the reads hoisted
-                sha256_rounds4_2lane(x0, x1, x2, hk, dd, kw[t], t < 15 ? kw[t + 1].x : 0u, c);
+                const uint4 q = src[t * stride];
+                kw[4 * t] = q.x; kw[4 * t + 1] = q.y; kw[4 * t + 2] = q.z; kw[4 * t + 3] = q.w;
             }
-            // after the last round hk = x3 + 0: h on the odd lanes, 0 on the even ones
-            H0 += x0;
-            H1 += x1;
-            H2 += x2;
-            H3 += a_lane ? dd : hk;  // d sits in dd on the even lanes, h in hk on the odd ones
+            kw[64] = 0;
+            Sha2LaneRing r;
+            r.x0 = H0; r.x1 = H1; r.x2 = H2; r.dd = H3;
+            r.hk = a_lane ? 0u : H3 + kw[0];  // x3 + kw of round 0
+            asm volatile("" : "=v"(r.nx));  // (defined, whatever it holds)
+#pragma unroll
+            for (int t = 0; t < 6; t++) sha256_rounds10_2lane(r, kw + 10 * t + 1, c);
+            sha256_rounds4_2lane(r, kw + 61, c);
+            // after the last round hk = x3 + 0: h on the e-lanes, 0 on the a-lanes
+            H0 += r.x0;
+            H1 += r.x1;
+            H2 += r.x2;
+            H3 += a_lane ? r.dd : r.hk;  // d sits in dd on the a-lanes, h in hk on the e-lanes
             __syncthreads();
         }
-        // the odd lane's words to the even lane, which reduces the digest and writes z
-        const uint32_t e0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H0, 0xB1, 0xF, 0xF, true), e1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H1, 0xB1, 0xF, 0xF, true);
-        const uint32_t e2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H2, 0xB1, 0xF, 0xF, true), e3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H3, 0xB1, 0xF, 0xF, true);
+        // the e-lane's words to the a-lane (row_shl:4: lane i reads lane i + 4), which reduces the digest and writes z
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H0, 0x104, 0xF, 0xF, true), e1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H1, 0x104, 0xF, 0xF, true);
+        const uint32_t e2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H2, 0x104, 0xF, 0xF, true), e3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H3, 0x104, 0xF, 0xF, true);
         if (live && a_lane) {
             const uint32_t hh[8] = {H0, H1, H2, H3, e0, e1, e2, e3};
             Fr dgst;

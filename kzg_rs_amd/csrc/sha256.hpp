@@ -94,49 +94,69 @@ __device__ __forceinline__ void sha256_rounds4(uint32_t& a, uint32_t& b, uint32_
 
 // ---- two lanes per hash state (the latency form of the challenge kernel, fr_kernels.hpp: k_blob_challenge_split2).
 // A wavefront issues at most one instruction every ~4.3 cycles whatever it is, so ONE blob's serial chain is as fast as its
-// instruction count per block allows: the even lane of a pair carries (a, b, c) and d, the odd lane (e, f, g, h), and one
-// uniform instruction stream serves both - 11 instructions per round instead of 14.5:
-//   x0..x2 : a, b, c | e, f, g         x3 : 0 | h          dd : d | -
+// instruction count per block allows: one lane of a pair carries (a, b, c) and d, the other (e, f, g, h), and one uniform
+// instruction stream serves both - 10 instructions per round instead of 14.5.  The pair sits four lanes apart (lanes 0-3 of
+// every eight: a-chains of four blobs; lanes 4-7: their e-chains), because a DPP bank mask enables groups of four lanes:
+//   x0..x2 : a, b, c | e, f, g         hk : 0 | h + kw      dd : d | -
 //   Sigma  : three v_alignbit with the rotation amounts in a VGPR (2, 13, 22 | 6, 11, 25) + one xor3
 //   F      : Maj(a, b, c) = Ch(~(a ^ b), b, c) | Ch(e, f, g): u = bitop3(x0, x1, m) (m = ~0 | 0), F = bitop3(u, x1, x2, Ch)
-//   w      : Sigma + F + hk,  hk = x3 + kw  =  T2 | T1   (kw reads as zero on the even lanes; hk is prepared a round ahead)
-//   x0'    : w + swap(y),  y = dd | w  (one v_cndmask; a DPP bank mask selects groups of four lanes, not odd lanes),
-//            swap = quad_perm [1,0,3,2]:  T2 + T1 | T1 + d
-//   x3'    : x2 & ~m  (0 | g),  dd' = x2
+//   w      : Sigma + F + hk  =  T2 | T1
+//   hk'    : e-lanes only: x2 + kw'   (v_add_u32_dpp with the identity permutation and bank_mask:0xa: the bank mask is a
+//            free execution mask - the a-lanes keep their zero)
+//   x0'    : e-lanes: w + dd[lane - 4] = T1 + d     (v_add_u32_dpp row_shr:4 bank_mask:0xa)
+//            a-lanes: w + w[lane + 4]  = T2 + T1    (v_add_u32_dpp row_shl:4 bank_mask:0x5)
+// The DPP read of w comes two instructions after the add3 that wrote it (the two e-lane additions sit in between): no
+// wait states, no select.
 struct Sha2LaneConsts {
     uint32_t n1, n2, n3;  // rotation amounts of this lane's Sigma
-    uint32_t m;           // ~0 on the even (a-chain) lanes, 0 on the odd (e-chain) lanes
+    uint32_t m;           // ~0 on the a-chain lanes, 0 on the e-chain lanes
 };
-// hk = x3 + kw of THIS round (prepared during the previous one); kw_next = the next round's message word.  The two
-// instructions that prepare the next round sit between the select that writes y and the DPP add that reads it across
-// lanes (a VALU write followed by a DPP read needs two wait states: an s_nop otherwise, one issue slot per round).
-__device__ __forceinline__ void sha256_round_2lane(uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& hk, uint32_t& dd, uint32_t kw_next,
-                                                   const Sha2LaneConsts& c) {
-    const uint32_t S = xor3(__builtin_amdgcn_alignbit(x0, x0, c.n1), __builtin_amdgcn_alignbit(x0, x0, c.n2), __builtin_amdgcn_alignbit(x0, x0, c.n3));
-    const uint32_t u = __builtin_amdgcn_bitop3_b32(x0, x1, c.m, 0xD2);  // m ? ~(x0 ^ x1) : x0
-    const uint32_t F = sha_ch(u, x1, x2);
-    const uint32_t w = S + F + hk;
-    const uint32_t y = c.m ? dd : w;  // even lanes: d, odd lanes: T1
-    __builtin_amdgcn_sched_barrier(0);
-    const uint32_t x3n = x2 & ~c.m;   // next round's h (odd lanes) / 0 (even lanes)
-    uint32_t hkn = x3n + kw_next;
-    asm volatile("" : "+v"(hkn));     // (keeps the addition here: reassociation would sink it into the next round's sum)
-    __builtin_amdgcn_sched_barrier(0);
-    const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y, 0xB1, 0xF, 0xF, true);  // the pair's other lane
-    const uint32_t nx = w + t;
-    dd = x2;
-    hk = hkn;
-    x2 = x1;
-    x1 = x0;
-    x0 = nx;
+// One round as text: operands %0..%4 = the ring of state registers (x0, x1, x2, dd, next x0 - it turns by one per round),
+// %5 = hk (x3 + kw of THIS round, prepared during the previous one; updated in place on the e-lanes only - the a-lanes
+// keep the zero it was initialised with), %6..%8 = temporaries, %9..%12 = n1, n2, n3, m, KW = the NEXT round's message word.
+// Rounds are chained inside ONE asm statement, ten at a time: the order of a round's last three instructions is the DPP
+// hazard protection (the compiler does not look inside; the two masked writes of the next x0 are kept apart as well:
+// back to back they cost a twelfth slot, tools/microbench/issuebench.hip), and the compiler pads every consumer of an asm result with a
+// wait state - also between two asm statements - which would put the eleventh instruction back into every round.
+#define KZG_SHA2L_ROUND(X0, X1, X2, DD, NX, KW)                                                       \
+    "v_alignbit_b32 %6, " X0 ", " X0 ", %9\n\t"                                                       \
+    "v_alignbit_b32 %7, " X0 ", " X0 ", %10\n\t"                                                      \
+    "v_alignbit_b32 %8, " X0 ", " X0 ", %11\n\t"                                                      \
+    "v_bitop3_b32 %6, %6, %7, %8 bitop3:0x96\n\t"                 /* Sigma */                        \
+    "v_bitop3_b32 %7, " X0 ", " X1 ", %12 bitop3:0xd2\n\t"        /* m ? ~(x0 ^ x1) : x0 */          \
+    "v_bitop3_b32 %7, %7, " X1 ", " X2 " bitop3:0xca\n\t"         /* Ch(u, x1, x2) */                \
+    "v_add3_u32 %6, %6, %7, %5\n\t"                               /* w = Sigma + F + hk */           \
+    "v_add_u32_dpp " NX ", " DD ", %6 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"           /* e: d[lane - 4] + w */ \
+    "v_add_u32_dpp %5, " X2 ", " KW " quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xa\n\t" /* e: hk' = x2 + kw' */ \
+    "v_add_u32_dpp " NX ", %6, %6 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"               /* a: w[lane + 4] + w */
+#define KZG_SHA2L_ROUNDS5(K0, K1, K2, K3, K4)                                                                                  \
+    KZG_SHA2L_ROUND("%0", "%1", "%2", "%3", "%4", K0) KZG_SHA2L_ROUND("%4", "%0", "%1", "%2", "%3", K1)                       \
+    KZG_SHA2L_ROUND("%3", "%4", "%0", "%1", "%2", K2) KZG_SHA2L_ROUND("%2", "%3", "%4", "%0", "%1", K3)                       \
+    KZG_SHA2L_ROUND("%1", "%2", "%3", "%4", "%0", K4)
+#define KZG_SHA2L_OPERANDS "+v"(r.x0), "+v"(r.x1), "+v"(r.x2), "+v"(r.dd), "+v"(r.nx), "+v"(r.hk), "=&v"(t0), "=&v"(t1), "=&v"(t2)
+struct Sha2LaneRing {
+    uint32_t x0, x1, x2, dd, nx, hk;
+};
+// ten rounds: k[0..9] = the message words of the rounds AFTER each of them; the ring is back in place afterwards
+__device__ __forceinline__ void sha256_rounds10_2lane(Sha2LaneRing& r, const uint32_t* k, const Sha2LaneConsts& c) {
+    uint32_t t0, t1, t2;
+    asm volatile(KZG_SHA2L_ROUNDS5("%13", "%14", "%15", "%16", "%17") KZG_SHA2L_ROUNDS5("%18", "%19", "%20", "%21", "%22")
+                 : KZG_SHA2L_OPERANDS
+                 : "v"(c.n1), "v"(c.n2), "v"(c.n3), "v"(c.m), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]), "v"(k[4]), "v"(k[5]), "v"(k[6]), "v"(k[7]),
+                   "v"(k[8]), "v"(k[9]));
 }
-// four rounds; kwz = this quad's message words (zero on the even lanes), kw_after = the first word of the next quad
-__device__ __forceinline__ void sha256_rounds4_2lane(uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& hk, uint32_t& dd, const uint4& kwz,
-                                                     uint32_t kw_after, const Sha2LaneConsts& c) {
-    sha256_round_2lane(x0, x1, x2, hk, dd, kwz.y, c);
-    sha256_round_2lane(x0, x1, x2, hk, dd, kwz.z, c);
-    sha256_round_2lane(x0, x1, x2, hk, dd, kwz.w, c);
-    sha256_round_2lane(x0, x1, x2, hk, dd, kw_after, c);
+// the last four rounds of a block (k[3] = 0): afterwards x0..x2, dd are renamed back into place
+__device__ __forceinline__ void sha256_rounds4_2lane(Sha2LaneRing& r, const uint32_t* k, const Sha2LaneConsts& c) {
+    uint32_t t0, t1, t2;
+    asm volatile(KZG_SHA2L_ROUND("%0", "%1", "%2", "%3", "%4", "%13") KZG_SHA2L_ROUND("%4", "%0", "%1", "%2", "%3", "%14")
+                 KZG_SHA2L_ROUND("%3", "%4", "%0", "%1", "%2", "%15") KZG_SHA2L_ROUND("%2", "%3", "%4", "%0", "%1", "%16")
+                 : KZG_SHA2L_OPERANDS
+                 : "v"(c.n1), "v"(c.n2), "v"(c.n3), "v"(c.m), "v"(k[0]), "v"(k[1]), "v"(k[2]), "v"(k[3]));
+    const uint32_t a = r.x1, b = r.x2, cc = r.dd, d = r.nx;  // the ring turned by four
+    r.x0 = a;
+    r.x1 = b;
+    r.x2 = cc;
+    r.dd = d;
 }
 
 }  // namespace kzg

@@ -51,6 +51,39 @@ PROBE(p_fma_f64, "v_fma_f64 %4, %4, %5, %6\n\tv_fma_f64 %5, %5, %6, %7\n\tv_fma_
 PROBE(p_fma_f32, R4_3("v_fma_f32"), "memory")
 PROBE(p_mad_i32_i24, R4_3("v_mad_i32_i24"), "memory")
 PROBE(p_dot4_u8, "v_dot4_u32_u8 %0, %8, %9, %0\n\tv_dot4_u32_u8 %1, %8, %9, %1\n\tv_dot4_u32_u8 %2, %8, %9, %2\n\tv_dot4_u32_u8 %3, %8, %9, %3", "memory")
+PROBE(p_add_dpp_quad, "v_add_u32_dpp %0, %0, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %1, %1, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %2, %2, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %3, %3, %8 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "memory")
+PROBE(p_add_dpp_shr4, "v_add_u32_dpp %0, %8, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\tv_add_u32_dpp %1, %8, %9 row_shr:4 row_mask:0xf bank_mask:0xa\n\tv_add_u32_dpp %2, %8, %9 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_add_u32_dpp %3, %8, %9 row_shl:4 row_mask:0xf bank_mask:0x5", "memory")
+PROBE(p_add_dpp_ident, "v_add_u32_dpp %0, %8, %9 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xa\n\tv_add_u32_dpp %1, %8, %9 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xa\n\tv_add_u32_dpp %2, %8, %9 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xa\n\tv_add_u32_dpp %3, %8, %9 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xa", "memory")
+// dependent chains: every instruction consumes the previous result (what one SHA-256 round looks like)
+PROBE(p_chain_add, "v_add_u32 %0, %0, %8\n\tv_add_u32 %0, %0, %9\n\tv_add_u32 %0, %0, %8\n\tv_add_u32 %0, %0, %9", "memory")
+PROBE(p_chain_alignbit_bitop, "v_alignbit_b32 %1, %0, %0, %8\n\tv_alignbit_b32 %2, %0, %0, %9\n\tv_bitop3_b32 %0, %0, %1, %2 bitop3:0x96\n\tv_add3_u32 %0, %0, %1, %2", "memory")
+// the 10-instruction two-lane SHA-256 round of sha256.hpp (x0 = %0, temporaries %1 %2 %3; the other state words fixed)
+PROBE(p_sha_round10, "v_alignbit_b32 %1, %0, %0, %8\n\tv_alignbit_b32 %2, %0, %0, %9\n\tv_alignbit_b32 %3, %0, %0, %8\n\tv_bitop3_b32 %1, %1, %2, %3 bitop3:0x96\n\t"
+      "v_bitop3_b32 %2, %0, %8, %9 bitop3:0xd2\n\tv_bitop3_b32 %2, %2, %8, %9 bitop3:0xca\n\tv_add3_u32 %1, %1, %2, %8\n\t"
+      "v_add_u32_dpp %3, %8, %9 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xa\n\tv_add_u32_dpp %0, %9, %1 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_u32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5", "memory")
+// the 11-instruction form before it (select + one DPP add, two filler instructions for the hazard)
+PROBE(p_sha_round11, "v_alignbit_b32 %1, %0, %0, %8\n\tv_alignbit_b32 %2, %0, %0, %9\n\tv_alignbit_b32 %3, %0, %0, %8\n\tv_bitop3_b32 %1, %1, %2, %3 bitop3:0x96\n\t"
+      "v_bitop3_b32 %2, %0, %8, %9 bitop3:0xd2\n\tv_bitop3_b32 %2, %2, %8, %9 bitop3:0xca\n\tv_add3_u32 %1, %1, %2, %8\n\t"
+      "v_cndmask_b32 %2, %1, %9, vcc\n\tv_and_b32 %3, %8, %9\n\tv_add_u32 %3, %3, %9\n\tv_add_u32_dpp %0, %2, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "memory")
+// variants of the round's tail, to see what the DPP additions cost on the dependent chain
+PROBE(p_sha_tail_plain, "v_alignbit_b32 %1, %0, %0, %8\n\tv_alignbit_b32 %2, %0, %0, %9\n\tv_alignbit_b32 %3, %0, %0, %8\n\tv_bitop3_b32 %1, %1, %2, %3 bitop3:0x96\n\t"
+      "v_bitop3_b32 %2, %0, %8, %9 bitop3:0xd2\n\tv_bitop3_b32 %2, %2, %8, %9 bitop3:0xca\n\tv_add3_u32 %1, %1, %2, %8\n\t"
+      "v_add_u32 %3, %8, %9\n\tv_add_u32 %0, %9, %1\n\tv_add_u32 %0, %1, %0", "memory")
+PROBE(p_sha_tail_none, "v_alignbit_b32 %1, %0, %0, %8\n\tv_alignbit_b32 %2, %0, %0, %9\n\tv_alignbit_b32 %3, %0, %0, %8\n\tv_bitop3_b32 %1, %1, %2, %3 bitop3:0x96\n\t"
+      "v_bitop3_b32 %2, %0, %8, %9 bitop3:0xd2\n\tv_bitop3_b32 %2, %2, %8, %9 bitop3:0xca\n\tv_add3_u32 %1, %1, %2, %8\n\t"
+      "v_add_u32 %0, %9, %1", "memory")
+PROBE(p_sha_tail_onedpp, "v_alignbit_b32 %1, %0, %0, %8\n\tv_alignbit_b32 %2, %0, %0, %9\n\tv_alignbit_b32 %3, %0, %0, %8\n\tv_bitop3_b32 %1, %1, %2, %3 bitop3:0x96\n\t"
+      "v_bitop3_b32 %2, %0, %8, %9 bitop3:0xd2\n\tv_bitop3_b32 %2, %2, %8, %9 bitop3:0xca\n\tv_add3_u32 %1, %1, %2, %8\n\t"
+      "v_add_u32 %3, %8, %9\n\tv_add_u32 %2, %9, %1\n\tv_add_u32_dpp %0, %1, %2 row_shl:4 row_mask:0xf bank_mask:0xf", "memory")
+PROBE(p_sha_tail_twodpp_indep, "v_alignbit_b32 %1, %0, %0, %8\n\tv_alignbit_b32 %2, %0, %0, %9\n\tv_alignbit_b32 %3, %0, %0, %8\n\tv_bitop3_b32 %1, %1, %2, %3 bitop3:0x96\n\t"
+      "v_bitop3_b32 %2, %0, %8, %9 bitop3:0xd2\n\tv_bitop3_b32 %2, %2, %8, %9 bitop3:0xca\n\tv_add3_u32 %1, %1, %2, %8\n\t"
+      "v_add_u32 %3, %8, %9\n\tv_add_u32_dpp %2, %9, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf", "memory")
+// the committed order: the two bank-masked writes of the next x0 with the hk addition between them
+PROBE(p_sha_round10_split, "v_alignbit_b32 %1, %0, %0, %8\n\tv_alignbit_b32 %2, %0, %0, %9\n\tv_alignbit_b32 %3, %0, %0, %8\n\tv_bitop3_b32 %1, %1, %2, %3 bitop3:0x96\n\t"
+      "v_bitop3_b32 %2, %0, %8, %9 bitop3:0xd2\n\tv_bitop3_b32 %2, %2, %8, %9 bitop3:0xca\n\tv_add3_u32 %1, %1, %2, %8\n\t"
+      "v_add_u32_dpp %0, %9, %1 row_shr:4 row_mask:0xf bank_mask:0xa\n\tv_add_u32_dpp %3, %8, %9 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_u32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5", "memory")
 
 typedef void (*probe_t)(uint32_t*, uint32_t, uint32_t, int);
 int main() {
@@ -64,6 +97,11 @@ int main() {
         {"v_mad_i32_i24", p_mad_i32_i24}, {"v_mad_u64_u32 (vcc)", p_mad_u64_u32}, {"v_mad_u64_u32 (sgpr pair)", p_mad_u64_sgprcarry},
         {"v_add_co_u32", p_add_co}, {"v_addc_co_u32", p_addc_co}, {"v_lshrrev_b64", p_lshrrev_b64}, {"v_lshlrev_b64", p_lshlrev_b64},
         {"v_pk_add_u16", p_pk_add_u16}, {"v_fma_f32", p_fma_f32}, {"v_fma_f64", p_fma_f64}, {"v_dot4_u32_u8", p_dot4_u8},
+        {"v_add_u32_dpp quad_perm", p_add_dpp_quad}, {"v_add_u32_dpp row_shr/shl:4 bank-masked", p_add_dpp_shr4}, {"v_add_u32_dpp identity bank-masked", p_add_dpp_ident},
+        {"dependent v_add_u32 chain", p_chain_add}, {"dependent alignbit/bitop3/add3 chain", p_chain_alignbit_bitop},
+        {"SHA round, 10 instr, masked writes adjacent", p_sha_round10}, {"SHA round, 11 instr", p_sha_round11}, {"SHA round, 10 instr, masked writes apart", p_sha_round10_split},
+        {"SHA round, tail = 3 plain adds", p_sha_tail_plain}, {"SHA round, tail = 1 add (8 instr)", p_sha_tail_none}, {"SHA round, tail = 2 adds + 1 DPP add", p_sha_tail_onedpp},
+        {"SHA round, tail = add + 2 DPP adds, separate dst", p_sha_tail_twodpp_indep},
     };
     for (int cfg = 0; cfg < 2; cfg++) {
         int blocks = cfg == 0 ? 4096 : 1024, threads = cfg == 0 ? 256 : 64;
