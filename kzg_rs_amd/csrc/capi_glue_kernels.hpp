@@ -136,6 +136,24 @@ __global__ void k_pack_records(const uint32_t* __restrict__ c, const uint32_t* _
     out[t] = k < 12 ? c[12 * i + k] : k < 20 ? z[8 * i + k - 12] : k < 28 ? y[8 * i + k - 20] : p[12 * i + k - 28];
 }
 
+// The same for a small launch, with the host mirror written by the kernel itself (pinned, device-visible memory): records,
+// then the per-blob status words and the 2 T point flags - one dispatch instead of one kernel and three copies.
+__global__ void k_pack_records_mirror(const uint32_t* __restrict__ c, const uint32_t* __restrict__ p, const uint32_t* __restrict__ z,
+                                      const uint32_t* __restrict__ y, uint32_t* __restrict__ out, uint32_t* __restrict__ host,
+                                      const uint32_t* __restrict__ status, const uint32_t* __restrict__ pflag, int T) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T * 40) {
+        int i = t / 40, k = t % 40;
+        const uint32_t v = k < 12 ? c[12 * i + k] : k < 20 ? z[8 * i + k - 12] : k < 28 ? y[8 * i + k - 20] : p[12 * i + k - 28];
+        out[t] = v;
+        host[t] = v;
+    } else if (t < T * 41) {
+        host[t] = status[t - T * 40];
+    } else if (t < T * 43) {
+        host[t] = pflag[t - T * 41];
+    }
+}
+
 // the generator and its precomputed multiples (gen_mult[4], made once per settings) as point `idx` of a workspace
 template <class Mem>
 __global__ void k_set_generator_multiples(G1Aff* __restrict__ points, uint32_t* __restrict__ pflag, Mem* __restrict__ mult,

@@ -72,10 +72,11 @@ struct KzgSettings {
     // workgroups of the challenge chain and the 32 decode waves otherwise land on the same first CUs of every XCD and,
     // run to run, share SIMDs (the chain then takes 4.9 ms instead of 3.5 ms).  Measured: one 1 024-blob batch 9.1 ms on
     // the split pair, 10.1-11.5 ms on the plain pair; KZG_CU_MASK=0 disables the split pair.
-    mutable hipStream_t s1 = nullptr, s2 = nullptr;
+    mutable hipStream_t s1 = nullptr, s2 = nullptr, s_sha = nullptr;  // main | point decode | challenge chain (select_streams)
     hipStream_t s_plain[2] = {nullptr, nullptr};
     mutable hipStream_t s_half[2] = {nullptr, nullptr};
     mutable bool s_half_tried = false;
+    int n_cus = 0;
     hipEvent_t ev[12] = {};
     mutable hipStream_t s_copy = nullptr;  // host -> device staging copies of the host-fed stream (made on first use)
     mutable hipEvent_t ev_copy[2] = {nullptr, nullptr};
@@ -195,7 +196,8 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
 static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
     HIPCHK(hipGetDevice(&s->device));
     HIPCHK(hipStreamCreateWithFlags(&s->s_plain[0], hipStreamNonBlocking));
-    s->s1 = s->s_plain[0];
+    s->s1 = s->s_sha = s->s_plain[0];
+    HIPCHK(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->device));
     // KZG_SINGLE_STREAM=1 (profiling aid): run the point-decode chain on the same stream as the challenge chain, so
     // per-dispatch PMC counters are not polluted by a concurrent kernel
     if (getenv("KZG_SINGLE_STREAM") && getenv("KZG_SINGLE_STREAM")[0] == '1') s->s2 = s->s1;

@@ -22,7 +22,12 @@ static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const F
     }
     const unsigned per_lane = (unsigned)((T + 63) / 64);
     hipLaunchKernelGGL(k_eval_powers, dim3(per_lane), dim3(64), 0, s->s1, d_z, s->d_eval_scratch, (int)T);
-    hipLaunchKernelGGL(k_blob_evaluate, dim3((unsigned)((T + EVAL_BLOBS_PER_BLOCK - 1) / EVAL_BLOBS_PER_BLOCK)), dim3(64 * EVAL_BLOBS_PER_BLOCK), 0, s->s1,
+    // A launch that leaves CUs free asks for enough (unused) dynamic LDS that no CU takes a second workgroup: the dispatcher
+    // otherwise pairs workgroups on half the CUs, two wavefronts per SIMD, and the single batch waits twice as long.
+    const unsigned eval_blocks = (unsigned)((T + EVAL_BLOBS_PER_BLOCK - 1) / EVAL_BLOBS_PER_BLOCK);
+    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate), hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_SPREAD_LDS) == hipSuccess;
+    const size_t spread_lds = lds_ok && eval_blocks <= (unsigned)s->n_cus ? EVAL_SPREAD_LDS : 0;
+    hipLaunchKernelGGL(k_blob_evaluate, dim3(eval_blocks), dim3(64 * EVAL_BLOBS_PER_BLOCK), spread_lds, s->s1,
                        (const uint8_t*)d_blobs, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, s->d_eval_scratch, d_status, (int)T);
     hipLaunchKernelGGL(k_eval_finish, dim3(per_lane), dim3(64), 0, s->s1, s->d_eval_scratch, d_y, (int)T);
     return KZG_OK;
@@ -33,7 +38,8 @@ static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const F
 // Small launches take the form with two lanes per blob on the consumer side (k_blob_challenge_split2), mid-size ones the
 // one-lane consumer (k_blob_challenge_split); KZG_CHALLENGE_KERNEL = lane | split | split2 forces a form (A/B
 // measurement, cross-check in the tests).
-static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const void* d_commitments, Fr* d_z, size_t T) {
+static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const void* d_commitments, Fr* d_z, size_t T, hipStream_t st = nullptr) {
+    if (!st) st = s->s1;
     static const int forced = [] {
         const char* e = getenv("KZG_CHALLENGE_KERNEL");
         return !e ? 0 : strcmp(e, "lane") == 0 ? 1 : strcmp(e, "split") == 0 ? 2 : strcmp(e, "split2") == 0 ? 3 : 0;
@@ -47,14 +53,14 @@ static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const 
     if (form == 1) {
         unsigned long long* kt = s->ws.d_ktime;  // null for callers that never reserved the workspace
         if (kt) {
-            HIPCHK(hipMemsetAsync(kt, 0, 16, s->s1));
+            HIPCHK(hipMemsetAsync(kt, 0, 16, st));
             s->ws.ktime_valid = true;
         }
-        hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s->s1, bl, cm, d_z, (int)T, kt);
+        hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, bl, cm, d_z, (int)T, kt);
     } else if (form == 2) {
-        hipLaunchKernelGGL(k_blob_challenge_split, dim3((unsigned)((T + 63) / 64)), dim3(128), 0, s->s1, bl, cm, d_z, (int)T);
+        hipLaunchKernelGGL(k_blob_challenge_split, dim3((unsigned)((T + 63) / 64)), dim3(128), 0, st, bl, cm, d_z, (int)T);
     } else {
-        hipLaunchKernelGGL(k_blob_challenge_split2, dim3((unsigned)((T + 63) / 64)), dim3(192), 0, s->s1, bl, cm, d_z, (int)T);
+        hipLaunchKernelGGL(k_blob_challenge_split2, dim3((unsigned)((T + 63) / 64)), dim3(192), 0, st, bl, cm, d_z, (int)T);
     }
     HIPCHK(hipGetLastError());
     return KZG_OK;
@@ -304,8 +310,12 @@ static void select_streams(const KzgSettings* s, size_t T) {
             }
         }
     }
+    // Only the two kernels that run side by side live on the CU halves: the challenge chain (s_sha) and the point decode (s2).
+    // What follows them (evaluation, MSM, pairing) has the chip to itself and runs on the unmasked s1 - on a half mask the
+    // 256 workgroups of the evaluation and the MSM's (window, slice) grid sat two to a CU.
     const bool use_half = small && s->s_half[0];
-    s->s1 = use_half ? s->s_half[0] : s->s_plain[0];
+    s->s1 = s->s_plain[0];
+    s->s_sha = use_half ? s->s_half[0] : s->s_plain[0];
     s->s2 = use_half ? s->s_half[1] : s->s_plain[1];
 }
 
@@ -323,23 +333,38 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
     if ((rc = launch_decode(s, d_commitments, d_proofs, T)) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[6], s->s2));
     HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * T, s->s1));
-    if ((rc = launch_challenge(s, d_blobs, d_commitments, w.d_z, T)) != KZG_OK) return rc;
-    HIPCHK(hipEventRecord(s->ev[7], s->s1));
+    if (s->s_sha != s->s1) {
+        HIPCHK(hipEventRecord(s->ev[11], s->s1));
+        HIPCHK(hipStreamWaitEvent(s->s_sha, s->ev[11], 0));
+    }
+    if ((rc = launch_challenge(s, d_blobs, d_commitments, w.d_z, T, s->s_sha)) != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[7], s->s_sha));
+    if (s->s_sha != s->s1) {  // both joins in one place: each wait on another stream's event is a ~13 us bubble, even when it has long fired
+        HIPCHK(hipStreamWaitEvent(s->s1, s->ev[7], 0));
+        HIPCHK(hipStreamWaitEvent(s->s1, s->ev[6], 0));
+    }
     if ((rc = launch_evaluate(s, d_blobs, w.d_z, w.d_y, w.d_status, T)) != KZG_OK) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[8], s->s1));
-    HIPCHK(hipStreamWaitEvent(s->s1, s->ev[6], 0));
+    if (s->s_sha == s->s1) HIPCHK(hipStreamWaitEvent(s->s1, s->ev[6], 0));
     HIPCHK(hipEventRecord(s->ev[1], s->s1));
     // the transcript records, packed on the device; pinned host mirror: [records 160 T | status 4 T | point flags 8 T]
-    hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((40 * T + 255) / 256)), dim3(256), 0, s->s1, (const uint32_t*)d_commitments,
-                       (const uint32_t*)d_proofs, (const uint32_t*)w.d_z, (const uint32_t*)w.d_y, (uint32_t*)w.d_records, (int)T);
-    HIPCHK(hipGetLastError());
     uint8_t* h = w.h_buf;
-    uint32_t* h_status = reinterpret_cast<uint32_t*>(h + 160 * T);
-    uint32_t* h_pflag = h_status + T;
-    HIPCHK(hipMemcpyAsync(h, w.d_records, 160 * T, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * T, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * T, hipMemcpyDeviceToHost, s->s1));
+    if (T <= LATENCY_MAX_BLOBS) {  // the kernel writes the mirror itself: every dispatch of a single batch's chain is ~10 us of latency
+        hipLaunchKernelGGL(k_pack_records_mirror, dim3((unsigned)((43 * T + 255) / 256)), dim3(256), 0, s->s1, (const uint32_t*)d_commitments,
+                           (const uint32_t*)d_proofs, (const uint32_t*)w.d_z, (const uint32_t*)w.d_y, (uint32_t*)w.d_records, (uint32_t*)h,
+                           (const uint32_t*)w.d_status, (const uint32_t*)w.d_pflag, (int)T);
+        HIPCHK(hipGetLastError());
+    } else {
+        hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((40 * T + 255) / 256)), dim3(256), 0, s->s1, (const uint32_t*)d_commitments,
+                           (const uint32_t*)d_proofs, (const uint32_t*)w.d_z, (const uint32_t*)w.d_y, (uint32_t*)w.d_records, (int)T);
+        HIPCHK(hipGetLastError());
+        uint32_t* h_status = reinterpret_cast<uint32_t*>(h + 160 * T);
+        uint32_t* h_pflag = h_status + T;
+        HIPCHK(hipMemcpyAsync(h, w.d_records, 160 * T, hipMemcpyDeviceToHost, s->s1));
+        HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * T, hipMemcpyDeviceToHost, s->s1));
+        HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * T, hipMemcpyDeviceToHost, s->s1));
+    }
     if (w.ktime_valid) HIPCHK(hipMemcpyAsync(h + 176 * T, w.d_ktime, 16, hipMemcpyDeviceToHost, s->s1));
     w.pending_n = n;
     w.pending_b = B;
@@ -385,7 +410,7 @@ static KzgRet phase1_wait_locked(uint8_t* records_out, uint8_t* bad_out, const K
 //   all_records != NULL, world  > 0   : hashed here from [world][B][n] records (n_total = world n)
 //   both NULL                         : hashed here from the handle's own records of phase 1 (single rank: n_total = n)
 static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, size_t offset, const KzgSettings* s, size_t world = 0,
-                                   const uint8_t* r_le = nullptr) {
+                                   const uint8_t* r_le = nullptr, bool want_partials = true) {
     Workspace& w = s->ws;
     const size_t n = w.pending_n, B = w.pending_b;
     if (!all_records && !r_le) {
@@ -401,16 +426,18 @@ static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, s
         uint8_t* h_r = w.h_buf + w.off_r;  // pinned staging for the async H2D copy
         if (r_le) memcpy(h_r, r_le, 32 * B);
         else host_batch_challenges(h_r, all_records, B, n, n_total, world);
-        HIPCHK(hipMemcpyAsync(w.d_r, h_r, 32 * B, hipMemcpyHostToDevice, s->s1));
+        const Fr* d_r = w.d_r;
+        if (n * B <= LATENCY_MAX_BLOBS) d_r = reinterpret_cast<const Fr*>(h_r);  // a small launch reads r where the host wrote it (pinned memory)
+        else HIPCHK(hipMemcpyAsync(w.d_r, h_r, 32 * B, hipMemcpyHostToDevice, s->s1));
         unsigned blocks = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_batch_scalars, dim3(blocks, (unsigned)B), dim3(256), 0, s->s1, w.d_r, w.d_z, w.d_y, w.d_scalars,
+        hipLaunchKernelGGL(k_batch_scalars, dim3(blocks, (unsigned)B), dim3(256), 0, s->s1, d_r, w.d_z, w.d_y, w.d_scalars,
                            w.d_partial, (int)n, (unsigned long long)offset);
         hipLaunchKernelGGL(k_finish_g, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_partial, (int)blocks, w.d_scalars, (int)n);
     }
     HIPCHK(hipGetLastError());
     KzgRet rc = run_msm(s, n, B);
     if (rc != KZG_OK) return rc;
-    HIPCHK(hipMemcpyAsync(w.h_buf + w.off_part, w.d_ab, 288 * B, hipMemcpyDeviceToHost, s->s1));
+    if (want_partials) HIPCHK(hipMemcpyAsync(w.h_buf + w.off_part, w.d_ab, 288 * B, hipMemcpyDeviceToHost, s->s1));  // (the local callers go straight on to the pairing)
     return KZG_OK;
 }
 
@@ -435,10 +462,12 @@ static KzgRet finish_launch_locked(const uint8_t* partials, size_t world, size_t
     hipLaunchKernelGGL(k_jac_to_slp, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_ab, w.d_slp_in);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[4], s->s1));
-    KzgRet rc = run_verify(s, w.d_slp_in, w.d_slp_out, (int)B, s->s1);
+    // (a handful of instances write their 288 bytes straight into the pinned mirror: one dispatch less at the end of the chain)
+    const bool direct = B <= LATENCY_PAIRING_MAX;
+    KzgRet rc = run_verify(s, w.d_slp_in, direct ? reinterpret_cast<Fp*>(w.h_buf + w.off_out) : w.d_slp_out, (int)B, s->s1);
     if (rc != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[9], s->s1));
-    HIPCHK(hipMemcpyAsync(w.h_buf + w.off_out, w.d_slp_out, sizeof(Fp) * 6 * B, hipMemcpyDeviceToHost, s->s1));
+    if (!direct) HIPCHK(hipMemcpyAsync(w.h_buf + w.off_out, w.d_slp_out, sizeof(Fp) * 6 * B, hipMemcpyDeviceToHost, s->s1));
     w.finish_b = B;
     return KZG_OK;
 }
@@ -465,7 +494,7 @@ static KzgRet batch_device_locked(bool* ok, const void* d_blobs, const void* d_c
     KzgRet rc;
     if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, 1, s)) != KZG_OK) return rc;
     if ((rc = phase1_wait_locked(nullptr, nullptr, s)) != KZG_OK) return rc;
-    if ((rc = phase2_launch_locked(nullptr, n, 0, s)) != KZG_OK) return rc;
+    if ((rc = phase2_launch_locked(nullptr, n, 0, s, 0, nullptr, false)) != KZG_OK) return rc;
     if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;  // same stream: no host round trip needed
     return finish_wait_locked(ok, s);
 }
@@ -565,7 +594,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batches_device(bool* ok_out, uint8_t
     if (rc != KZG_OK) return rc;
     if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, n_batches, s)) != KZG_OK) return rc;
     if ((rc = phase1_wait_locked(nullptr, err_out, s)) != KZG_OK) return rc;
-    if ((rc = phase2_launch_locked(nullptr, n, 0, s)) != KZG_OK) return rc;
+    if ((rc = phase2_launch_locked(nullptr, n, 0, s, 0, nullptr, false)) != KZG_OK) return rc;
     if ((rc = finish_launch_locked(nullptr, 1, n_batches, s)) != KZG_OK) return rc;
     if ((rc = finish_wait_locked(ok_out, s)) != KZG_OK) return rc;
     if (err_out)
@@ -690,7 +719,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batches(bool* ok_out, uint8_t* err_o
         if (c + 1 < n_chunks && (rc = copy_part(c + 1, 0)) != KZG_OK) return drained(rc);
         uint8_t* err = err_out ? err_out + c * G : nullptr;
         if ((rc = phase1_wait_locked(nullptr, err, s)) != KZG_OK) return drained(rc);
-        if ((rc = phase2_launch_locked(nullptr, n, 0, s)) != KZG_OK) return drained(rc);
+        if ((rc = phase2_launch_locked(nullptr, n, 0, s, 0, nullptr, false)) != KZG_OK) return drained(rc);
         if ((rc = finish_launch_locked(nullptr, 1, B, s)) != KZG_OK) return drained(rc);
         if (c + 1 < n_chunks && (rc = copy_part(c + 1, 1)) != KZG_OK) return drained(rc);
         if ((rc = finish_wait_locked(ok_out + c * G, s)) != KZG_OK) return drained(rc);
@@ -762,7 +791,7 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
     w.pending_n = n;
     w.pending_b = 1;
     // n == 1: r^0 = 1 whatever the transcript hashes to, which is phase 2's n_total == 1 branch (scalars 1, z, -y)
-    if ((rc = phase2_launch_locked(records.data(), n, 0, s)) != KZG_OK) return rc;
+    if ((rc = phase2_launch_locked(records.data(), n, 0, s, 0, nullptr, false)) != KZG_OK) return rc;
     if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;
     return finish_wait_locked(ok, s);
 }

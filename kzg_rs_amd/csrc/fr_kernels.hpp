@@ -599,6 +599,7 @@ __global__ __launch_bounds__(64) void k_eval_finish(const uint32_t* __restrict__
 // Register budget of two waves per SIMD (192 VGPRs used): with 168 the allocator reuses the prefetch registers and the
 // wait counters turn the prefetches into stalls - three waves per SIMD were 2 % slower than two with working prefetches.
 constexpr int EVAL_BLOBS_PER_BLOCK = 4;
+constexpr int EVAL_SPREAD_LDS = 96 * 1024;  // dynamic LDS nobody touches: with it a CU holds ONE workgroup (launch_evaluate)
 __global__ __launch_bounds__(256, 2) void k_blob_evaluate(const uint8_t* __restrict__ blobs, const EvalTables tab,
                                                        uint32_t* __restrict__ scratch, uint32_t* __restrict__ status, int T) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
