@@ -256,6 +256,9 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
                            (const G1Aff29Mem*)s->d_gen_mult_aff, n2, np, w.chunks);
     } else if (fp29_enabled()) {
         G1Jac29Mem* mult = (G1Jac29Mem*)w.d_mult;
+        // (the generator's rows first: behind the decode kernel they would sit on the critical path of a proof-tuple call)
+        hipLaunchKernelGGL(k_set_generator_multiples<G1Jac29Mem>, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, mult,
+                           (const G1Jac29Mem*)s->d_gen_mult + gen_off, n2, np, w.chunks);
         if (w.chunks == MSM_CHUNKS_LATENCY)
             hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS_LATENCY, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
         else if (w.chunks == MSM_CHUNKS_PROOFS)
@@ -263,8 +266,6 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
         else
             hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
         HIPCHK(hipEventRecord(s->ev[10], s->s2));
-        hipLaunchKernelGGL(k_set_generator_multiples<G1Jac29Mem>, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, mult,
-                           (const G1Jac29Mem*)s->d_gen_mult + gen_off, n2, np, w.chunks);
     } else {
         G1Jac* mult = (G1Jac*)w.d_mult;
         if (w.chunks == MSM_CHUNKS_LATENCY)
@@ -779,19 +780,41 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
     }
     HIPCHK(hipMemcpyAsync(w.d_z, w.h_buf, 32 * n, hipMemcpyHostToDevice, s->s1));
     HIPCHK(hipMemcpyAsync(w.d_y, w.h_buf + 32 * n, 32 * n, hipMemcpyHostToDevice, s->s1));
-    HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
-    HIPCHK(hipMemcpyAsync(w.d_stage_cp + 48 * n, proofs, 48 * n, hipMemcpyHostToDevice, s->s1));
-    HIPCHK(hipStreamSynchronize(s->s1));
-    if ((rc = launch_decode(s, w.d_stage_cp, w.d_stage_cp + 48 * n, n, /*behind_sha=*/false)) != KZG_OK) return rc;
     uint32_t* h_pflag = reinterpret_cast<uint32_t*>(w.h_buf + 64 * n);
-    HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * n, hipMemcpyDeviceToHost, s->s2));
-    HIPCHK(hipStreamSynchronize(s->s2));
-    for (size_t i = 0; i < 2 * n; i++)
-        if (h_pflag[i] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    // A small call keeps the host out of the chain: the decode kernel reads the points where they lie (a pinned copy - the
+    // caller's memory is pageable), the MSM waits for it through an event, and the point flags are looked at after the
+    // pairing (flagged points have identity table rows: the work on them is wasted, not wrong).
+    const bool chained = n <= LATENCY_MAX_BLOBS;
+    if (chained) {
+        uint8_t* h_cp = w.h_buf + 72 * n;
+        memcpy(h_cp, commitments, 48 * n);
+        memcpy(h_cp + 48 * n, proofs, 48 * n);
+        HIPCHK(hipEventRecord(s->ev[11], s->s1));
+        HIPCHK(hipStreamWaitEvent(s->s2, s->ev[11], 0));  // the previous call's readers of the tables
+        if ((rc = launch_decode(s, h_cp, h_cp + 48 * n, n, /*behind_sha=*/false)) != KZG_OK) return rc;
+        HIPCHK(hipEventRecord(s->ev[11], s->s2));
+        HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * n, hipMemcpyDeviceToHost, s->s2));
+        HIPCHK(hipStreamWaitEvent(s->s1, s->ev[11], 0));
+    } else {
+        HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
+        HIPCHK(hipMemcpyAsync(w.d_stage_cp + 48 * n, proofs, 48 * n, hipMemcpyHostToDevice, s->s1));
+        HIPCHK(hipStreamSynchronize(s->s1));
+        if ((rc = launch_decode(s, w.d_stage_cp, w.d_stage_cp + 48 * n, n, /*behind_sha=*/false)) != KZG_OK) return rc;
+        HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * n, hipMemcpyDeviceToHost, s->s2));
+        HIPCHK(hipStreamSynchronize(s->s2));
+        for (size_t i = 0; i < 2 * n; i++)
+            if (h_pflag[i] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    }
     w.pending_n = n;
     w.pending_b = 1;
     // n == 1: r^0 = 1 whatever the transcript hashes to, which is phase 2's n_total == 1 branch (scalars 1, z, -y)
     if ((rc = phase2_launch_locked(records.data(), n, 0, s, 0, nullptr, false)) != KZG_OK) return rc;
     if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;
-    return finish_wait_locked(ok, s);
+    if ((rc = finish_wait_locked(ok, s)) != KZG_OK) return rc;
+    if (chained) {
+        HIPCHK(hipStreamSynchronize(s->s2));  // (the flags landed long ago)
+        for (size_t i = 0; i < 2 * n; i++)
+            if (h_pflag[i] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    }
+    return KZG_OK;
 }
