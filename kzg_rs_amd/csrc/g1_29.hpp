@@ -250,11 +250,56 @@ __device__ inline Fp29 fp29_pow_window3(const Fp29& a, const uint32_t (&e)[12], 
     return acc;
 }
 __device__ inline Fp29 fp29_sqrt_candidate(const Fp29& a) { return fp29_pow_window3(a, consts::FP_SQRT_EXP, 378); }  // (p+1)/4 has 379 bits
+// The same power with the window table's upper half (a^5, a^7) in the parking place, elements [at, at + 8): the table, the
+// accumulator and the caller's x and y^2 on top of a squaring's own ~150 registers do not fit 248, and what the allocator
+// then moved to scratch was the accumulator - a 56-byte store and load per squaring, 2 KB of it per point reaching HBM
+// (that, not the table rows, was the decode pass's WRITE_SIZE).
+__device__ inline Fp29 fp29_sqrt_candidate_parked(const Fp29& a, const LdsPark& pk, int at) {
+    const uint32_t (&e)[12] = consts::FP_SQRT_EXP;
+    const Fp29 a2 = fp29_sqr(a);
+    const Fp29 t1 = fp29_mul(a, a2);
+    {
+        const Fp29 t2 = fp29_mul(t1, a2);
+        park_store<14>(pk, at, t2.l);
+        const Fp29 t3 = fp29_mul(t2, a2);
+        park_store<14>(pk, at + 4, t3.l);
+    }
+    Fp29 acc = fp29_const(cp29::FP29_ONE);
+    bool started = false;
+    int i = 378;  // (p+1)/4 has 379 bits
+    auto bit = [&](int k) { return (e[k >> 5] >> (k & 31)) & 1u; };
+    while (i >= 0) {
+        if (!bit(i)) {
+            if (started) acc = fp29_sqr(acc);
+            i--;
+            continue;
+        }
+        int j = i - 2 < 0 ? 0 : i - 2;
+        while (!bit(j)) j++;
+        uint32_t v = 0;
+        for (int k = i; k >= j; k--) v = (v << 1) | bit(k);
+        if (started)
+            for (int k = i; k >= j; k--) acc = fp29_sqr(acc);
+        const uint32_t idx = v >> 1;  // uniform: the exponent is a constant
+        Fp29 m;
+        if (idx >= 2) {
+            park_load<14>(pk, at + 4 * (int)(idx - 2), m.l);
+        } else {
+#pragma unroll
+            for (int w = 0; w < 14; w++) m.l[w] = idx == 0 ? a.l[w] : t1.l[w];
+        }
+        acc = started ? fp29_mul(acc, m) : m;
+        started = true;
+        i = j - 1;
+    }
+    return acc;
+}
 __device__ inline Fp29 fp29_inverse(const Fp29& a) { return fp29_pow_window3(a, consts::FP_P_MINUS_2, 380); }       // p - 2 has 381 bits; a != 0 mod p
 
 // 48 compressed bytes -> affine point in this field (x R'', y R'' below 2p... y possibly 4p - y).  Subgroup NOT checked.
 // Returns G1_OK / G1_INFINITY / G1_INVALID exactly like g1_decompress.
-__device__ inline uint32_t g1_decompress29(Fp29& xo, Fp29& yo, const uint8_t* b) {
+// pk: the parking place (all of it is free here): x and y^2 wait there while the square root is taken.
+__device__ inline uint32_t g1_decompress29(Fp29& xo, Fp29& yo, const uint8_t* b, const LdsPark& pk) {
     uint32_t w[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
@@ -273,9 +318,11 @@ __device__ inline uint32_t g1_decompress29(Fp29& xo, Fp29& yo, const uint8_t* b)
     }
     if (i_flag) return (s_flag || any) ? G1_INVALID : G1_INFINITY;
     if (FpF::geq_mod(xs)) return G1_INVALID;
-    const Fp29 x = fp29_mul(fp29_from_words(xs.l), fp29_const(cp29::FP29_R2));           // x R'', < 2p
-    const Fp29 y2 = fp29_add(fp29_mul(fp29_sqr(x), x), fp29_const(cp29::FP29_B_MONT));    // < 3p
-    Fp29 y = fp29_sqrt_candidate(y2);                                                     // < 2p
+    Fp29 x = fp29_mul(fp29_from_words(xs.l), fp29_const(cp29::FP29_R2));           // x R'', < 2p
+    Fp29 y2 = fp29_add(fp29_mul(fp29_sqr(x), x), fp29_const(cp29::FP29_B_MONT));    // < 3p
+    park_xy(pk, x, y2);                                                             // elements [0, 7)
+    Fp29 y = fp29_sqrt_candidate_parked(y2, pk, 7);                                 // < 2p
+    unpark_xy(pk, x, y2);
     const Fp29 one = fp29_const(cp29::FP29_ONE);
     if (!fp29_is_zero_mod_p(fp29_mul(fp29_sub<3>(fp29_sqr(y), y2), one))) return G1_INVALID;  // not a square
     // sign: "lexicographically largest" on the plain canonical value of y

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, KZG_DECODE_OCC) void k_g1_decode_multiples29(c
     if (i >= n) return;
     const uint8_t* src = i < n0 ? bytes0 + (size_t)i * 48 : bytes1 + (size_t)(i - n0) * 48;
     Fp29 x, y;
-    uint32_t st = g1_decompress29(x, y, src);
+    uint32_t st = g1_decompress29(x, y, src, pk);
     G1Aff a;
     a.x = FpF::zero();
     a.y = FpF::zero();
