@@ -93,23 +93,39 @@ __device__ __forceinline__ G1Jac g1j29_to_std(const G1Jac29& p) {
 // at 256 VGPRs the allocator spilled q, x and y to scratch inside the chains (4.4 KB of HBM writes per point).  LDS is
 // there for the taking (the kernel uses none otherwise): 18 uint4 per thread, element e of thread t at [e * stride + t]
 // (one ds_write_b128 per element, conflict-free).
+// The pointer carries the LDS address space in its TYPE.  As a plain (generic) pointer it survived only while everything
+// was inlined: the out-of-line chain function got it as a 64-bit flat address, every park access became a flat_load /
+// flat_store, and the counters showed them going through the L1 to the L2 like global accesses (TCP_TCC_WRITE_REQ 113 M
+// per launch group, ~0.8 GB of it written on to HBM as the parked lines were evicted) - the "LDS parking" was parked
+// in memory.
+typedef uint32_t ParkVec __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) ParkVec LdsParkVec;
 struct LdsPark {
-    uint4* base;      // already offset by the thread index
-    unsigned stride;  // threads per workgroup
+    LdsParkVec* base;  // already offset by the thread index
+    unsigned stride;   // threads per workgroup
 };
+// from a pointer into a __shared__ array (the low 32 bits of its generic address are the LDS offset)
+__device__ __forceinline__ LdsPark lds_park(const uint4* shared_ptr, unsigned stride) {
+    return LdsPark{reinterpret_cast<LdsParkVec*>(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(shared_ptr))), stride};
+}
 constexpr int PARK_UINT4_PER_THREAD = 18;  // (x, y): 7, a Jacobian point: 11
 template <int NWORDS>
 __device__ __forceinline__ void park_store(const LdsPark& pk, int at, const uint32_t (&w)[NWORDS]) {
 #pragma unroll
-    for (int e = 0; e < (NWORDS + 3) / 4; e++)
-        pk.base[(at + e) * pk.stride] = make_uint4(w[4 * e], 4 * e + 1 < NWORDS ? w[4 * e + 1] : 0u, 4 * e + 2 < NWORDS ? w[4 * e + 2] : 0u,
-                                                  4 * e + 3 < NWORDS ? w[4 * e + 3] : 0u);
+    for (int e = 0; e < (NWORDS + 3) / 4; e++) {
+        ParkVec v;
+        v.x = w[4 * e];
+        v.y = 4 * e + 1 < NWORDS ? w[4 * e + 1] : 0u;
+        v.z = 4 * e + 2 < NWORDS ? w[4 * e + 2] : 0u;
+        v.w = 4 * e + 3 < NWORDS ? w[4 * e + 3] : 0u;
+        pk.base[(at + e) * pk.stride] = v;
+    }
 }
 template <int NWORDS>
 __device__ __forceinline__ void park_load(const LdsPark& pk, int at, uint32_t (&w)[NWORDS]) {
 #pragma unroll
     for (int e = 0; e < (NWORDS + 3) / 4; e++) {
-        const uint4 v = pk.base[(at + e) * pk.stride];
+        const ParkVec v = pk.base[(at + e) * pk.stride];
         w[4 * e] = v.x;
         if (4 * e + 1 < NWORDS) w[4 * e + 1] = v.y;
         if (4 * e + 2 < NWORDS) w[4 * e + 2] = v.z;
@@ -168,7 +184,9 @@ __device__ inline G1Jac29 g1j29_mul_xabs(const G1Jac29& p) {
     return acc;
 }
 // the same with P parked (unpark_point(pk)): it is needed five times in 63 iterations
-__device__ inline G1Jac29 g1j29_mul_xabs_parked(const LdsPark& pk) {
+// (forced inline: as a function of its own it returned the point through memory and kept the accumulator THERE - 168 bytes
+// of scratch stores per iteration, the bulk of the decode pass's WRITE_SIZE)
+__device__ __forceinline__ G1Jac29 g1j29_mul_xabs_parked(const LdsPark& pk) {
     G1Jac29 acc = unpark_point(pk);
 #pragma unroll 1
     for (int i = 62; i >= 0; i--) {

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, KZG_DECODE_OCC) void k_g1_decode_multiples29(c
     static_assert(!AFF || CHUNKS == 4, "the affine layout has one Jacobian multiple per point");
     constexpr int HALF = CHUNKS / 2, STEP = 256 / CHUNKS;
     extern __shared__ __attribute__((aligned(16))) uint4 park4[];  // PARK_UINT4_PER_THREAD per thread (g1_29.hpp LdsPark)
-    const LdsPark pk{park4 + threadIdx.x, blockDim.x};
+    const LdsPark pk = lds_park(park4 + threadIdx.x, blockDim.x);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint8_t* src = i < n0 ? bytes0 + (size_t)i * 48 : bytes1 + (size_t)(i - n0) * 48;
