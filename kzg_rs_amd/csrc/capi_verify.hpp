@@ -196,7 +196,12 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     while (S < MSM_MAX_SLICES && W * slots * 2 * B * S < 768 && n / (2 * S) >= 1024 && 2 * S * B <= 128) S *= 2;
     // a small launch (the latency layout: one batch, 64 blocks) is bound by its fullest bucket - ~18 of 2 049 terms, 15 us
     // a Jacobian addition at lone-wave speed: four slices quarter that chain for one more short fold
-    if (d.chunks != MSM_CHUNKS && S == 1 && n >= 256 && B <= 4) S = 4;
+    static const unsigned latency_slices = [] {  // KZG_MSM_LATENCY_SLICES = 1 | 2 | 4 | 8 (A/B measurement)
+        const char* e = getenv("KZG_MSM_LATENCY_SLICES");
+        const unsigned v = e ? (unsigned)atoi(e) : 0;
+        return v == 1 || v == 2 || v == 4 || v == 8 ? v : 4u;
+    }();
+    if (d.chunks != MSM_CHUNKS && S == 1 && n >= 256 && B <= 4) S = latency_slices;
     // ... and until a block's sorted term list fits in LDS (msm.hpp LDSSORT): the global list costs a line of HBM write
     // traffic per 4-byte entry once the launch outgrows the L2
     const size_t lds_cap = fp29_enabled() ? msm_lds_sort_capacity<Curve29>() : msm_lds_sort_capacity<Curve32>();
