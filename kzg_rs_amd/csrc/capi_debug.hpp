@@ -58,6 +58,25 @@ extern "C" KzgRet kzg_debug_slp_bench(float* ms_out, float* mhz_out, int instanc
     return KZG_OK;
 }
 
+// test hook (tests/test_gpu_parity.py): the sum of npts (a power of two, 2..128) Jacobian points through k_msm_sum_quads.
+// points / out: the library's in-memory G1Jac - x | y | z, each 12 little-endian 32-bit words in Montgomery form (R = 2^384),
+// z = 0 for the identity.
+extern "C" KzgRet kzg_debug_msm_sum_quads(uint8_t out[144], const uint8_t* points, int npts, const KzgSettings* s) {
+    if (!s || !out || !points || npts < 2 || npts > SUMQ_MAX_POINTS || (npts & (npts - 1))) return fail(KZG_BADARGS, "bad argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    DevTmp t_in, t_out;
+    HIPCHK(hipMalloc(&t_in.p, sizeof(G1Jac) * npts));
+    HIPCHK(hipMalloc(&t_out.p, sizeof(G1Jac)));
+    HIPCHK(hipMemcpy(t_in.p, points, sizeof(G1Jac) * npts, hipMemcpyHostToDevice));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_sum_quads), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SUMQ_LDS_BYTES));
+    hipLaunchKernelGGL(k_msm_sum_quads, dim3(1), dim3(256), SUMQ_LDS_BYTES, s->s1, t_in.as<G1Jac>(), t_out.as<G1Jac>(), npts);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->s1));
+    HIPCHK(hipMemcpy(out, t_out.p, sizeof(G1Jac), hipMemcpyDeviceToHost));
+    return KZG_OK;
+}
+
 extern "C" KzgRet kzg_last_timings(const KzgSettings* s, float out_ms[8]) {
     if (!s || !out_ms) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);

@@ -226,6 +226,19 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
         if (lds_sort) msm_window_launch<Curve32, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
         else msm_window_launch<Curve32, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
     }
+    // the latency layout (one window per chunk) of a few batches: every output is the plain sum of its slots x slices window
+    // sums - one workgroup per output, four lanes per addition (KZG_MSM_SUM_QUADS=0: the fold + combine kernels, A/B)
+    static const bool sum_quads = [] {
+        const char* e = getenv("KZG_MSM_SUM_QUADS");
+        if (e && e[0] == '0') return false;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_sum_quads), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SUMQ_LDS_BYTES) == hipSuccess;
+    }();
+    if (sum_quads && W == 1 && fp29_enabled() && slots * S >= 2 && slots * S <= (unsigned)SUMQ_MAX_POINTS && 2 * B < 64) {
+        hipLaunchKernelGGL(k_msm_sum_quads, dim3((unsigned)(2 * B)), dim3(256), SUMQ_LDS_BYTES, s->s1, d.window_sums, w.d_ab, (int)(slots * S));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s->ev[3], s->s1));
+        return KZG_OK;
+    }
     if (S > 1)
         hipLaunchKernelGGL(k_msm_fold_slices, dim3((unsigned)(2 * B * slots * W)), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, (int)W);
     if (2 * B >= 64)  // enough outputs to fill wavefronts with one lane each

@@ -732,6 +732,147 @@ __global__ __launch_bounds__(64) void k_msm_combine(const G1Jac* __restrict__ wi
     out[o] = acc;
 }
 
+// ---- the sum of a small batch's window sums with FOUR LANES PER ADDITION (the latency layout: W = 1, up to 128 sums per
+// output).  A Jacobian addition is 16 products of dependency depth 5; on one lane of a wavefront that is alone on its SIMD
+// it takes ~15 us, and the fold over the slices and the tree over the chunks were 7 of them in a row (k_msm_fold_slices +
+// k_msm_combine: 0.2 ms of a 5 ms batch).  Here the quad (lanes 4q .. 4q + 3) runs one addition as five ROUNDS of one
+// product per lane; a round's results go through three 16-word LDS slots per lane (same wavefront: the LDS executes its
+// instructions in order, no barrier inside an addition) and the next round's operands are read back by per-lane address:
+//     round 1   Z1Z1 = Z1^2        Z2Z2 = Z2^2        Y1Z2 = Y1 Z2         Y2Z1 = Y2 Z1
+//     round 2   U1 = X1 Z2Z2       U2 = X2 Z1Z1       S1 = Y1Z2 Z2Z2       S2 = Y2Z1 Z1Z1
+//               H = U2 - U1 (lanes 0, 1)              R = S2 - S1 (lanes 2, 3)
+//     round 3   HH = H^2           Z1H = Z1 H         RR = R^2             (RR again)
+//     round 4   HHH = H HH         Z3 = Z1H Z2        V = U1 HH            (V again)
+//               X3 = RR - HHH - 2V (lane 2)
+//     round 5   T = S1 HHH         -                  R (V - X3)           -
+//               Y3 = R (V - X3) - T (lane 2)
+// (the formulas and bounds of g1j29_add, g1_29_formulas.hpp).  An identity operand or equal x (P + P, P - P) shows in
+// Z1Z1, Z2Z2, HH; such a quad lets its lane 0 run the complete g1j29_add afterwards.
+constexpr int SUMQ_POINT_WORDS = 48;   // X | Y | Z, 16 words each (14 limbs + 2 of padding: ds_*_b128)
+constexpr int SUMQ_SCRATCH_WORDS = 192;  // per quad: 4 lanes x 3 slots x 16 words
+constexpr int SUMQ_MAX_POINTS = 128;
+__device__ __forceinline__ Fp29 sumq_load(const uint32_t* w) {
+    const uint4* q = reinterpret_cast<const uint4*>(w);
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    Fp29 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
+    r.l[12] = d.x; r.l[13] = d.y;
+    return r;
+}
+__device__ __forceinline__ void sumq_store(uint32_t* w, const Fp29& v) {
+    uint4* q = reinterpret_cast<uint4*>(w);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+    q[3] = make_uint4(v.l[12], v.l[13], 0u, 0u);
+}
+// P <- P + Q (points at P and Q, scr: the quad's scratch, r = lane & 3).  All four lanes of the quad call this together.
+__device__ __forceinline__ void g1j29_add_quad(uint32_t* P, const uint32_t* Q, uint32_t* scr, int r, int lane) {
+    auto slot = [&](int ln, int which) { return scr + ln * 48 + which * 16; };
+    const bool r0 = r == 0, r1 = r == 1, r2 = r == 2;
+    // round 1
+    const Fp29 a1 = sumq_load(r0 ? P + 32 : r1 ? Q + 32 : r2 ? P + 16 : Q + 16);
+    const Fp29 b1 = sumq_load((r1 || r2) ? Q + 32 : P + 32);
+    const Fp29 t1 = fp29_mul(a1, b1);
+    const unsigned long long zb1 = __ballot(fp29_is_zero_mod_p(t1));
+    sumq_store(slot(r, 0), t1);
+    // round 2
+    const Fp29 x2 = sumq_load(r0 ? P : Q);  // (only lanes 0, 1 use it)
+    Fp29 a2;
+#pragma unroll
+    for (int i = 0; i < 14; i++) a2.l[i] = r < 2 ? x2.l[i] : t1.l[i];
+    const Fp29 b2 = sumq_load(slot((r & 1) ? 0 : 1, 0));  // Z2Z2 for lanes 0, 2; Z1Z1 for lanes 1, 3
+    const Fp29 t2 = fp29_mul(a2, b2);
+    sumq_store(slot(r, 1), t2);
+    const Fp29 o2 = sumq_load(slot(r ^ 1, 1));
+    Fp29 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        hi.l[i] = (r & 1) ? t2.l[i] : o2.l[i];
+        lo.l[i] = (r & 1) ? o2.l[i] : t2.l[i];
+    }
+    const Fp29 D = fp29_sub<2>(hi, lo);  // H on lanes 0, 1; R on lanes 2, 3; below 6p
+    // round 3
+    const Fp29 z1 = sumq_load(P + 32);
+    Fp29 b3;
+#pragma unroll
+    for (int i = 0; i < 14; i++) b3.l[i] = r1 ? z1.l[i] : D.l[i];
+    const Fp29 t3 = fp29_mul(D, b3);  // HH | Z1 H | RR | RR
+    const unsigned long long zb3 = __ballot(fp29_is_zero_mod_p(t3));
+    sumq_store(slot(r, 0), t3);  // (every lane has read its round-2 operand from slot 0 by now)
+    // round 4
+    const Fp29 u1 = sumq_load(slot(0, 1)), hh = sumq_load(slot(0, 0)), z2 = sumq_load(Q + 32);
+    Fp29 a4, b4;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        a4.l[i] = r0 ? D.l[i] : r1 ? t3.l[i] : u1.l[i];
+        b4.l[i] = r0 ? t3.l[i] : r1 ? z2.l[i] : hh.l[i];
+    }
+    const Fp29 t4 = fp29_mul(a4, b4);  // HHH | Z3 | V | V
+    sumq_store(slot(r, 2), t4);
+    const Fp29 hhh = sumq_load(slot(0, 2));
+    const Fp29 X3 = fp29_sub<3>(fp29_sub<2>(t3, hhh), fp29_dbl(t4));  // lanes 2, 3: RR + 4p - HHH + 8p - 2V < 14p
+    // round 5
+    const Fp29 s1 = sumq_load(slot(2, 1));
+    const Fp29 vx = fp29_sub<5>(t4, X3);
+    Fp29 a5, b5;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        a5.l[i] = r0 ? s1.l[i] : D.l[i];
+        b5.l[i] = r0 ? t4.l[i] : vx.l[i];
+    }
+    const Fp29 t5 = fp29_mul(a5, b5);  // T | - | R (V - X3) | -
+    sumq_store(slot(r, 0), t5);
+    const Fp29 T = sumq_load(slot(0, 0));
+    const Fp29 Y3 = fp29_sub<2>(t5, T);  // lane 2: below 6p
+    // the quad's flags: bit 0 Z1Z1 = 0, bit 1 Z2Z2 = 0 (round 1); bit 0 HH = 0 (round 3)
+    const int q0 = lane & ~3;
+    const bool special = (((zb1 >> q0) & 3ull) != 0) || (((zb3 >> q0) & 1ull) != 0);
+    if (!special) {
+        if (r2) {
+            sumq_store(P, X3);
+            sumq_store(P + 16, Y3);
+        }
+        if (r1) sumq_store(P + 32, t4);
+    } else if (r0) {
+        G1Jac29 p, q;
+        p.x = sumq_load(P); p.y = sumq_load(P + 16); p.z = sumq_load(P + 32);
+        q.x = sumq_load(Q); q.y = sumq_load(Q + 16); q.z = sumq_load(Q + 32);
+        const G1Jac29 s = g1j29_add(p, q);
+        sumq_store(P, s.x);
+        sumq_store(P + 16, s.y);
+        sumq_store(P + 32, s.z);
+    }
+}
+// out[o] = the sum of the npts points sums[o * npts ..]; npts a power of two, 2 <= npts <= 128; one 256-thread workgroup
+// per output; dynamic LDS: SUMQ_MAX_POINTS points + 64 quad scratches = 72 KB
+constexpr size_t SUMQ_LDS_BYTES = 4 * (SUMQ_MAX_POINTS * SUMQ_POINT_WORDS + 64 * SUMQ_SCRATCH_WORDS);
+__global__ __launch_bounds__(256) void k_msm_sum_quads(const G1Jac* __restrict__ sums, G1Jac* __restrict__ out, int npts) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sumq_lds[];
+    uint32_t* pts = sumq_lds;
+    uint32_t* scr = sumq_lds + SUMQ_MAX_POINTS * SUMQ_POINT_WORDS;
+    const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    if (tid < npts) {
+        const G1Jac p = sums[(size_t)o * npts + tid];
+        sumq_store(pts + tid * SUMQ_POINT_WORDS, fp29_from_std(p.x));
+        sumq_store(pts + tid * SUMQ_POINT_WORDS + 16, fp29_from_std(p.y));
+        sumq_store(pts + tid * SUMQ_POINT_WORDS + 32, fp29_from_std(p.z));
+    }
+    __syncthreads();
+    const int q = tid >> 2, r = tid & 3;
+    for (int half = npts >> 1; half >= 1; half >>= 1) {
+        if (q < half) g1j29_add_quad(pts + q * SUMQ_POINT_WORDS, pts + (q + half) * SUMQ_POINT_WORDS, scr + q * SUMQ_SCRATCH_WORDS, r, lane);
+        __syncthreads();
+    }
+    if (tid < 3) {  // one coordinate each
+        const Fp c = fp29_to_std(sumq_load(pts + 16 * tid));
+        Fp* dst = tid == 0 ? &out[o].x : tid == 1 ? &out[o].y : &out[o].z;
+        *dst = c;
+    }
+}
+
 // The same sum with ONE LANE per output, for launches with many outputs (a launch group of batches): the Horner chain
 // is serial either way, and a workgroup per output spends a whole wavefront's issue slots on its single busy lane.
 __global__ __launch_bounds__(64) void k_msm_combine_lanes(const G1Jac* __restrict__ window_sums, G1Jac* __restrict__ out, int nslots, int W,

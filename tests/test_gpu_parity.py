@@ -882,3 +882,71 @@ def test_handles_release_device_memory_and_oom_is_malloc():
     torch.cuda.synchronize()
     free2, _ = torch.cuda.mem_get_info()
     assert free1 - free2 < (64 << 20)  # the failed reservation left nothing behind
+
+
+def test_msm_sum_quads(settings):
+    """k_msm_sum_quads (the latency layout's sum of window sums, four lanes per Jacobian addition; csrc/msm.hpp) through its
+    test hook, against sums made of the oracle's g1_add: generic points in random Jacobian representations, identities,
+    the SAME point in two representations meeting at every tree level (P + P), P and -P, an all-identity input."""
+    import ctypes as C
+    P_MOD = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+    L, h = api.lib(), settings._h
+    L.kzg_debug_msm_sum_quads.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_void_p]
+    rng = random.Random(77)
+
+    def mont_words(v):
+        return (v * (1 << 384) % P_MOD).to_bytes(48, "little")
+
+    def jac(comp, z=None):
+        if comp == G1_INF:
+            return mont_words(rng.randrange(P_MOD)) + mont_words(rng.randrange(P_MOD)) + bytes(48)
+        raw, inf = O.g1_decompress(comp)
+        assert not inf
+        x, y = int.from_bytes(raw[:48], "big"), int.from_bytes(raw[48:], "big")
+        z = z or rng.randrange(1, P_MOD)
+        return mont_words(x * z * z % P_MOD) + mont_words(y * z * z * z % P_MOD) + mont_words(z)
+
+    def neg(comp):
+        raw, _ = O.g1_decompress(comp)
+        x, y = int.from_bytes(raw[:48], "big"), int.from_bytes(raw[48:], "big")
+        ny = (P_MOD - y) % P_MOD
+        top = 0x80 | (0x20 if ny > (P_MOD - 1) // 2 else 0)
+        b = bytearray(x.to_bytes(48, "big"))
+        b[0] |= top
+        return bytes(b)
+
+    def run(comps):
+        n = len(comps)
+        out = C.create_string_buffer(144)
+        api._chk(L.kzg_debug_msm_sum_quads(out, b"".join(jac(c) for c in comps), n, h))
+        X, Y, Z = (int.from_bytes(out.raw[48 * k: 48 * k + 48], "little") * pow(1 << 384, -1, P_MOD) % P_MOD for k in range(3))
+        want = G1_INF
+        for c in comps:
+            want = O.g1_add(want, c)
+        if want == G1_INF:
+            assert Z == 0
+            return
+        assert Z != 0
+        zi = pow(Z, -1, P_MOD)
+        raw, _ = O.g1_decompress(want)
+        assert (X * zi * zi % P_MOD, Y * zi * zi * zi % P_MOD) == (int.from_bytes(raw[:48], "big"), int.from_bytes(raw[48:], "big"))
+
+    gen = _gen_multiples([rng.randrange(1, R) for _ in range(128)])
+    run(gen)                                                   # 128 generic points: seven levels of quads
+    run(gen[:2])
+    run(gen[:32])
+    mixed = list(gen[:64])
+    for i in (0, 5, 33, 40, 41, 63):
+        mixed[i] = G1_INF                                      # identity operands on either side, and both (40 + 8 = 48 is generic)
+    mixed[37] = G1_INF
+    mixed[5 + 32] = G1_INF                                     # identity + identity at the first level
+    run(mixed)
+    dup = list(gen[:16])
+    dup[8] = dup[0]                                            # P + P at the first level (two Jacobian representations)
+    dup[9] = neg(dup[1])                                       # P - P at the first level
+    dup[6], dup[2], dup[4] = dup[2], dup[6], dup[6]            # (P2 + P6) twice: equal sums meet at the second level
+    dup[10], dup[14], dup[12] = dup[6], dup[2], dup[2]
+    run(dup)
+    run([G1_INF] * 8)
+    run([gen[0], neg(gen[0])])
+    assert neg(neg(gen[3])) == gen[3]
