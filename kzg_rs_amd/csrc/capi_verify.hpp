@@ -220,7 +220,12 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
         if (lds_sort) msm_window_launch<Curve29Aff, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
         else msm_window_launch<Curve29Aff, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
     } else if (fp29_enabled()) {
-        if (lds_sort) msm_window_launch<Curve29, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
+        // the latency layout's few workgroups run their reduction trees with four lanes per addition (KZG_MSM_TREE_QUADS=0: A/B)
+        static const bool tree_quads = !(getenv("KZG_MSM_TREE_QUADS") && getenv("KZG_MSM_TREE_QUADS")[0] == '0');
+        if (tree_quads && d.chunks != MSM_CHUNKS && B <= 4) {
+            if (lds_sort) msm_window_launch<Curve29Quads, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
+            else msm_window_launch<Curve29Quads, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
+        } else if (lds_sort) msm_window_launch<Curve29, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
         else msm_window_launch<Curve29, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
     } else {
         if (lds_sort) msm_window_launch<Curve32, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);

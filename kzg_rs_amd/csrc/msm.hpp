@@ -376,6 +376,139 @@ __device__ __forceinline__ G1Jac lds_load_jac(const uint32_t* base, int slot) {
     return p;
 }
 
+// ---- the sum of a small batch's window sums with FOUR LANES PER ADDITION (the latency layout: W = 1, up to 128 sums per
+// output).  A Jacobian addition is 16 products of dependency depth 5; on one lane of a wavefront that is alone on its SIMD
+// it takes ~15 us, and the fold over the slices and the tree over the chunks were 7 of them in a row (k_msm_fold_slices +
+// k_msm_combine: 0.2 ms of a 5 ms batch).  Here the quad (lanes 4q .. 4q + 3) runs one addition as five ROUNDS of one
+// product per lane; a round's results go through three 16-word LDS slots per lane (same wavefront: the LDS executes its
+// instructions in order, no barrier inside an addition) and the next round's operands are read back by per-lane address:
+//     round 1   Z1Z1 = Z1^2        Z2Z2 = Z2^2        Y1Z2 = Y1 Z2         Y2Z1 = Y2 Z1
+//     round 2   U1 = X1 Z2Z2       U2 = X2 Z1Z1       S1 = Y1Z2 Z2Z2       S2 = Y2Z1 Z1Z1
+//               H = U2 - U1 (lanes 0, 1)              R = S2 - S1 (lanes 2, 3)
+//     round 3   HH = H^2           Z1H = Z1 H         RR = R^2             (RR again)
+//     round 4   HHH = H HH         Z3 = Z1H Z2        V = U1 HH            (V again)
+//               X3 = RR - HHH - 2V (lane 2)
+//     round 5   T = S1 HHH         -                  R (V - X3)           -
+//               Y3 = R (V - X3) - T (lane 2)
+// (the formulas and bounds of g1j29_add, g1_29_formulas.hpp).  An identity operand or equal x (P + P, P - P) shows in
+// Z1Z1, Z2Z2, HH; such a quad lets its lane 0 run the complete g1j29_add afterwards.
+constexpr int SUMQ_POINT_WORDS = 48;   // X | Y | Z, 16 words each (14 limbs + 2 of padding: ds_*_b128)
+constexpr int SUMQ_SCRATCH_WORDS = 192;  // per quad: 4 lanes x 3 slots x 16 words
+constexpr int SUMQ_MAX_POINTS = 128;
+__device__ __forceinline__ Fp29 sumq_load(const uint32_t* w) {
+    const uint4* q = reinterpret_cast<const uint4*>(w);
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    Fp29 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
+    r.l[12] = d.x; r.l[13] = d.y;
+    return r;
+}
+__device__ __forceinline__ void sumq_store(uint32_t* w, const Fp29& v) {
+    uint4* q = reinterpret_cast<uint4*>(w);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+    q[3] = make_uint4(v.l[12], v.l[13], 0u, 0u);
+}
+// point layouts in LDS: coordinate c of the point at p
+struct SumqLayout16 {  // X | Y | Z at 16-word strides (this file's sum kernel)
+    __device__ static __forceinline__ Fp29 ld(const uint32_t* p, int c) { return sumq_load(p + 16 * c); }
+    __device__ static __forceinline__ void st(uint32_t* p, int c, const Fp29& v) { sumq_store(p + 16 * c, v); }
+};
+struct SumqLayout14 {  // lds_store_jac29's 42-word slots (the window kernel's bucket arrays)
+    __device__ static __forceinline__ Fp29 ld(const uint32_t* p, int c) {
+        Fp29 r;
+#pragma unroll
+        for (int i = 0; i < 14; i++) r.l[i] = p[14 * c + i];
+        return r;
+    }
+    __device__ static __forceinline__ void st(uint32_t* p, int c, const Fp29& v) {
+#pragma unroll
+        for (int i = 0; i < 14; i++) p[14 * c + i] = v.l[i];
+    }
+};
+// OUT <- P + Q (points at P and Q; OUT may be P; scr: the quad's scratch, r = lane & 3).  All four lanes of the quad call
+// this together.
+template <class LY>
+__device__ __forceinline__ void g1j29_add_quad(const uint32_t* P, const uint32_t* Q, uint32_t* OUT, uint32_t* scr, int r, int lane) {
+    auto slot = [&](int ln, int which) { return scr + ln * 48 + which * 16; };
+    const bool r0 = r == 0, r1 = r == 1, r2 = r == 2;
+    // round 1
+    const Fp29 a1 = LY::ld((r0 || r2) ? P : Q, (r0 || r1) ? 2 : 1);  // Z1 | Z2 | Y1 | Y2
+    const Fp29 b1 = LY::ld((r1 || r2) ? Q : P, 2);                    // Z1 | Z2 | Z2 | Z1
+    const Fp29 t1 = fp29_mul(a1, b1);
+    const unsigned long long zb1 = __ballot(fp29_is_zero_mod_p(t1));
+    sumq_store(slot(r, 0), t1);
+    // round 2
+    const Fp29 x2 = LY::ld(r0 ? P : Q, 0);  // (only lanes 0, 1 use it)
+    Fp29 a2;
+#pragma unroll
+    for (int i = 0; i < 14; i++) a2.l[i] = r < 2 ? x2.l[i] : t1.l[i];
+    const Fp29 b2 = sumq_load(slot((r & 1) ? 0 : 1, 0));  // Z2Z2 for lanes 0, 2; Z1Z1 for lanes 1, 3
+    const Fp29 t2 = fp29_mul(a2, b2);
+    sumq_store(slot(r, 1), t2);
+    const Fp29 o2 = sumq_load(slot(r ^ 1, 1));
+    Fp29 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        hi.l[i] = (r & 1) ? t2.l[i] : o2.l[i];
+        lo.l[i] = (r & 1) ? o2.l[i] : t2.l[i];
+    }
+    const Fp29 D = fp29_sub<2>(hi, lo);  // H on lanes 0, 1; R on lanes 2, 3; below 6p
+    // round 3
+    const Fp29 z1 = LY::ld(P, 2);
+    Fp29 b3;
+#pragma unroll
+    for (int i = 0; i < 14; i++) b3.l[i] = r1 ? z1.l[i] : D.l[i];
+    const Fp29 t3 = fp29_mul(D, b3);  // HH | Z1 H | RR | RR
+    const unsigned long long zb3 = __ballot(fp29_is_zero_mod_p(t3));
+    sumq_store(slot(r, 0), t3);  // (every lane has read its round-2 operand from slot 0 by now)
+    // round 4
+    const Fp29 u1 = sumq_load(slot(0, 1)), hh = sumq_load(slot(0, 0)), z2 = LY::ld(Q, 2);
+    Fp29 a4, b4;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        a4.l[i] = r0 ? D.l[i] : r1 ? t3.l[i] : u1.l[i];
+        b4.l[i] = r0 ? t3.l[i] : r1 ? z2.l[i] : hh.l[i];
+    }
+    const Fp29 t4 = fp29_mul(a4, b4);  // HHH | Z3 | V | V
+    sumq_store(slot(r, 2), t4);
+    const Fp29 hhh = sumq_load(slot(0, 2));
+    const Fp29 X3 = fp29_sub<3>(fp29_sub<2>(t3, hhh), fp29_dbl(t4));  // lanes 2, 3: RR + 4p - HHH + 8p - 2V < 14p
+    // round 5
+    const Fp29 s1 = sumq_load(slot(2, 1));
+    const Fp29 vx = fp29_sub<5>(t4, X3);
+    Fp29 a5, b5;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        a5.l[i] = r0 ? s1.l[i] : D.l[i];
+        b5.l[i] = r0 ? t4.l[i] : vx.l[i];
+    }
+    const Fp29 t5 = fp29_mul(a5, b5);  // T | - | R (V - X3) | -
+    sumq_store(slot(r, 0), t5);
+    const Fp29 T = sumq_load(slot(0, 0));
+    const Fp29 Y3 = fp29_sub<2>(t5, T);  // lane 2: below 6p
+    // the quad's flags: bit 0 Z1Z1 = 0, bit 1 Z2Z2 = 0 (round 1); bit 0 HH = 0 (round 3)
+    const int q0 = lane & ~3;
+    const bool special = (((zb1 >> q0) & 3ull) != 0) || (((zb3 >> q0) & 1ull) != 0);
+    if (!special) {
+        if (r2) {
+            LY::st(OUT, 0, X3);
+            LY::st(OUT, 1, Y3);
+        }
+        if (r1) LY::st(OUT, 2, t4);
+    } else if (r0) {
+        G1Jac29 p, q;
+        p.x = LY::ld(P, 0); p.y = LY::ld(P, 1); p.z = LY::ld(P, 2);
+        q.x = LY::ld(Q, 0); q.y = LY::ld(Q, 1); q.z = LY::ld(Q, 2);
+        const G1Jac29 s = g1j29_add(p, q);
+        LY::st(OUT, 0, s.x);
+        LY::st(OUT, 1, s.y);
+        LY::st(OUT, 2, s.z);
+    }
+}
 // grid (W windows per chunk, chunks / chunks_per_block, 2 outputs x batches), 256 threads: block (w, g, o) handles digit
 // byte W j + w of every scalar of output o for its chunks j, against the table of chunk j (W = 32 / chunks).
 __device__ __forceinline__ void lds_store_jac29(uint32_t* base, int slot, const G1Jac29& p) {
@@ -407,6 +540,7 @@ struct Curve32 {
     using Entry = G1Jac;
     static constexpr int WORDS = 36;
     static constexpr bool SPLIT = false;  // the 12x32 A/B variant keeps the complete formulas in its loops
+    static constexpr bool QUADS = false;
     __device__ static __forceinline__ Pt add_entry(const Pt& a, const Entry& b) { return g1_add(a, b); }
     __device__ static __forceinline__ Pt identity() { return g1_identity(); }
     __device__ static __forceinline__ Pt add(const Pt& a, const Pt& b) { return g1_add(a, b); }
@@ -423,6 +557,7 @@ struct Curve29 {
     static constexpr int WORDS = 42;
     // the additions of the loops in two halves (g1_29_formulas.hpp): special(h) -> the pair needs the complete formula
     static constexpr bool SPLIT = true;
+    static constexpr bool QUADS = false;  // reduction trees with four lanes per addition (Curve29Quads)
     using EntryHead = G1AddHead;
     // (accumulator and table entries are finite in the bucket loop; an accumulator that a P - P turned into the identity
     // has Z = 0, hence H = 0 - U1 ... not necessarily 0: the flags are part of "special")
@@ -446,6 +581,13 @@ struct Curve29 {
     __device__ static __forceinline__ Pt lds_load(const uint32_t* b, int s) { return lds_load_jac29(b, s); }
     __device__ static __forceinline__ G1Jac to_std(const Pt& p) { return g1j29_to_std(p); }
 };
+
+// Curve29 for the latency layout: the levels of the bucket reduction that have at most 64 additions run them with four lanes
+// each (g1j29_add_quad; 192 words of dynamic LDS per quad + a second R | C vector for the scan levels: MSM_QUADS_LDS_BYTES)
+struct Curve29Quads : Curve29 {
+    static constexpr bool QUADS = true;
+};
+constexpr size_t MSM_QUADS_LDS_BYTES = 4 * (64 * SUMQ_SCRATCH_WORDS + 32 * Curve29::WORDS);
 
 // Curve29 with AFFINE table entries (k_mult_to_affine29): bucket accumulation by mixed additions
 struct Curve29Aff : Curve29 {
@@ -476,7 +618,7 @@ struct Curve29Aff : Curve29 {
 template <class CV>
 constexpr int msm_lds_sort_capacity() { return MSM_BUCKETS * CV::WORDS; }
 template <class CV, bool LDSSORT = false>
-__global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
+__global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window(MsmDesc d) {  // (the latency variant has a CU to itself)
     using Pt = typename CV::Pt;
     // blockIdx.z = (2*batch + output) * slices + slice
     const int zz = (int)blockIdx.z + d.z0;  // logical z: (2 batch + output) * slices + slice
@@ -600,6 +742,10 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
     uint32_t* const save = d.save + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * CV::WORDS) * 256 + tid;
 #pragma unroll
     for (int i = 0; i < CV::WORDS; i++) save[(size_t)i * 256] = pts[tid * CV::WORDS + i];
+    // (CV::QUADS) quad scratch and the second R | C vector of the scan levels, in dynamic LDS
+    extern __shared__ __attribute__((aligned(16))) uint32_t msm_dyn_lds[];
+    uint32_t* rc_cur = rc;
+    uint32_t* rc_nxt = msm_dyn_lds + 64 * SUMQ_SCRATCH_WORDS;
 #pragma unroll 1
     for (int lvl = 0; lvl < 16; lvl++) {
         const int kind = lvl >> 2, s = kind == 3 ? (8 >> (lvl & 3)) : (1 << (lvl & 3));
@@ -616,27 +762,61 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
             if (tid < 32 && (tid & 15) == 0) CV::lds_store(rc, tid, CV::identity());
             __syncthreads();
         }
-        uint32_t* const arr = kind < 2 ? pts : rc;
+        if constexpr (CV::QUADS) {
+            // 16 R_hi instead of 16 (sum hi R_hi): the four doublings run on sixteen lanes of the fourth wavefront, which the
+            // column levels leave idle (two during the 128 single-lane additions of level 4, one each beside levels 6, 7)
+            if ((lvl == 4 || lvl == 6 || lvl == 7) && tid >= 192 && tid < 208) {
+                Pt R = CV::lds_load(rc, tid - 192);
+                R = CV::dbl(R);
+                if (lvl == 4) R = CV::dbl(R);
+                CV::lds_store(rc, tid - 192, R);
+            }
+        }
+        const int ops = kind < 2 ? 128 / s : 32;  // additions of this level (some of the 32 of a scan / tree level idle)
+        // k = the operation this thread works on: its own, or - with at most 64 of them - its quad's
+        const bool quads = CV::QUADS && ops <= 64;
+        const int k = quads ? tid >> 2 : tid;
         bool active;
         int dst, src;
         if (kind == 0) {
             const int per_row = 8 / s;
-            active = tid < 128 / s;
-            dst = 16 * (tid / per_row) + 2 * s * (tid % per_row);
+            active = k < ops;
+            dst = 16 * (k / per_row) + 2 * s * (k % per_row);
             src = dst + s;
         } else if (kind == 1) {
-            active = tid < 128 / s;
-            dst = 16 * (2 * s * (tid >> 4)) + (tid & 15);
+            active = k < ops;
+            dst = 16 * (2 * s * (k >> 4)) + (k & 15);
             src = dst + 16 * s;
         } else if (kind == 2) {
-            active = tid < 32 && (tid & 15) + s < 16;
-            dst = tid;
-            src = tid + s;
+            active = k < 32 && (k & 15) + s < 16;
+            dst = k;
+            src = k + s;
         } else {
-            active = tid < 32 && (tid & 15) < s;
-            dst = tid;
-            src = tid + s;
+            active = k < 32 && (k & 15) < s;
+            dst = k;
+            src = k + s;
         }
+        if constexpr (CV::QUADS) {
+            if (quads) {
+                uint32_t* const qs = msm_dyn_lds + (tid >> 2) * SUMQ_SCRATCH_WORDS;
+                const int r = tid & 3;
+                if (kind == 2) {
+                    // a scan level reads slots that their owners rewrite in the same level: from one vector into the other
+                    if (active) g1j29_add_quad<SumqLayout14>(rc_cur + dst * CV::WORDS, rc_cur + src * CV::WORDS, rc_nxt + dst * CV::WORDS, qs, r, tid & 63);
+                    else if (k < 32 && r == 0) CV::lds_store(rc_nxt, k, CV::lds_load(rc_cur, k));
+                    __syncthreads();
+                    uint32_t* const t = rc_cur;
+                    rc_cur = rc_nxt;
+                    rc_nxt = t;  // (four scan levels: back in rc at level 12)
+                } else {
+                    uint32_t* const arr = kind < 2 ? pts : rc;
+                    if (active) g1j29_add_quad<SumqLayout14>(arr + dst * CV::WORDS, arr + src * CV::WORDS, arr + dst * CV::WORDS, qs, r, tid & 63);
+                    __syncthreads();
+                }
+                continue;
+            }
+        }
+        uint32_t* const arr = kind < 2 ? pts : rc;
         Pt x = CV::identity(), y = CV::identity();
         if (active) {
             x = CV::lds_load(arr, dst);
@@ -662,11 +842,21 @@ __global__ __launch_bounds__(256, KZG_MSM_OCC) void k_msm_window(MsmDesc d) {
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        Pt r = CV::lds_load(rc, 0);  // sum hi * R_hi
+    if constexpr (CV::QUADS) {
+        // rc[0] = sum hi (16 R_hi), rc[16] = sum lo C_lo: one more addition, then a lane per coordinate for the way out
+        if (tid < 4) g1j29_add_quad<SumqLayout14>(rc, rc + 16 * CV::WORDS, rc, msm_dyn_lds, tid, tid);
+        if (tid < 3) {  // (same wavefront as the quad: its LDS instructions execute in order)
+            const Fp c = fp29_to_std(SumqLayout14::ld(rc, tid));
+            G1Jac& o = d.window_sums[wi];
+            *(tid == 0 ? &o.x : tid == 1 ? &o.y : &o.z) = c;
+        }
+    } else {
+        if (tid == 0) {
+            Pt r = CV::lds_load(rc, 0);  // sum hi * R_hi
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) r = CV::dbl(r);
-        d.window_sums[wi] = CV::to_std(CV::add(r, CV::lds_load(rc, 16)));
+            for (int k = 0; k < 4; k++) r = CV::dbl(r);
+            d.window_sums[wi] = CV::to_std(CV::add(r, CV::lds_load(rc, 16)));
+        }
     }
 }
 
@@ -676,9 +866,13 @@ inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, 
     const size_t layer = (size_t)gx * gy * 256 * CV::WORDS * 4;
     unsigned per = (unsigned)std::min<size_t>(gz, std::max<size_t>(1, save_bytes / layer));
     d.save = save;
+    if (CV::QUADS) {  // static + dynamic LDS pass 64 KB
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_window<CV, LDSSORT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_QUADS_LDS_BYTES);
+        (void)attr;
+    }
     for (unsigned z = 0; z < gz; z += per) {
         d.z0 = (int)z;
-        hipLaunchKernelGGL((k_msm_window<CV, LDSSORT>), dim3(gx, gy, std::min(per, gz - z)), dim3(256), 0, st, d);
+        hipLaunchKernelGGL((k_msm_window<CV, LDSSORT>), dim3(gx, gy, std::min(per, gz - z)), dim3(256), CV::QUADS ? MSM_QUADS_LDS_BYTES : 0, st, d);
     }
 }
 constexpr size_t msm_save_layer_bytes(unsigned gx, unsigned gy, int words) { return (size_t)gx * gy * 256 * words * 4; }
@@ -732,120 +926,6 @@ __global__ __launch_bounds__(64) void k_msm_combine(const G1Jac* __restrict__ wi
     out[o] = acc;
 }
 
-// ---- the sum of a small batch's window sums with FOUR LANES PER ADDITION (the latency layout: W = 1, up to 128 sums per
-// output).  A Jacobian addition is 16 products of dependency depth 5; on one lane of a wavefront that is alone on its SIMD
-// it takes ~15 us, and the fold over the slices and the tree over the chunks were 7 of them in a row (k_msm_fold_slices +
-// k_msm_combine: 0.2 ms of a 5 ms batch).  Here the quad (lanes 4q .. 4q + 3) runs one addition as five ROUNDS of one
-// product per lane; a round's results go through three 16-word LDS slots per lane (same wavefront: the LDS executes its
-// instructions in order, no barrier inside an addition) and the next round's operands are read back by per-lane address:
-//     round 1   Z1Z1 = Z1^2        Z2Z2 = Z2^2        Y1Z2 = Y1 Z2         Y2Z1 = Y2 Z1
-//     round 2   U1 = X1 Z2Z2       U2 = X2 Z1Z1       S1 = Y1Z2 Z2Z2       S2 = Y2Z1 Z1Z1
-//               H = U2 - U1 (lanes 0, 1)              R = S2 - S1 (lanes 2, 3)
-//     round 3   HH = H^2           Z1H = Z1 H         RR = R^2             (RR again)
-//     round 4   HHH = H HH         Z3 = Z1H Z2        V = U1 HH            (V again)
-//               X3 = RR - HHH - 2V (lane 2)
-//     round 5   T = S1 HHH         -                  R (V - X3)           -
-//               Y3 = R (V - X3) - T (lane 2)
-// (the formulas and bounds of g1j29_add, g1_29_formulas.hpp).  An identity operand or equal x (P + P, P - P) shows in
-// Z1Z1, Z2Z2, HH; such a quad lets its lane 0 run the complete g1j29_add afterwards.
-constexpr int SUMQ_POINT_WORDS = 48;   // X | Y | Z, 16 words each (14 limbs + 2 of padding: ds_*_b128)
-constexpr int SUMQ_SCRATCH_WORDS = 192;  // per quad: 4 lanes x 3 slots x 16 words
-constexpr int SUMQ_MAX_POINTS = 128;
-__device__ __forceinline__ Fp29 sumq_load(const uint32_t* w) {
-    const uint4* q = reinterpret_cast<const uint4*>(w);
-    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
-    Fp29 r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
-    r.l[12] = d.x; r.l[13] = d.y;
-    return r;
-}
-__device__ __forceinline__ void sumq_store(uint32_t* w, const Fp29& v) {
-    uint4* q = reinterpret_cast<uint4*>(w);
-    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
-    q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
-    q[3] = make_uint4(v.l[12], v.l[13], 0u, 0u);
-}
-// P <- P + Q (points at P and Q, scr: the quad's scratch, r = lane & 3).  All four lanes of the quad call this together.
-__device__ __forceinline__ void g1j29_add_quad(uint32_t* P, const uint32_t* Q, uint32_t* scr, int r, int lane) {
-    auto slot = [&](int ln, int which) { return scr + ln * 48 + which * 16; };
-    const bool r0 = r == 0, r1 = r == 1, r2 = r == 2;
-    // round 1
-    const Fp29 a1 = sumq_load(r0 ? P + 32 : r1 ? Q + 32 : r2 ? P + 16 : Q + 16);
-    const Fp29 b1 = sumq_load((r1 || r2) ? Q + 32 : P + 32);
-    const Fp29 t1 = fp29_mul(a1, b1);
-    const unsigned long long zb1 = __ballot(fp29_is_zero_mod_p(t1));
-    sumq_store(slot(r, 0), t1);
-    // round 2
-    const Fp29 x2 = sumq_load(r0 ? P : Q);  // (only lanes 0, 1 use it)
-    Fp29 a2;
-#pragma unroll
-    for (int i = 0; i < 14; i++) a2.l[i] = r < 2 ? x2.l[i] : t1.l[i];
-    const Fp29 b2 = sumq_load(slot((r & 1) ? 0 : 1, 0));  // Z2Z2 for lanes 0, 2; Z1Z1 for lanes 1, 3
-    const Fp29 t2 = fp29_mul(a2, b2);
-    sumq_store(slot(r, 1), t2);
-    const Fp29 o2 = sumq_load(slot(r ^ 1, 1));
-    Fp29 hi, lo;
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        hi.l[i] = (r & 1) ? t2.l[i] : o2.l[i];
-        lo.l[i] = (r & 1) ? o2.l[i] : t2.l[i];
-    }
-    const Fp29 D = fp29_sub<2>(hi, lo);  // H on lanes 0, 1; R on lanes 2, 3; below 6p
-    // round 3
-    const Fp29 z1 = sumq_load(P + 32);
-    Fp29 b3;
-#pragma unroll
-    for (int i = 0; i < 14; i++) b3.l[i] = r1 ? z1.l[i] : D.l[i];
-    const Fp29 t3 = fp29_mul(D, b3);  // HH | Z1 H | RR | RR
-    const unsigned long long zb3 = __ballot(fp29_is_zero_mod_p(t3));
-    sumq_store(slot(r, 0), t3);  // (every lane has read its round-2 operand from slot 0 by now)
-    // round 4
-    const Fp29 u1 = sumq_load(slot(0, 1)), hh = sumq_load(slot(0, 0)), z2 = sumq_load(Q + 32);
-    Fp29 a4, b4;
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        a4.l[i] = r0 ? D.l[i] : r1 ? t3.l[i] : u1.l[i];
-        b4.l[i] = r0 ? t3.l[i] : r1 ? z2.l[i] : hh.l[i];
-    }
-    const Fp29 t4 = fp29_mul(a4, b4);  // HHH | Z3 | V | V
-    sumq_store(slot(r, 2), t4);
-    const Fp29 hhh = sumq_load(slot(0, 2));
-    const Fp29 X3 = fp29_sub<3>(fp29_sub<2>(t3, hhh), fp29_dbl(t4));  // lanes 2, 3: RR + 4p - HHH + 8p - 2V < 14p
-    // round 5
-    const Fp29 s1 = sumq_load(slot(2, 1));
-    const Fp29 vx = fp29_sub<5>(t4, X3);
-    Fp29 a5, b5;
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        a5.l[i] = r0 ? s1.l[i] : D.l[i];
-        b5.l[i] = r0 ? t4.l[i] : vx.l[i];
-    }
-    const Fp29 t5 = fp29_mul(a5, b5);  // T | - | R (V - X3) | -
-    sumq_store(slot(r, 0), t5);
-    const Fp29 T = sumq_load(slot(0, 0));
-    const Fp29 Y3 = fp29_sub<2>(t5, T);  // lane 2: below 6p
-    // the quad's flags: bit 0 Z1Z1 = 0, bit 1 Z2Z2 = 0 (round 1); bit 0 HH = 0 (round 3)
-    const int q0 = lane & ~3;
-    const bool special = (((zb1 >> q0) & 3ull) != 0) || (((zb3 >> q0) & 1ull) != 0);
-    if (!special) {
-        if (r2) {
-            sumq_store(P, X3);
-            sumq_store(P + 16, Y3);
-        }
-        if (r1) sumq_store(P + 32, t4);
-    } else if (r0) {
-        G1Jac29 p, q;
-        p.x = sumq_load(P); p.y = sumq_load(P + 16); p.z = sumq_load(P + 32);
-        q.x = sumq_load(Q); q.y = sumq_load(Q + 16); q.z = sumq_load(Q + 32);
-        const G1Jac29 s = g1j29_add(p, q);
-        sumq_store(P, s.x);
-        sumq_store(P + 16, s.y);
-        sumq_store(P + 32, s.z);
-    }
-}
 // out[o] = the sum of the npts points sums[o * npts ..]; npts a power of two, 2 <= npts <= 128; one 256-thread workgroup
 // per output; dynamic LDS: SUMQ_MAX_POINTS points + 64 quad scratches = 72 KB
 constexpr size_t SUMQ_LDS_BYTES = 4 * (SUMQ_MAX_POINTS * SUMQ_POINT_WORDS + 64 * SUMQ_SCRATCH_WORDS);
@@ -863,7 +943,8 @@ __global__ __launch_bounds__(256) void k_msm_sum_quads(const G1Jac* __restrict__
     __syncthreads();
     const int q = tid >> 2, r = tid & 3;
     for (int half = npts >> 1; half >= 1; half >>= 1) {
-        if (q < half) g1j29_add_quad(pts + q * SUMQ_POINT_WORDS, pts + (q + half) * SUMQ_POINT_WORDS, scr + q * SUMQ_SCRATCH_WORDS, r, lane);
+        if (q < half)
+            g1j29_add_quad<SumqLayout16>(pts + q * SUMQ_POINT_WORDS, pts + (q + half) * SUMQ_POINT_WORDS, pts + q * SUMQ_POINT_WORDS, scr + q * SUMQ_SCRATCH_WORDS, r, lane);
         __syncthreads();
     }
     if (tid < 3) {  // one coordinate each
