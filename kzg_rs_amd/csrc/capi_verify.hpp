@@ -262,7 +262,8 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
     const int np = (int)(2 * T + 1);
     unsigned blocks = (unsigned)((2 * T + 63) / 64);
     static const bool no_latency_layout = getenv("KZG_MSM_LATENCY_LAYOUT") && getenv("KZG_MSM_LATENCY_LAYOUT")[0] == '0';
-    w.chunks = (T <= LATENCY_MAX_BLOBS && !no_latency_layout) ? (behind_sha ? MSM_CHUNKS_LATENCY : MSM_CHUNKS_PROOFS) : MSM_CHUNKS;
+    static const bool proofs_16 = getenv("KZG_PROOFS_CHUNKS") && atoi(getenv("KZG_PROOFS_CHUNKS")) == 16;  // (A/B measurement)
+    w.chunks = (T <= LATENCY_MAX_BLOBS && !no_latency_layout) ? ((behind_sha || !proofs_16) ? MSM_CHUNKS_LATENCY : MSM_CHUNKS_PROOFS) : MSM_CHUNKS;
     const uint8_t *c = (const uint8_t*)d_commitments, *p = (const uint8_t*)d_proofs;
     const int n2 = (int)(2 * T);
     const size_t gen_off = w.chunks == MSM_CHUNKS ? 0 : w.chunks == MSM_CHUNKS_LATENCY ? MSM_CHUNKS : MSM_CHUNKS + MSM_CHUNKS_LATENCY;

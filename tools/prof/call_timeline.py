@@ -12,7 +12,13 @@ if sys.argv[1] == "run":
     import torch
     from kzg_rs_amd import api, synth
     from kzg_rs_amd.api import Bytes32, Bytes48, KzgProof
-    if sys.argv[2] == "proof":
+    if sys.argv[2].startswith("proofs"):  # proofsN: verify_kzg_proof_batch over N tuples
+        n = int(sys.argv[2][6:])
+        cs, zs, ys, ps, st = synth.make_valid_proofs(n, seed=9)
+        for _ in range(4):
+            time.sleep(0.005)
+            assert KzgProof.verify_kzg_proof_batch([Bytes48(c) for c in cs], [Bytes32(z) for z in zs], [Bytes32(y) for y in ys], [Bytes48(p) for p in ps], st)
+    elif sys.argv[2] == "proof":
         cs, zs, ys, ps, st = synth.make_valid_proofs(4, seed=9)
         for _ in range(4):
             time.sleep(0.005)
