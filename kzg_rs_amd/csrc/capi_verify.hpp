@@ -813,12 +813,9 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
         uint8_t* h_cp = w.h_buf + 72 * n;
         memcpy(h_cp, commitments, 48 * n);
         memcpy(h_cp + 48 * n, proofs, 48 * n);
-        HIPCHK(hipEventRecord(s->ev[11], s->s1));
-        HIPCHK(hipStreamWaitEvent(s->s2, s->ev[11], 0));  // the previous call's readers of the tables
+        s->s2 = s->s1;  // nothing runs beside the decode here: one stream, no event between the kernels (select_streams resets the pair)
         if ((rc = launch_decode(s, h_cp, h_cp + 48 * n, n, /*behind_sha=*/false)) != KZG_OK) return rc;
-        HIPCHK(hipEventRecord(s->ev[11], s->s2));
-        HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * n, hipMemcpyDeviceToHost, s->s2));
-        HIPCHK(hipStreamWaitEvent(s->s1, s->ev[11], 0));
+        HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * n, hipMemcpyDeviceToHost, s->s1));
     } else {
         HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
         HIPCHK(hipMemcpyAsync(w.d_stage_cp + 48 * n, proofs, 48 * n, hipMemcpyHostToDevice, s->s1));
@@ -835,8 +832,7 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
     if ((rc = phase2_launch_locked(records.data(), n, 0, s, 0, nullptr, false)) != KZG_OK) return rc;
     if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;
     if ((rc = finish_wait_locked(ok, s)) != KZG_OK) return rc;
-    if (chained) {
-        HIPCHK(hipStreamSynchronize(s->s2));  // (the flags landed long ago)
+    if (chained) {  // (finish_wait_locked has waited for the stream the flags were copied on)
         for (size_t i = 0; i < 2 * n; i++)
             if (h_pflag[i] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
     }
