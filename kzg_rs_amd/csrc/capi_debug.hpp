@@ -77,6 +77,15 @@ extern "C" KzgRet kzg_debug_msm_sum_quads(uint8_t out[144], const uint8_t* point
     return KZG_OK;
 }
 
+// diagnostic: placement and duration of the first wavefront of the last latency-layout decode kernel (g_decode_dbg)
+extern "C" KzgRet kzg_debug_decode_placement(unsigned long long out[4], const KzgSettings* s) {
+    if (!s || !out) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_decode_dbg), 32));
+    return KZG_OK;
+}
+
 extern "C" KzgRet kzg_last_timings(const KzgSettings* s, float out_ms[8]) {
     if (!s || !out_ms) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);

@@ -160,6 +160,9 @@ __global__ __launch_bounds__(64, 2) void k_g1_decode_multiples(const uint8_t* __
     pflag[i] = st;
 }
 
+// diagnostic (tools/prof/decode_placement.py): where the first wavefront of the last latency decode ran, and for how long
+__device__ unsigned long long g_decode_dbg[4];  // HW_ID | XCC_ID | shader cycles | wall-clock ticks (100 MHz)
+
 #ifndef KZG_DECODE_OCC
 #define KZG_DECODE_OCC 2
 #endif
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(256, KZG_DECODE_OCC) void k_g1_decode_multiples29(c
     const LdsPark pk = lds_park(park4 + threadIdx.x, blockDim.x);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_t0 = wall_clock64();
     const uint8_t* src = i < n0 ? bytes0 + (size_t)i * 48 : bytes1 + (size_t)(i - n0) * 48;
     Fp29 x, y;
     uint32_t st = g1_decompress29(x, y, src, pk);
@@ -219,6 +223,12 @@ __global__ __launch_bounds__(256, KZG_DECODE_OCC) void k_g1_decode_multiples29(c
     }
     points[i] = a;
     pflag[i] = st;
+    if (!AFF && i == 0) {
+        g_decode_dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_decode_dbg[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        g_decode_dbg[2] = __builtin_readcyclecounter() - dbg_c0;
+        g_decode_dbg[3] = wall_clock64() - dbg_t0;
+    }
 }
 
 // jtmp[i] = 2^64 P_i (Jacobian) -> table rows 1 and 3 of the affine layout: (X / Z^2, Y / Z^3) and its -phi image.

@@ -17,7 +17,7 @@ d_c = torch.frombuffer(bytearray(g * n), dtype=torch.uint8).cuda()
 d_p = d_c.clone()
 torch.cuda.synchronize()
 ts = []
-for _ in range(6):
+for _ in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
     try:
         api.KzgProof.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, st)
     except api.KzgError:
