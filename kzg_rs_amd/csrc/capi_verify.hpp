@@ -25,8 +25,10 @@ static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const F
     // A launch that leaves CUs free asks for enough (unused) dynamic LDS that no CU takes a second workgroup: the dispatcher
     // otherwise pairs workgroups on half the CUs, two wavefronts per SIMD, and the single batch waits twice as long.
     const unsigned eval_blocks = (unsigned)((T + EVAL_BLOBS_PER_BLOCK - 1) / EVAL_BLOBS_PER_BLOCK);
-    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate), hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_SPREAD_LDS) == hipSuccess;
-    const size_t spread_lds = lds_ok && eval_blocks <= (unsigned)s->n_cus ? EVAL_SPREAD_LDS : 0;
+    size_t spread_lds = 0;
+    if (eval_blocks <= (unsigned)s->n_cus &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate), hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_SPREAD_LDS) == hipSuccess)
+        spread_lds = EVAL_SPREAD_LDS;
     hipLaunchKernelGGL(k_blob_evaluate, dim3(eval_blocks), dim3(64 * EVAL_BLOBS_PER_BLOCK), spread_lds, s->s1,
                        (const uint8_t*)d_blobs, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, s->d_eval_scratch, d_status, (int)T);
     hipLaunchKernelGGL(k_eval_finish, dim3(per_lane), dim3(64), 0, s->s1, s->d_eval_scratch, d_y, (int)T);
@@ -233,12 +235,9 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     }
     // the latency layout (one window per chunk) of a few batches: every output is the plain sum of its slots x slices window
     // sums - one workgroup per output, four lanes per addition (KZG_MSM_SUM_QUADS=0: the fold + combine kernels, A/B)
-    static const bool sum_quads = [] {
-        const char* e = getenv("KZG_MSM_SUM_QUADS");
-        if (e && e[0] == '0') return false;
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_sum_quads), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SUMQ_LDS_BYTES) == hipSuccess;
-    }();
+    static const bool sum_quads = !(getenv("KZG_MSM_SUM_QUADS") && getenv("KZG_MSM_SUM_QUADS")[0] == '0');
     if (sum_quads && W == 1 && fp29_enabled() && slots * S >= 2 && slots * S <= (unsigned)SUMQ_MAX_POINTS && 2 * B < 64) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_sum_quads), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SUMQ_LDS_BYTES));
         hipLaunchKernelGGL(k_msm_sum_quads, dim3((unsigned)(2 * B)), dim3(256), SUMQ_LDS_BYTES, s->s1, d.window_sums, w.d_ab, (int)(slots * S));
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s->ev[3], s->s1));

@@ -876,10 +876,8 @@ inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, 
     const size_t layer = (size_t)gx * gy * 256 * CV::WORDS * 4;
     unsigned per = (unsigned)std::min<size_t>(gz, std::max<size_t>(1, save_bytes / layer));
     d.save = save;
-    if (CV::QUADS) {  // static + dynamic LDS pass 64 KB
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_window<CV, LDSSORT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_QUADS_LDS_BYTES);
-        (void)attr;
-    }
+    if (CV::QUADS)  // static + dynamic LDS pass 64 KB (set per call: the attribute belongs to the current device's copy of the kernel)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_window<CV, LDSSORT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_QUADS_LDS_BYTES);
     for (unsigned z = 0; z < gz; z += per) {
         d.z0 = (int)z;
         hipLaunchKernelGGL((k_msm_window<CV, LDSSORT>), dim3(gx, gy, std::min(per, gz - z)), dim3(256), CV::QUADS ? MSM_QUADS_LDS_BYTES : 0, st, d);
