@@ -597,7 +597,8 @@ struct Curve29 {
 struct Curve29Quads : Curve29 {
     static constexpr bool QUADS = true;
 };
-constexpr size_t MSM_QUADS_LDS_BYTES = 4 * (64 * SUMQ_SCRATCH_WORDS + 32 * Curve29::WORDS);
+constexpr size_t MSM_QUADS_LDS_BYTES = 4 * (64 * SUMQ_SCRATCH_WORDS + 32 * Curve29::WORDS + 64 * Curve29::WORDS);  // quad scratch | R, C | staged table rows
+constexpr uint32_t MSM_QUADS_BUCKET_CAP = 4;  // entries of a bucket that its own thread adds (the first is a copy)
 
 // Curve29 with AFFINE table entries (k_mult_to_affine29): bucket accumulation by mixed additions
 struct Curve29Aff : Curve29 {
@@ -642,11 +643,14 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     const uint32_t* tsc = d.term_scalar + (size_t)bo * d.max_terms + t0;
     // scratch of this block: the (window, chunk group) region of its output, then the slice's share of it
     __shared__ uint32_t cnt[MSM_BUCKETS], off[MSM_BUCKETS + 1], cur[MSM_BUCKETS];
+    __shared__ uint32_t long_buckets[MSM_BUCKETS], n_long;  // (CV::QUADS) buckets with more than MSM_QUADS_BUCKET_CAP entries
+    extern __shared__ __attribute__((aligned(16))) uint32_t msm_dyn_lds[];  // (CV::QUADS) quad scratch | second R | C vector
     __shared__ uint32_t pts[MSM_BUCKETS * CV::WORDS];  // 36 / 42 KiB: one Jacobian point per thread
     uint32_t* const sorted_global = d.sorted + ((size_t)(bo * gridDim.y + blockIdx.y) * W + w) * cpb * d.max_terms + (size_t)cpb * t0;
     // (compile-time choice: an LDS pointer or a global one, never a flat one)
     cnt[tid] = 0;
     cur[tid] = 0;
+    if (tid == 0) n_long = 0;
     __syncthreads();
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(d.scalars);
     // 1. counting sort by digit of the cpb * nt (chunk, term) pairs; entry = chunk << 27 | point index (32 chunks at most, 2^27 points)
@@ -708,7 +712,10 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
         // bucket's own list and the loop below, outside the hot one, takes care of it.  (Inlined, the complete formula's
         // five exits kept the accumulator in scratch memory: 112 bytes loaded and stored per addition.)
         uint32_t k = bucket > 0 ? off[bucket] : 0u, w = k;
-        const uint32_t kend = bucket > 0 ? off[bucket + 1] : 0u;
+        const uint32_t kend_all = bucket > 0 ? off[bucket + 1] : 0u;
+        // (CV::QUADS) a thread takes the first MSM_QUADS_BUCKET_CAP entries of its bucket; what a long bucket has beyond them
+        // is added afterwards by a quad per bucket, while the short buckets' threads would only wait
+        const uint32_t kend = (CV::QUADS && kend_all - k > MSM_QUADS_BUCKET_CAP) ? k + MSM_QUADS_BUCKET_CAP : kend_all;
         if (k < kend) {  // the first entry of a bucket is a copy, not an addition to the identity
             const uint32_t e = sorted_at(k++);
             acc = CV::from_entry(CV::load(mult[(size_t)(e >> MSM_ENTRY_CHUNK_SHIFT) * d.stride + (e & MSM_ENTRY_POINT_MASK)]));
@@ -725,6 +732,13 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
         for (uint32_t j = first; j < w; j++) {  // rare
             const uint32_t e = sorted_at(j);
             acc = CV::add_entry(acc, CV::load(mult[(size_t)(e >> MSM_ENTRY_CHUNK_SHIFT) * d.stride + (e & MSM_ENTRY_POINT_MASK)]));
+        }
+        if constexpr (CV::QUADS) {
+            if (kend < kend_all) {
+                if constexpr (LDSSORT)  // the list's LDS region is about to become the bucket points: the rest of it to the global copy
+                    for (uint32_t j = kend; j < kend_all; j++) sorted_global[j] = pts[j];
+                long_buckets[atomicAdd(&n_long, 1u)] = (uint32_t)bucket;
+            }
         }
     } else if (bucket > 0) {
         for (uint32_t k = off[bucket]; k < off[bucket + 1]; k++) {
@@ -745,6 +759,24 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     if constexpr (LDSSORT) __syncthreads();  // every list has been read: the region becomes the bucket points
     CV::lds_store(pts, bucket, acc);
     __syncthreads();
+    if constexpr (CV::QUADS) {
+        const uint32_t nl = n_long;
+        if (nl) {
+            for (uint32_t it = tid >> 2; it < nl; it += 64) {
+                const uint32_t b = long_buckets[it];
+                uint32_t* const P = pts + b * CV::WORDS;
+                for (uint32_t j = off[b] + MSM_QUADS_BUCKET_CAP; j < off[b + 1]; j++) {
+                    const uint32_t e = sorted_global[j];
+                    // the table row into the quad's staging slot (lanes 0..2: one coordinate each), then an LDS-to-LDS addition
+                    uint32_t* const Qs = msm_dyn_lds + 64 * SUMQ_SCRATCH_WORDS + 32 * CV::WORDS + (tid >> 2) * CV::WORDS;
+                    const typename CV::Mem& row = mult[(size_t)(e >> MSM_ENTRY_CHUNK_SHIFT) * d.stride + (e & MSM_ENTRY_POINT_MASK)];
+                    if ((tid & 3) < 3) SumqLayout14::st(Qs, tid & 3, fp29_load((tid & 3) == 0 ? row.x : (tid & 3) == 1 ? row.y : row.z));
+                    g1j29_add_quad<SumqLayout14>(P, Qs, P, msm_dyn_lds + (tid >> 2) * SUMQ_SCRATCH_WORDS, tid & 3, tid & 63);
+                }
+            }
+            __syncthreads();
+        }
+    }
     // From here on thread tid looks after bucket tid.  The row trees run in place and destroy the bucket sums the column
     // trees need: a copy waits in global memory (d.save; word-major, so a wavefront writes and reads whole lines).
     // R and C get their own small LDS vectors for the scans.
@@ -752,8 +784,6 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     uint32_t* const save = d.save + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * CV::WORDS) * 256 + tid;
 #pragma unroll
     for (int i = 0; i < CV::WORDS; i++) save[(size_t)i * 256] = pts[tid * CV::WORDS + i];
-    // (CV::QUADS) quad scratch and the second R | C vector of the scan levels, in dynamic LDS
-    extern __shared__ __attribute__((aligned(16))) uint32_t msm_dyn_lds[];
     uint32_t* rc_cur = rc;
     uint32_t* rc_nxt = msm_dyn_lds + 64 * SUMQ_SCRATCH_WORDS;
 #pragma unroll 1

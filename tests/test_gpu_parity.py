@@ -204,6 +204,23 @@ def test_verify_kzg_proof_batch_synthetic(n):
     assert both(cs, z2, ys, ps) is False
 
 
+def test_verify_kzg_proof_batch_repeated_tuples():
+    """600 tuples made of 3 distinct ones: every bucket of the latency MSM holds the same few points again and again - P + P
+    and P + (a multiple of P) in the per-thread phase, and long buckets (more than MSM_QUADS_BUCKET_CAP entries) whose tail
+    goes through the quad additions (csrc/msm.hpp).  True by construction; one changed y must flip it."""
+    from kzg_rs_amd import synth
+    cs, zs, ys, ps, st = synth.make_valid_proofs(3, seed=4242)
+    idx = [i % 3 for i in range(600)]
+    wrap = lambda c, z, y, p: ([Bytes48(x) for x in c], [Bytes32(x) for x in z], [Bytes32(x) for x in y], [Bytes48(x) for x in p])
+    c, z, y, p = ([v[i] for i in idx] for v in (cs, zs, ys, ps))
+    assert KzgProof.verify_kzg_proof_batch(*wrap(c, z, y, p), st) is True
+    y2 = list(y)
+    y2[301] = ((int.from_bytes(y[301], "big") + 1) % R).to_bytes(32, "big")
+    assert KzgProof.verify_kzg_proof_batch(*wrap(c, z, y2, p), st) is False
+    # all 600 the same tuple
+    assert KzgProof.verify_kzg_proof_batch(*wrap([cs[0]] * 600, [zs[0]] * 600, [ys[0]] * 600, [ps[0]] * 600), st) is True
+
+
 def test_verify_blob_kzg_proof(settings):
     """src/kzg_proof.rs:654-680 over the 29 vectors."""
     for c in G.vectors()["verify_blob_kzg_proof"]:
