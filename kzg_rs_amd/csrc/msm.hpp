@@ -598,7 +598,7 @@ struct Curve29Quads : Curve29 {
     static constexpr bool QUADS = true;
 };
 constexpr size_t MSM_QUADS_LDS_BYTES = 4 * (64 * SUMQ_SCRATCH_WORDS + 32 * Curve29::WORDS + 64 * Curve29::WORDS);  // quad scratch | R, C | staged table rows
-constexpr uint32_t MSM_QUADS_BUCKET_CAP = 4;  // entries of a bucket that its own thread adds (the first is a copy)
+constexpr uint32_t MSM_QUADS_BUCKET_CAP = 3;  // entries of a bucket that its own thread adds (the first is a copy)
 
 // Curve29 with AFFINE table entries (k_mult_to_affine29): bucket accumulation by mixed additions
 struct Curve29Aff : Curve29 {
