@@ -282,7 +282,20 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
         // (the generator's rows first: behind the decode kernel they would sit on the critical path of a proof-tuple call)
         hipLaunchKernelGGL(k_set_generator_multiples<G1Jac29Mem>, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, mult,
                            (const G1Jac29Mem*)s->d_gen_mult + gen_off, n2, np, w.chunks);
-        if (w.chunks == MSM_CHUNKS_LATENCY)
+        // the latency layouts: eight lanes per point, one wavefront of 8 points per CU (KZG_DECODE_QUADS=0: one lane, A/B)
+        static const bool dec_quads = !(getenv("KZG_DECODE_QUADS") && getenv("KZG_DECODE_QUADS")[0] == '0');
+        // (while every workgroup can have a CU to itself, and not beside the challenge chain: there the decode hides behind the
+        // chain anyway and has only half the CUs)
+        if (dec_quads && w.chunks != MSM_CHUNKS && !behind_sha && (2 * T + DECQ_POINTS_PER_BLOCK - 1) / DECQ_POINTS_PER_BLOCK <= (size_t)s->n_cus) {
+            blocks = (unsigned)((2 * T + DECQ_POINTS_PER_BLOCK - 1) / DECQ_POINTS_PER_BLOCK);
+            if (w.chunks == MSM_CHUNKS_LATENCY) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_decode_multiples29_quads<MSM_CHUNKS_LATENCY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECQ_LDS_BYTES));
+                hipLaunchKernelGGL(k_g1_decode_multiples29_quads<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), DECQ_LDS_BYTES, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
+            } else {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_decode_multiples29_quads<MSM_CHUNKS_PROOFS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECQ_LDS_BYTES));
+                hipLaunchKernelGGL(k_g1_decode_multiples29_quads<MSM_CHUNKS_PROOFS>, dim3(blocks), dim3(64), DECQ_LDS_BYTES, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
+            }
+        } else if (w.chunks == MSM_CHUNKS_LATENCY)
             hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS_LATENCY, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
         else if (w.chunks == MSM_CHUNKS_PROOFS)
             hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS_PROOFS, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);

@@ -403,7 +403,10 @@ __device__ __forceinline__ G1Jac lds_load_jac(const uint32_t* base, int slot) {
 // (the formulas and bounds of g1j29_add, g1_29_formulas.hpp).  An identity operand or equal x (P + P, P - P) shows in
 // Z1Z1, Z2Z2, HH; such a quad lets its lane 0 run the complete g1j29_add afterwards.
 constexpr int SUMQ_POINT_WORDS = 48;   // X | Y | Z, 16 words each (14 limbs + 2 of padding: ds_*_b128)
-constexpr int SUMQ_SCRATCH_WORDS = 192;  // per quad: 4 lanes x 3 slots x 16 words
+// per quad: 4 lanes x 3 slots x 16 words, the lanes 68 words apart and the quads 272: a b128 access of sixteen lanes (four
+// quads) then touches sixteen different groups of four banks (at 48 / 192 words the four quads of a pass hit the same banks)
+constexpr int SUMQ_LANE_WORDS = 68;
+constexpr int SUMQ_SCRATCH_WORDS = 4 * SUMQ_LANE_WORDS;
 constexpr int SUMQ_MAX_POINTS = 128;
 __device__ __forceinline__ Fp29 sumq_load(const uint32_t* w) {
     const uint4* q = reinterpret_cast<const uint4*>(w);
@@ -443,7 +446,7 @@ struct SumqLayout14 {  // lds_store_jac29's 42-word slots (the window kernel's b
 // this together.
 template <class LY>
 __device__ __forceinline__ void g1j29_add_quad(const uint32_t* P, const uint32_t* Q, uint32_t* OUT, uint32_t* scr, int r, int lane) {
-    auto slot = [&](int ln, int which) { return scr + ln * 48 + which * 16; };
+    auto slot = [&](int ln, int which) { return scr + ln * SUMQ_LANE_WORDS + which * 16; };
     const bool r0 = r == 0, r1 = r == 1, r2 = r == 2;
     // round 1
     const Fp29 a1 = LY::ld((r0 || r2) ? P : Q, (r0 || r1) ? 2 : 1);  // Z1 | Z2 | Y1 | Y2
@@ -519,6 +522,177 @@ __device__ __forceinline__ void g1j29_add_quad(const uint32_t* P, const uint32_t
         LY::st(OUT, 2, s.z);
     }
 }
+// OUT <- 2 P with three lanes of a quad (dbl-2009-l as in g1j29_dbl, same bounds): three rounds instead of seven products in
+// a row.   round 1: B = Y^2 | A = X^2 | YZ        round 2: C = B^2 | F = (3A)^2 | t = (X + B)^2        round 3 (lane 1):
+// E (D + 512p - X3), with D = 2 (t - A - C) + 16p, X3 = F + 128p - 2D; lane 1 writes X3, Y3 and lane 2 Z3 = 2 YZ.
+// scr: the quad's scratch (slots 0 and 1 of every lane are used).  OUT may be P.  No special cases: Z = 0 stays so.
+template <class LY>
+__device__ __forceinline__ void g1j29_dbl_quad(const uint32_t* P, uint32_t* OUT, uint32_t* scr, int r) {
+    auto slot = [&](int ln, int which) { return scr + ln * SUMQ_LANE_WORDS + which * 16; };
+    const bool r0 = r == 0, r1 = r == 1;
+    // round 1
+    const Fp29 a1 = LY::ld(P, r1 ? 0 : 1);             // Y | X | Y | Y
+    const Fp29 b1 = LY::ld(P, r0 ? 1 : r1 ? 0 : 2);    // Y | X | Z | Z
+    const Fp29 t1 = fp29_mul(a1, b1);                  // B | A | YZ | (YZ)
+    sumq_store(slot(r, 0), t1);
+    // round 2
+    const Fp29 x = LY::ld(P, 0), Bv = sumq_load(slot(0, 0));
+    Fp29 E, a2;  // E = 3A on lane 1
+#pragma unroll
+    for (int i = 0; i < 14; i++) E.l[i] = (t1.l[i] << 1) + t1.l[i];  // words < 2^31
+    E = fp29_normalize(E);                                             // < 6p
+    const Fp29 xb = fp29_add(x, Bv);
+#pragma unroll
+    for (int i = 0; i < 14; i++) a2.l[i] = r0 ? t1.l[i] : r1 ? E.l[i] : xb.l[i];
+    const Fp29 t2 = fp29_sqr(a2);                      // C | F | t | (t)
+    sumq_store(slot(r, 1), t2);
+    // lane 1: D, X3, then round 3
+    const Fp29 C = sumq_load(slot(0, 1)), t = sumq_load(slot(2, 1));
+    Fp29 D, X, C8;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        D.l[i] = ((t.l[i] - t1.l[i] - C.l[i]) << 1) + cp29::FP29_BIASX4[i];  // lane 1: t1 = A
+        C8.l[i] = C.l[i] << 3;
+    }
+    D = fp29_normalize(D);    // < 20p
+    C8 = fp29_normalize(C8);  // < 16p
+#pragma unroll
+    for (int i = 0; i < 14; i++) X.l[i] = t2.l[i] + cp29::FP29_BIASW7[i] - (D.l[i] << 1);  // lane 1: t2 = F
+    X = fp29_normalize(X);    // < 130p
+    const Fp29 Y3 = fp29_sub<5>(fp29_mul(E, fp29_sub<9>(D, X)), C8);  // < 34p
+    if (r1) {
+        LY::st(OUT, 0, X);
+        LY::st(OUT, 1, Y3);
+    }
+    if (r == 2) LY::st(OUT, 2, fp29_dbl(t1));  // < 4p
+}
+
+// The latency form of the pass (Jacobian tables; launches that leave most of the chip idle): EIGHT LANES PER POINT, two quads.
+// Lane 0 decodes (the square root is one chain of products), then quad A walks the doubling chain R = 2^k P with the point in
+// LDS - doublings in three product rounds (g1j29_dbl_quad), the additions into ACC = [|x|]P in five (g1j29_add_quad) - and
+// from k = 64 on, where the doublings that extend the multiples and the chain [|x|]ACC of the subgroup test no longer depend
+// on each other, quad B runs the second chain IN THE SAME INSTRUCTIONS as quad A's doublings (the two quads are lanes of one
+// wavefront: same code, different LDS slots).  ~500 product times on the critical path instead of ~1 450 (+ the square root).
+// 64 threads = 8 points per workgroup; dynamic LDS per point: R | ACC | R2 (48 words each) | two quad scratches | x, y (32),
+// then 18 uint4 of parking per point for the decode.
+constexpr int DECQ_POINT_WORDS = 3 * 48 + 2 * SUMQ_SCRATCH_WORDS + 32 + 16;  // (+16: consecutive points 32 banks apart)
+constexpr int DECQ_POINTS_PER_BLOCK = 8;  // ONE wavefront per workgroup, and one workgroup per CU (DECQ_LDS_BYTES is padded for
+                                          // that): the quads talk through LDS, ~30 b128 accesses of every lane per product
+                                          // round - four such wavefronts on a CU spend as long waiting for the LDS as multiplying
+constexpr size_t DECQ_LDS_USED = DECQ_POINTS_PER_BLOCK * (DECQ_POINT_WORDS * 4 + PARK_UINT4_PER_THREAD * 16);
+constexpr size_t DECQ_LDS_BYTES = 96 * 1024;
+template <int CHUNKS>
+__global__ __launch_bounds__(64, 1) void k_g1_decode_multiples29_quads(const uint8_t* __restrict__ bytes0, const uint8_t* __restrict__ bytes1, int n0,
+                                                                     G1Aff* __restrict__ points, uint32_t* __restrict__ pflag,
+                                                                     G1Jac29Mem* __restrict__ mult, int n, int stride) {
+    constexpr int HALF = CHUNKS / 2, STEP = 256 / CHUNKS;
+    static_assert(64 % STEP == 0, "a multiple is due at k = 64");
+    extern __shared__ __attribute__((aligned(16))) uint32_t decq_lds[];
+    const int lane = threadIdx.x & 63, r = threadIdx.x & 3, qb = (threadIdx.x >> 2) & 1, pt = threadIdx.x >> 3;
+    static_assert(DECQ_LDS_USED <= DECQ_LDS_BYTES, "LDS");
+    const int i = blockIdx.x * DECQ_POINTS_PER_BLOCK + pt;
+    if (i >= n) return;  // (whole groups of eight lanes; nothing below synchronises across groups)
+    uint32_t* const mine = decq_lds + pt * DECQ_POINT_WORDS;
+    uint32_t *const R = mine, *const ACC = mine + 48, *const R2 = mine + 96, *const scr = mine + 144 + qb * SUMQ_SCRATCH_WORDS;
+    uint32_t* const XY = mine + 144 + 2 * SUMQ_SCRATCH_WORDS;
+    const bool first = qb == 0 && r == 0;
+    uint32_t st = G1_INVALID;
+    if (first) {
+        const LdsPark pk = lds_park(reinterpret_cast<const uint4*>(decq_lds + DECQ_POINTS_PER_BLOCK * DECQ_POINT_WORDS) + pt, DECQ_POINTS_PER_BLOCK);
+        Fp29 x, y;
+        st = g1_decompress29(x, y, i < n0 ? bytes0 + (size_t)i * 48 : bytes1 + (size_t)(i - n0) * 48, pk);
+        if (st == G1_OK) {
+            sumq_store(XY, x);
+            sumq_store(XY + 16, y);
+            sumq_store(R, x);
+            sumq_store(R + 16, y);
+            sumq_store(R + 32, fp29_const(cp29::FP29_ONE));
+        }
+    }
+    st = (uint32_t)__shfl((int)st, lane & ~7, 64);
+    bool in = false;
+    if (st == G1_OK) {
+        auto emit = [&](int k) {  // (quad A) rows k and HALF + k: lane 0 the point, lane 1 its -phi image
+            if (r < 2) {
+                G1Jac29 m;
+                m.x = sumq_load(R);
+                m.y = sumq_load(R + 16);
+                m.z = sumq_load(R + 32);
+                if (r == 0) g1j29_store(mult[(size_t)k * stride + i], m);
+                else g1j29_store(mult[(size_t)(HALF + k) * stride + i], g1j29_neg_phi(m));
+            }
+        };
+        if (qb == 0) {
+            // R = 2^k P with the multiples on the way; ACC = [|x|]P accumulated right to left (the highest set bit of |x| is 63)
+            emit(0);
+#pragma unroll 1
+            for (int k = 0; k < 64; k++) {
+                if (k && k % STEP == 0) emit(k / STEP);
+                if ((BLS_X_ABS >> k) & 1) {
+                    if (k == 16) {  // the lowest set bit
+                        if (r < 3) sumq_store(ACC + 16 * r, sumq_load(R + 16 * r));
+                    } else {
+                        g1j29_add_quad<SumqLayout16>(ACC, R, ACC, scr, r, lane);
+                    }
+                }
+                g1j29_dbl_quad<SumqLayout16>(R, R, scr, r);
+            }
+        } else if (r < 3) {
+            // (quad B waits - its lanes are masked off while quad A runs - and then starts [|x|]ACC from ACC)
+        }
+        if (qb == 1 && r < 3) sumq_store(R2 + 16 * r, sumq_load(ACC + 16 * r));
+        // k = 64 + j on quad A (emit, double until the last multiple is out), bit 62 - j of |x| on quad B (double, add ACC)
+        bool a_done = false;
+#pragma unroll 1
+        for (int j = 0; j < 63; j++) {
+            const int k = 64 + j;
+            if (qb == 0 && !a_done) {
+                if (k % STEP == 0) {
+                    emit(k / STEP);
+                    if (k + STEP >= 128) a_done = true;
+                }
+            }
+            if (qb == 1 || !a_done) g1j29_dbl_quad<SumqLayout16>(qb ? R2 : R, qb ? R2 : R, scr, r);
+            if (qb == 1 && ((BLS_X_ABS >> (62 - j)) & 1)) g1j29_add_quad<SumqLayout16>(R2, ACC, R2, scr, r, lane);
+        }
+        // phi(P) == -R2  <=>  X = beta x Z^2  and  Y + y Z^3 = 0 (as in g1j29_in_subgroup_with_multiples)
+        if (qb == 1 && r == 0) {
+            const Fp29 qx = sumq_load(R2), qy = sumq_load(R2 + 16), qz = sumq_load(R2 + 32);
+            const Fp29 zz = fp29_sqr(qz);
+            if (!fp29_is_zero_mod_p(zz)) {
+                const Fp29 xx = sumq_load(XY), yy = sumq_load(XY + 16);
+                const Fp29 zzz = fp29_mul(zz, qz), one = fp29_const(cp29::FP29_ONE);
+                const Fp29 bx = fp29_mul(xx, fp29_const(cp29::FP29_BETA_MONT));
+                const Fp29 dx = fp29_mul(fp29_sub<2>(qx, fp29_mul(bx, zz)), one);
+                const Fp29 dy = fp29_mul(fp29_add(qy, fp29_mul(yy, zzz)), one);
+                in = fp29_is_zero_mod_p(dx) && fp29_is_zero_mod_p(dy);
+            }
+        }
+    }
+    if (!(qb == 1 && r == 0)) return;  // the lane that ran the test writes the verdict
+    G1Aff a;
+    a.x = FpF::zero();
+    a.y = FpF::zero();
+    if (st == G1_OK) {
+        if (in) {
+            a.x = fp29_to_std(sumq_load(XY));
+            a.y = fp29_to_std(sumq_load(XY + 16));
+        } else {
+            st = G1_INVALID;
+        }
+    }
+    if (st != G1_OK) {  // (quad A's row stores of this point have been issued by the same wavefront before these)
+        const G1Jac29 id = g1j29_identity();
+        for (int k = 0; k < CHUNKS; k++) g1j29_store(mult[(size_t)k * stride + i], id);
+    }
+    points[i] = a;
+    pflag[i] = st;
+    if (i == 0) {
+        g_decode_dbg[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        g_decode_dbg[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    }
+}
+
 // grid (W windows per chunk, chunks / chunks_per_block, 2 outputs x batches), 256 threads: block (w, g, o) handles digit
 // byte W j + w of every scalar of output o for its chunks j, against the table of chunk j (W = 32 / chunks).
 __device__ __forceinline__ void lds_store_jac29(uint32_t* base, int slot, const G1Jac29& p) {
