@@ -19,6 +19,15 @@ is hashed once (the batches of a step are dealt to the ranks), r travels as 32 b
 all-gather of 288-byte partial sums folded on every rank (kzg_rs_amd/distributed.py).  `--workload configs1` keeps
 1 024 blobs per GPU and batch at any N; `--workload config5` (= `--config5`) runs the 32 768-blob shard shape on one GPU.
 Rank 0 prints ONE JSON line.
+
+`python3 bench.py --gpus N` from a bare command (no WORLD_SIZE in the environment) starts the N ranks itself, as child
+processes, BEFORE anything in this process has touched the GPU, and exits with their worst return code.
+
+Also in the line: `self_check` (one control group of the full shape with a corrupted proof in one batch and a non-canonical
+field element in another - the benchmarked kernels must say false / Err for exactly those), `roofline.standalone_ms`
+(the dominant kernel alone on the chip: one launch group on a single-stream handle, nothing else in flight), `path`
+(whole-path algorithmic bandwidth and the HBM traffic ratio), `verify_kzg_proof_ms`, and at N > 1 `multi_gpu.single_process`
+(ONE process driving all N GPUs through a multi-device settings handle and the unchanged entry point, in-process RCCL).
 """
 import argparse
 import json
@@ -43,7 +52,8 @@ ALG_BYTES = {
 PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge", "k_blob_evaluate": "kzg::k_blob_evaluate",
             "k_g1_decode_multiples": "kzg::k_g1_decode_multiples29<4, true>", "k_msm": "kzg::k_msm_window<kzg::Curve29Aff, true>",
             "k_slp_run(pairing)": "kzg::k_slp_run<false>"}
-PMC_FILES = ("r2_pmc.json",)  # newest first; the first that exists is used (kernel names must match PMC_NAME)
+PMC_FILES = ("r3_pmc.json", "r2_pmc.json")  # newest first; the first that exists is used (kernel names must match PMC_NAME)
+PATH_ALG_BYTES = BYTES_PER_BLOB + 48 + 48 + 64   # full verify, per blob: blob + commitment + proof read, z and y written
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
 
 
@@ -81,6 +91,90 @@ def load_pmc():
     return None, None
 
 
+def spawn_ranks(n):
+    """`python3 bench.py --gpus N` without a launcher: N fresh child processes, one rank each, started before this
+    process has imported torch or made any GPU call (never re-exec a process that touched the GPU); rank 0's stdout is
+    ours.  Returns the worst child return code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KZG_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    return max(abs(rc) for rc in rcs)
+
+
+def single_process_leg(spec, n, steps, warmup):
+    """`--single-process-devices 0,1,...`: ONE process, ONE settings handle over the listed devices (include/kzg_rs_amd.h:
+    kzg_settings_from_tau_g2_devices), one batch of n blobs PER DEVICE already resident there, verified through
+    kzg_verify_blob_kzg_proof_batch_sharded - BASELINE configs[4] behind the reference's call shape (one call, one bool).
+    Prints one JSON object."""
+    import ctypes as C
+
+    import torch
+
+    from kzg_rs_amd import api, synth
+
+    devs = [int(x) for x in spec.split(",")]
+    torch.cuda.set_device(devs[0])
+    blobs, cs, ps, st0 = synth.make_valid_batch(n, seed=77, chunk=1024)
+    st = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1], devices=devs)
+    hc, hp = b"".join(cs), b"".join(ps)
+    bad = bytearray(hp)
+    bad[48 * (n - 1): 48 * n] = ps[0] if n > 1 else cs[0]   # a valid G1 point, but not this blob's proof
+    shards, shards_bad, keep = [], [], []
+    src = torch.from_numpy(blobs)
+    for k, d in enumerate(devs):
+        dev = torch.device("cuda", d)
+        t = (src.to(dev), torch.frombuffer(bytearray(hc), dtype=torch.uint8).to(dev), torch.frombuffer(bytearray(hp), dtype=torch.uint8).to(dev),
+             torch.frombuffer(bad, dtype=torch.uint8).to(dev))
+        keep.append(t)
+        shards.append((t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n))
+        shards_bad.append((t[0].data_ptr(), t[1].data_ptr(), (t[3] if k == len(devs) - 1 else t[2]).data_ptr(), n))
+    for d in devs:
+        torch.cuda.synchronize(d)
+    for _ in range(max(warmup, 1)):
+        assert api.verify_blob_kzg_proof_batch_sharded(shards, st) is True
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ok = api.verify_blob_kzg_proof_batch_sharded(shards, st)
+    dt = (time.perf_counter() - t0) / steps
+    stages = st.multi_last_timings()
+    neg = api.verify_blob_kzg_proof_batch_sharded(shards_bad, st)
+    # the same batch from HOST memory through the unchanged kzg_verify_blob_kzg_proof_batch (every slice over its own PCIe link)
+    host = None
+    if n * len(devs) <= 8192:
+        hb = np_tile(blobs, len(devs))
+        okh = C.c_bool(False)
+        for _ in range(2):
+            api._chk(api.lib().kzg_verify_blob_kzg_proof_batch(C.byref(okh), hb.ctypes.data_as(C.c_char_p), hc * len(devs), hp * len(devs), n * len(devs), st._h))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            api._chk(api.lib().kzg_verify_blob_kzg_proof_batch(C.byref(okh), hb.ctypes.data_as(C.c_char_p), hc * len(devs), hp * len(devs), n * len(devs), st._h))
+        host = {"ms_per_call": round((time.perf_counter() - t0) / steps * 1e3, 4), "ok": bool(okh.value)}
+    devices, exchange = st.devices()
+    print(json.dumps({"devices": devices, "exchange": exchange, "batch": n * len(devs), "blobs_per_device": n, "steps": steps,
+                      "ms_per_call": round(dt * 1e3, 4), "value": round(n * len(devs) / dt, 2), "unit": "blobs/s", "ok": bool(ok),
+                      "corrupted_proof_on_last_device": neg,
+                      "stage_ms": {k: round(v, 4) for k, v in zip(("call", "copy_and_phase1", "transcript_hash", "phase2_launch", "exchange", "fold_and_pairing"), stages)},
+                      "host_vec_blob": host,
+                      "what": "one process, one multi-device KzgSettings handle, ONE verify_blob_kzg_proof_batch of %d blobs sharded by blob "
+                              "(%d resident per device), partial sums exchanged by %s" % (n * len(devs), n, exchange)}))
+
+
+def np_tile(blobs, k):
+    import numpy as np
+    return np.ascontiguousarray(np.broadcast_to(blobs, (k,) + blobs.shape)).reshape(k * blobs.shape[0], -1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,7 +190,20 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single_batch / end_to_end legs (profiling runs)")
+    ap.add_argument("--no-self-check", action="store_true", help="skip the poisoned control group and the stand-alone group (profiling runs)")
+    ap.add_argument("--single-process-devices", default=None, metavar="0,1,...",
+                    help="only the single-process multi-device leg: one handle over these devices, --blobs per device (default 32768)")
     args = ap.parse_args()
+
+    if args.single_process_devices:
+        return single_process_leg(args.single_process_devices, args.blobs or 32768, max(args.steps, 1) if args.steps != 20 else 5, args.warmup if args.warmup != 5 else 2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if os.environ.get("KZG_BENCH_SPAWNED"):
+            raise SystemExit("bench.py: spawned rank without WORLD_SIZE")
+        raise SystemExit(spawn_ranks(args.gpus))
+    if os.environ.get("KZG_BENCH_DRY_SPAWN") == "1":  # CPU test of the launcher: say who we are, touch nothing
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+        return
 
     import numpy as np
     import torch
@@ -280,28 +387,91 @@ def main():
                                             "(chunked copies on a copy stream overlapped with the previous chunk's verification); first_pass = the same "
                                             "call on never-touched pages" % (NB, n)}}
             del h_many
+    # ---- the kernels ALONE on the chip: one launch group on a single-stream handle, nothing else in flight.  With several
+    # groups in flight a kernel's interval is its residency (how long it shared the chip), not its cost.
+    standalone = None
+    self_check = None
+    proof_ms = None
+    if not args.no_self_check:
+        os.environ["KZG_SINGLE_STREAM"] = "1"   # read when a handle is made
+        solo = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1])
+        os.environ.pop("KZG_SINGLE_STREAM")
+        v = variants[0]
+        solo_res = None
+        for _ in range(2):  # first pass: workspace allocation
+            torch.cuda.synchronize()
+            solo_res = api.verify_blob_kzg_proof_batches_device(v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), n, G, solo)
+        st_tm = solo.last_timings()
+        standalone = {"k_blob_challenge": st_tm[5], "k_blob_evaluate": st_tm[4], "k_g1_decode_multiples": st_tm[6], "k_msm": st_tm[2],
+                      "k_slp_run(pairing)": st_tm[3], "whole_group": st_tm[0]}
+        if not all(r is True for r in solo_res):
+            raise SystemExit("verification of a valid synthetic batch returned false (stand-alone group)")
+        # ---- self check at the benchmarked shape: the same full group with two poisoned batches.  Batch `bf` gets a valid G1
+        # point that is not its blob's proof (-> false), batch `be` a field element >= r (-> Err); everything else stays true.
+        bf, be = (G // 3, (2 * G) // 3) if G >= 3 else (0, G - 1)
+        i_f, i_e = bf * n + n // 2, be * n + n - 1
+        keep_p = v[2][i_f].clone()
+        keep_e = v[0][i_e, 64:96].clone()
+        v[2][i_f] = v[2][(i_f + 1) % (n * G)]
+        v[0][i_e, 64:96] = torch.tensor(list((0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001).to_bytes(32, "big")), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        res = api.verify_blob_kzg_proof_batches_device(v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), n, G, solo)
+        v[2][i_f] = keep_p
+        v[0][i_e, 64:96] = keep_e
+        torch.cuda.synchronize()
+        false_b = [b for b, r in enumerate(res) if r is False]
+        err_b = [b for b, r in enumerate(res) if r is None]
+        want_f, want_e = ([bf], [be]) if bf != be else ([], [be])
+        self_check = {"batches": G, "blobs": n * G, "poisoned": {"wrong_proof_in_batch": bf, "non_canonical_element_in_batch": be},
+                      "false_batches": false_b, "err_batches": err_b, "true_batches": sum(1 for r in res if r is True),
+                      "passed": false_b == want_f and err_b == want_e and sum(1 for r in res if r is True) == G - len(set(want_f + want_e))}
+        solo.close()
+        if world == 1:
+            # one proof at a time (src/kzg_proof.rs:353-397, the revm precompile's call): median of 32 calls
+            pc, pz, py, pp, _ = synth.make_valid_proofs(1, seed=5, settings=settings)
+            args4 = (api.Bytes48(pc[0]), api.Bytes32(pz[0]), api.Bytes32(py[0]), api.Bytes48(pp[0]))
+            ts = []
+            for _ in range(36):
+                t0 = time.perf_counter()
+                okp = api.KzgProof.verify_kzg_proof(*args4, settings)
+                ts.append(time.perf_counter() - t0)
+            assert okp is True
+            proof_ms = round(sorted(ts[4:])[16] * 1e3, 4)
+    backend_name = dist.get_backend() if dist else None
+    if dist:
+        # every rank leaves its GPU before rank 0 reports (and, at N > 1, drives all of them from one process)
+        del variants, d_blobs
+        pipe = type("Stats", (), {"stats": dict(pipe.stats)})
+        del backends, handles, backend0, settings
+        torch.cuda.empty_cache()
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
-        if dist:
-            dist.destroy_process_group()
         return
-    # The dominant kernel.  With several launch groups in flight the event-to-event time of a kernel measures how long
-    # it SHARED the chip, not what it costs, so dominance is decided by the kernels' stand-alone cost in the newest
-    # committed PMC profile (largest VALU instruction count); if that profile does not know this build's kernels the
-    # largest live interval decides.  The duration itself is always live: measured in this run on the library's stream.
+    # The dominant kernel: the one that costs most when it has the chip to itself (stand-alone group above); without that
+    # measurement, the largest VALU instruction count in the newest committed PMC profile, then the largest live interval.
     pmc_file, pmc = load_pmc()
     prof = (pmc or {}).get("kernels", {})
-    if all(PMC_NAME[k] in prof for k in ("k_blob_challenge", "k_blob_evaluate")):
+    knames = ("k_blob_challenge", "k_blob_evaluate", "k_g1_decode_multiples", "k_msm", "k_slp_run(pairing)")
+    if standalone:
+        dom = max(knames, key=lambda k: standalone[k])
+        dom_source = "largest stand-alone duration in this run (one launch group alone on a single-stream handle)"
+    elif all(PMC_NAME[k] in prof for k in ("k_blob_challenge", "k_blob_evaluate")):
         dom = max(kernels, key=lambda k: prof.get(PMC_NAME[k], {}).get("SQ_INSTS_VALU", 0))
         dom_source = "largest SQ_INSTS_VALU in profiles/" + pmc_file
     else:
         dom = max(kernels, key=kernels.get)
         dom_source = "largest live interval (no matching PMC profile)"
     units = n * G
-    achieved = ALG_BYTES[dom] * units / (kernels[dom] * 1e-3) / 1e9 if kernels[dom] > 0 else 0.0
+    stamped = dom == "k_blob_challenge" and kernels[dom] > 0   # the throughput-form challenge kernel stamps its own interval
+    launch_ms = kernels[dom] if stamped or not standalone else standalone[dom]
+    achieved = ALG_BYTES[dom] * units / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    sa_ms = standalone[dom] if standalone else None
+    sa_achieved = ALG_BYTES[dom] * units / (sa_ms * 1e-3) / 1e9 if sa_ms else None
     # HBM traffic of that kernel and the VALU instruction counts of all kernels come from the PMC passes committed under
     # profiles/ (tools/prof/collect_round.sh; rocprofv3 --pmc cannot run inside this process).  They are per launch of
     # `blobs_per_launch` blobs there; if that differs from this run's launch size the figure is scaled and SAYS so.
-    traffic, traffic_source, valu = None, None, None
+    traffic, traffic_source, valu, path_ratio = None, None, None, None
     try:
         pk = prof.get(PMC_NAME[dom])
         if pk and "hbm_bytes_corrected" in pk:
@@ -319,8 +489,11 @@ def main():
                 "note": "VALU wave-instructions issued per SIMD cycle at the measured throughput (SQ_INSTS_VALU of every kernel of the path, profiles/"
                         + pmc_file + "); gfx950 issues the path's instruction mix at 2.4-4.3 cycles per wave-instruction "
                         "(profiles/r1_issuebench_valu_issue_cost.txt, the builder's own microbenchmark), i.e. 0.23-0.42 is the ceiling"}
+        path_bytes = sum(prof[k].get("hbm_bytes_corrected", 0) for k in path if k in prof)
+        path_ratio = round(path_bytes / (PATH_ALG_BYTES * pmc["blobs_per_launch"]), 3)
     except Exception:
         pass
+    path_gbps = PATH_ALG_BYTES * n * G * K / elapsed / 1e9   # per GPU
     out = {
         "metric": "blobs/sec verify_blob_kzg_proof_batch",
         "value": round(n * world * G * K / elapsed, 2),
@@ -341,26 +514,41 @@ def main():
                                   "BASELINE.json configs[4]" + ("" if world == 8 else " shard shape: 32 768 blobs per GPU") if n == 32768 else "custom size", G, n * G),
                    "blobs_per_gpu_per_batch": n, "batch": n * world, "batches_per_step": G, "blobs_per_step": n * world * G,
                    "parallelism": "shard-by-blob x%d" % world, "groups_in_flight": F},
-        "roofline": {"bound": "hbm", "kernel": dom, "kernel_chosen_by": dom_source, "units_per_launch": units, "launch_ms": round(kernels[dom], 4),
+        # launch_ms / achieved / frac: the kernel's average duration over the launches of the timed region - what rocprofv3
+        # --kernel-trace --stats reports for this command (with %d groups in flight that is its RESIDENCY: it shares the chip);
+        # standalone_ms / frac_standalone: the same kernel with the chip to itself - its cost.
+        "roofline": {"bound": "hbm", "kernel": dom, "kernel_chosen_by": dom_source, "units_per_launch": units, "launch_ms": round(launch_ms, 4),
                      "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                     "standalone_ms": round(sa_ms, 4) if sa_ms else None,
+                     "achieved_standalone": round(sa_achieved, 3) if sa_achieved else None,
+                     "frac_standalone": round(sa_achieved / HBM_PEAK_GBS, 6) if sa_achieved else None,
                      "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": ALG_BYTES[dom] * units,
-                     "launch_ms_incl_warmup": round((sums[5] + warm_sum5) / max(cnt + warm_cnt, 1), 4) if dom == "k_blob_challenge" else None,
+                     "launch_ms_incl_warmup": round((sums[5] + warm_sum5) / max(cnt + warm_cnt, 1), 4) if stamped else None,
                      "launch_ms_source": ("live: the kernel's own execution interval, stamped inside the kernel with s_memrealtime (first wavefront in, last "
-                                          "wavefront out) and averaged over the %d launch groups of the timed region; launch_ms_incl_warmup averages the %d "
-                                          "warm-up groups in as well (the pipeline is still filling during the first ones: shorter intervals) - that is the "
-                                          "population rocprofv3 --kernel-trace --stats of this same command averages into the kernel's AverageNs"
-                                          % (cnt, warm_cnt)) if dom == "k_blob_challenge" else
-                                         "live: HIP events on the kernel's stream (includes waiting behind the other launch groups' kernels)",
+                                          "wavefront out) and averaged over the %d launch groups of the timed region, %d groups in flight (residency, not cost); "
+                                          "launch_ms_incl_warmup averages the %d warm-up groups in as well - the population rocprofv3 --kernel-trace --stats of "
+                                          "this same command averages into the kernel's AverageNs; standalone_ms: the same stamp from one launch group alone on "
+                                          "the chip" % (cnt, F, warm_cnt)) if stamped else
+                                         "live: HIP events around the kernel on a single-stream handle, one launch group alone on the chip",
                      "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 5)"},
+        "path": {"algorithmic_bytes_per_blob": PATH_ALG_BYTES, "algorithmic_GBps": round(path_gbps, 2), "frac": round(path_gbps / HBM_PEAK_GBS, 6),
+                 "hbm_traffic_ratio": path_ratio,
+                 "note": "whole path per GPU: 131 232 algorithmic bytes per blob x blobs/s; hbm_traffic_ratio = PMC HBM bytes of every kernel of the path / "
+                         "algorithmic bytes (profiles/%s; the blob is streamed twice - hash, then evaluate - and the MSM re-reads its table rows)" % pmc_file},
         "valu": valu,
-        "kernel_ms_per_launch_group": {k: round(v, 4) for k, v in kernels.items()},
+        "kernel_ms_standalone": {k: round(v, 4) for k, v in standalone.items()} if standalone else None,
+        "kernel_ms_in_flight": {"k_blob_challenge": round(kernels["k_blob_challenge"], 4),
+                                "note": "in-kernel stamp, %d groups in flight; the other kernels are not stamped and HIP-event intervals around them would "
+                                        "include queueing behind other groups - see kernel_ms_standalone" % F} if world == 1 or stamped else None,
+        "self_check": self_check,
         "single_batch": single,
         "end_to_end": end2end,
+        "verify_kzg_proof_ms": proof_ms,
     }
-    if dist:
+    if world > 1:
         g = max(pipe.stats["groups"], 1)  # warm-up groups included; per-step averages of THIS rank's host time
-        out["multi_gpu"] = {"ranks": world, "backend": dist.get_backend(), "rccl_ranks": world if dist.get_backend() == "nccl" else 0,
+        out["multi_gpu"] = {"ranks": world, "backend": backend_name, "rccl_ranks": world if backend_name == "nccl" else 0,
                             "transcript_hash": "once per batch: rank j hashes batches [jB/N, (j+1)B/N) of every step" if G % world == 0 else
                                                "every rank hashes every batch (batches per step not divisible by the rank count)",
                             "r_hash_ms_per_step": round(pipe.stats["r_hash_s"] / g * 1e3, 4),
@@ -369,11 +557,26 @@ def main():
                             "note": "exchange 1 = all-to-all of 160 B transcript records + all-gather of r (32 B per batch) and error flags; exchange 2 = "
                                     "all-gather of the 288 B partial sums (A_k, B_k) - the G1 all-reduce of the north star, folded on every rank; host "
                                     "times of rank 0, overlapped with the GPU work of the other groups in flight"}
+        # ONE process over all the GPUs through a multi-device handle and the reference's call shape (the ranks have left the
+        # GPUs by now).  A child process: a failure or a hang there costs this leg, not the line.
+        if not share and os.environ.get("KZG_BENCH_SINGLE_PROCESS", "1") != "0":
+            out["multi_gpu"]["single_process"] = run_single_process_child(",".join(str(i) for i in range(world)), n)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blobs, cs, ps, synth.synthetic_setup()[1], args.cpu_sample)
     print(json.dumps(out))
-    if dist:
-        dist.destroy_process_group()
+
+
+def run_single_process_child(devices, n, timeout=420):
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-process-devices", devices, "--blobs", str(n)],
+                           capture_output=True, text=True, timeout=timeout)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-600:])}
+    except Exception as e:  # timeout included
+        return {"error": repr(e)[:600]}
 
 
 if __name__ == "__main__":

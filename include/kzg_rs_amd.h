@@ -63,6 +63,24 @@ KzgRet kzg_settings_load_trusted_setup(KzgSettings **out, const char *txt, size_
 /* EnvKzgSettings::Custom (src/trusted_setup.rs:52-57): settings from g2_points[1] = [tau]G2 alone
  * (96-byte compressed).  Used by the synthetic known-tau workloads of the benchmark. */
 KzgRet kzg_settings_from_tau_g2(KzgSettings **out, const uint8_t tau_g2[96]);
+/* The same two constructors over a DEVICE LIST: one process, one handle, several GPUs.  A Rust caller of
+ * KzgProof::verify_blob_kzg_proof_batch (src/kzg_proof.rs:472-477) is one process and passes one &KzgSettings; a handle
+ * made here shards every batch of at least KZG_MULTI_MIN_BLOBS (default 256) blobs by blob, in contiguous index ranges,
+ * over `devices` (HIP ordinals; shard k on devices[k]; devices == NULL or n_devices == 0: every visible device) behind the
+ * UNCHANGED kzg_verify_blob_kzg_proof_batch / _device signatures: phase 1 per device (each slice over its own PCIe link),
+ * one host hash of the whole transcript (:291-334), phase 2 per device from r^offset, then the north star's "G1
+ * all-reduce" - an in-process RCCL all-gather (ncclCommInitAll + ncclAllGather over xGMI) of the 288-byte partial sums,
+ * folded on the first device - and ONE pairing.  The handle is also a complete single-device handle on devices[0]: every
+ * other entry point runs there.  The plain constructors above read KZG_DEVICES ("all" or "0,1,2,...") from the
+ * environment, so an unchanged caller gets the same handle without a source change.  If librccl cannot be loaded, or
+ * the list names a device twice (test rigs), the partial sums travel through pinned host memory instead
+ * (KZG_MULTI_EXCHANGE=host forces that, =rccl makes the fallback an error). */
+KzgRet kzg_settings_load_trusted_setup_devices(KzgSettings **out, const char *txt, size_t len, const int *devices,
+                                               size_t n_devices);
+KzgRet kzg_settings_from_tau_g2_devices(KzgSettings **out, const uint8_t tau_g2[96], const int *devices, size_t n_devices);
+/* The shape of a handle: *n_devices shards, shard k on devices_out[k] (optional, `cap` entries); *exchange (optional) =
+ * 0 single device, 1 partial sums through host memory (kzg_last_error() then says why), 2 in-process RCCL all-gather. */
+KzgRet kzg_settings_devices(const KzgSettings *s, size_t *n_devices, int *devices_out, size_t cap, int *exchange);
 void kzg_settings_free(KzgSettings *s);
 /* roots_of_unity[i] as 32 big-endian bytes (i < 4096), for parity tests of the settings tables. */
 KzgRet kzg_settings_root_of_unity(const KzgSettings *s, size_t i, uint8_t out[32]);
@@ -101,7 +119,18 @@ KzgRet kzg_verify_blob_kzg_proof_batch(bool *ok, const uint8_t *blobs, const uin
 KzgRet kzg_verify_blob_kzg_proof_batch_device(bool *ok, const void *d_blobs, const void *d_commitments,
                                               const void *d_proofs, size_t n, const KzgSettings *s);
 
-/* ---- multi-GPU: one process per GPU, the batch sharded by blob in contiguous index ranges ----
+/* One batch whose shards are ALREADY resident on the devices of a multi-device handle (BASELINE configs[4]: 8 x 32 768
+ * blobs): shard k = n_local[k] blobs at d_blobs[k] / d_commitments[k] / d_proofs[k] in the memory of the handle's k-th
+ * device, global blob order = shard order; n_shards = the handle's device count; empty shards allowed.  Same result as
+ * kzg_verify_blob_kzg_proof_batch over the concatenation (n == 0 -> true, n == 1 -> the single-blob branch :482-489). */
+KzgRet kzg_verify_blob_kzg_proof_batch_sharded(bool *ok, const void *const *d_blobs, const void *const *d_commitments,
+                                               const void *const *d_proofs, const size_t *n_local, size_t n_shards,
+                                               const KzgSettings *s);
+/* Host wall-clock stages of the last sharded call on a multi-device handle, milliseconds: [0] whole call, [1] inputs onto
+ * the devices + phase 1 (all shards), [2] transcript hash, [3] phase-2 launches, [4] exchange, [5] fold + pairing. */
+KzgRet kzg_multi_last_timings(const KzgSettings *s, float out_ms[8]);
+
+/* ---- multi-GPU, one process per GPU (torch.distributed / any transport): the batch sharded by blob in contiguous index ranges ----
  * (the loop of src/kzg_proof.rs:261-273 is the data-parallel axis; the batch challenge r of :291-348
  * needs every (C, z, y, pi), and the three MSMs of :419-430 are sums that split by index range).
  *   1. kzg_shard_phase1 on every rank: decode + challenge + evaluate its n_local blobs (device pointers);
@@ -207,6 +236,14 @@ KzgRet kzg_g1_mul_generator(uint8_t *out48, const uint8_t *scalars, size_t n, co
 /* pairings_verify (src/pairings.rs:5-9) specialised to the verifier's use (src/kzg_proof.rs:436-441):
  * *ok = ( e(a, g2_points[1]) == e(b, G2::generator()) ); a, b: 48-byte compressed G1 (unchecked). */
 KzgRet kzg_pairing_check(bool *ok, const uint8_t a[48], const uint8_t b[48], const KzgSettings *s);
+/* pairings_verify (src/pairings.rs:5-9, re-exported at src/lib.rs:15) with ARBITRARY G2 arguments:
+ * *ok = ( e(a1, a2) == e(b1, b2) ).  a1, b1: 48-byte compressed G1; a2, b2: 96-byte compressed G2 (x.c1 || x.c0, the
+ * flag bits of src/trusted_setup.txt's G2 lines).  The reference takes decoded G1Affine / G2Affine values; here the
+ * bytes are decoded on the device like from_compressed_unchecked (on the curve; the subgroup invariant of a typed value
+ * is the caller's) and an undecodable point is KZG_BADARGS.  Identity arguments (G1 or G2) make their pair contribute 1,
+ * as the reference's multi_miller_loop skips them.  The handle supplies the device and the pairing programs only. */
+KzgRet kzg_pairings_verify(bool *ok, const uint8_t a1[48], const uint8_t a2[96], const uint8_t b1[48], const uint8_t b2[96],
+                           const KzgSettings *s);
 
 /* Timing of the last batch call on this handle, in milliseconds, measured with HIP events on the
  * library's own stream: [0] whole call (device work), [1] per-blob phase (challenge + evaluate +

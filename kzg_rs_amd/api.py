@@ -69,6 +69,11 @@ def lib():
         vp, pp, u8, sz, bp = C.c_void_p, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t, C.POINTER(C.c_bool)
         L.kzg_settings_load_trusted_setup.argtypes = [pp, u8, sz]
         L.kzg_settings_from_tau_g2.argtypes = [pp, u8]
+        L.kzg_settings_load_trusted_setup_devices.argtypes = [pp, u8, sz, C.POINTER(C.c_int), sz]
+        L.kzg_settings_from_tau_g2_devices.argtypes = [pp, u8, C.POINTER(C.c_int), sz]
+        L.kzg_settings_devices.argtypes = [vp, C.POINTER(sz), C.POINTER(C.c_int), sz, C.POINTER(C.c_int)]
+        L.kzg_verify_blob_kzg_proof_batch_sharded.argtypes = [bp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), sz, vp]
+        L.kzg_multi_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
         L.kzg_settings_free.argtypes = [vp]
         L.kzg_settings_free.restype = None
         L.kzg_settings_root_of_unity.argtypes = [vp, sz, u8]
@@ -92,6 +97,7 @@ def lib():
         L.kzg_g1_decompress.argtypes = [u8, u8, u8, sz, vp]
         L.kzg_g1_msm.argtypes = [u8, u8, u8, sz, vp]
         L.kzg_pairing_check.argtypes = [bp, u8, u8, vp]
+        L.kzg_pairings_verify.argtypes = [bp, u8, u8, u8, u8, vp]
         L.kzg_g1_mul_generator.argtypes = [u8, u8, sz, vp]
         L.kzg_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
         L.kzg_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
@@ -170,13 +176,26 @@ class KzgSettings:
     def __init__(self, handle):
         self._h = handle
 
+    @staticmethod
+    def _devs(devices):
+        """devices: "all" or a list of HIP ordinals -> (int array or None, count)"""
+        if devices == "all":
+            return None, 0
+        arr = (C.c_int * len(devices))(*devices)
+        return arr, len(devices)
+
     @classmethod
-    def load_trusted_setup_file(cls, path=None):
+    def load_trusted_setup_file(cls, path=None, devices=None):
         """src/trusted_setup.rs:94-98 (the reference embeds the file at build time; here the same
-        public ceremony file ships as package data)."""
+        public ceremony file ships as package data).  devices: None = the current device (or KZG_DEVICES from the
+        environment), "all" or a list of ordinals = one handle over several GPUs (include/kzg_rs_amd.h)."""
         txt = open(path or TRUSTED_SETUP_PATH, "rb").read()
         h = C.c_void_p()
-        _chk(lib().kzg_settings_load_trusted_setup(C.byref(h), txt, len(txt)))
+        if devices is None:
+            _chk(lib().kzg_settings_load_trusted_setup(C.byref(h), txt, len(txt)))
+        else:
+            arr, n = cls._devs(devices)
+            _chk(lib().kzg_settings_load_trusted_setup_devices(C.byref(h), txt, len(txt), arr, n))
         return cls(h)
 
     @classmethod
@@ -187,11 +206,27 @@ class KzgSettings:
         return cls(h)
 
     @classmethod
-    def from_tau_g2(cls, tau_g2):
-        """EnvKzgSettings::Custom (src/trusted_setup.rs:52-57) from g2_points[1] alone."""
+    def from_tau_g2(cls, tau_g2, devices=None):
+        """EnvKzgSettings::Custom (src/trusted_setup.rs:52-57) from g2_points[1] alone; devices as in load_trusted_setup_file."""
         h = C.c_void_p()
-        _chk(lib().kzg_settings_from_tau_g2(C.byref(h), bytes(tau_g2)))
+        if devices is None:
+            _chk(lib().kzg_settings_from_tau_g2(C.byref(h), bytes(tau_g2)))
+        else:
+            arr, n = cls._devs(devices)
+            _chk(lib().kzg_settings_from_tau_g2_devices(C.byref(h), bytes(tau_g2), arr, n))
         return cls(h)
+
+    def devices(self):
+        """(device ordinals of the handle's shards, exchange) - exchange: "none" (one device), "host" or "rccl"."""
+        n, ex = C.c_size_t(0), C.c_int(0)
+        arr = (C.c_int * 64)()
+        _chk(lib().kzg_settings_devices(self._h, C.byref(n), arr, 64, C.byref(ex)))
+        return list(arr[: n.value]), ("none", "host", "rccl")[ex.value]
+
+    def multi_last_timings(self):
+        t = (C.c_float * 8)()
+        _chk(lib().kzg_multi_last_timings(self._h, t))
+        return list(t)
 
     def root_of_unity(self, i):
         out = C.create_string_buffer(32)
@@ -322,6 +357,18 @@ class KzgProof:
         return bool(ok.value)
 
 
+def verify_blob_kzg_proof_batch_sharded(shards, kzg_settings):
+    """ONE batch whose shards are resident on the devices of a multi-device handle: shards = [(d_blobs, d_commitments,
+    d_proofs, n_local), ...] in the order of the handle's device list (device pointers as ints)."""
+    k = len(shards)
+    vp = C.c_void_p
+    b, c, p = (vp * k)(*[s[0] for s in shards]), (vp * k)(*[s[1] for s in shards]), (vp * k)(*[s[2] for s in shards])
+    nl = (C.c_size_t * k)(*[s[3] for s in shards])
+    ok = C.c_bool(False)
+    _chk(lib().kzg_verify_blob_kzg_proof_batch_sharded(C.byref(ok), b, c, p, nl, k, kzg_settings._h))
+    return bool(ok.value)
+
+
 def verify_blob_kzg_proof_batches_device(d_blobs, d_commitments, d_proofs, n, n_batches, kzg_settings):
     """n_batches independent verify_blob_kzg_proof_batch calls of n blobs each in one launch group (device pointers).
     Returns a list with True / False per batch, or None where the reference would return Err."""
@@ -337,9 +384,30 @@ def verify_blob_kzg_proof_batches(blobs, commitments, proofs, n, n_batches, kzg_
     an int); copies overlap verification.  Returns True / False / None (Err) per batch."""
     ok = (C.c_bool * n_batches)()
     err = C.create_string_buffer(n_batches)
-    ptr = lambda x: C.c_void_p(x) if isinstance(x, int) else C.cast(C.c_char_p(x), C.c_void_p)
-    _chk(lib().kzg_verify_blob_kzg_proof_batches(ok, err, ptr(blobs), ptr(commitments), ptr(proofs), n, n_batches, kzg_settings._h))
+    keep = []
+    ptrs = [_host_ptr(x, want, what, keep) for x, want, what in
+            ((blobs, n * n_batches * BYTES_PER_BLOB, "blobs"), (commitments, n * n_batches * BYTES_PER_COMMITMENT, "commitments"),
+             (proofs, n * n_batches * BYTES_PER_PROOF, "proofs"))]
+    _chk(lib().kzg_verify_blob_kzg_proof_batches(ok, err, ptrs[0], ptrs[1], ptrs[2], n, n_batches, kzg_settings._h))
+    del keep
     return [None if err.raw[b] else bool(ok[b]) for b in range(n_batches)]
+
+
+def _host_ptr(x, want_len, what, keep):
+    """A host address for the C ABI.  bytes-like objects are length-checked (the reference's Err(InvalidBytesLength) for
+    mismatched lengths, src/kzg_proof.rs:491-501); an int is taken as a raw address the caller vouches for - the
+    explicitly unsafe form."""
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        if len(x) != want_len:
+            raise InvalidBytesLength("Invalid %s length: %d bytes, expected %d" % (what, len(x), want_len))
+        if isinstance(x, bytes):
+            return C.cast(C.c_char_p(x), C.c_void_p)
+        buf = (C.c_char * len(x)).from_buffer(x)  # bytearray / writable memoryview: no copy
+        keep.append(buf)
+        return C.cast(buf, C.c_void_p)
+    raise TypeError("%s: bytes, bytearray or an int address expected" % what)
 
 
 # ---- pieces of the path (parity tests / per-kernel benchmarks) ----
@@ -382,6 +450,16 @@ def g1_msm(points, scalars, kzg_settings):
 def pairing_check(a, b, kzg_settings):
     ok = C.c_bool(False)
     _chk(lib().kzg_pairing_check(C.byref(ok), a, b, kzg_settings._h))
+    return bool(ok.value)
+
+
+def pairings_verify(a1, a2, b1, b2, kzg_settings):
+    """pairings_verify (src/pairings.rs:5-9, src/lib.rs:15): e(a1, a2) == e(b1, b2) for compressed G1 (48 B) / G2 (96 B)
+    points; the settings supply the device and the pairing programs only."""
+    if len(a1) != 48 or len(b1) != 48 or len(a2) != 96 or len(b2) != 96:
+        raise InvalidBytesLength("pairings_verify: 48-byte G1 and 96-byte G2 encodings expected")
+    ok = C.c_bool(False)
+    _chk(lib().kzg_pairings_verify(C.byref(ok), bytes(a1), bytes(a2), bytes(b1), bytes(b2), kzg_settings._h))
     return bool(ok.value)
 
 

@@ -227,6 +227,80 @@ extern "C" KzgRet kzg_pairing_check(bool* ok, const uint8_t a[48], const uint8_t
     return KZG_OK;
 }
 
+// pairings_verify(a1, a2, b1, b2) (src/pairings.rs:5-9, public at src/lib.rs:15) with ARBITRARY G2 arguments:
+//     multi_miller_loop([(-a1, prep(a2)), (b1, prep(b2))]).final_exponentiation() == 1   <=>   e(a1, a2) == e(b1, b2).
+// The reference takes decoded G1Affine / G2Affine; across the C ABI they are compressed bytes, decoded on the device like
+// from_compressed_unchecked (on the curve, no subgroup test - a typed Rust value carries that invariant already); an
+// undecodable point is KZG_BADARGS.  The PREP program that makes a G2 point's 68 line triples (the reference's
+// G2Prepared::from, which it runs on every call) runs here on both G2 arguments - two instances, one launch - and VERIFY
+// takes those lines instead of the handle's.  An identity G2 argument makes its pair contribute 1, as the reference's
+// skipped pair does: its G1 partner is replaced by the identity and the lines by the generator's.
+extern "C" KzgRet kzg_pairings_verify(bool* ok, const uint8_t a1[48], const uint8_t a2[96], const uint8_t b1[48], const uint8_t b2[96],
+                                      const KzgSettings* s) {
+    if (!ok || !a1 || !a2 || !b1 || !b2 || !s) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
+    KzgRet rc = ws_reserve(s, 2, 1, STAGE_NONE);
+    if (rc != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    const size_t n_lines = (size_t)2 * s->prep.p.n_out;
+    DevTmp t_g2b, t_q, t_flag, t_lines, t_lines29;
+    HIPCHK(hipMalloc(&t_g2b.p, 192));
+    HIPCHK(hipMalloc(&t_q.p, sizeof(Fp) * 8));
+    HIPCHK(hipMalloc(&t_flag.p, 8));
+    HIPCHK(hipMalloc(&t_lines.p, sizeof(Fp) * n_lines));
+    HIPCHK(hipMalloc(&t_lines29.p, (size_t)64 * n_lines));
+    auto g2_is_identity_encoding = [](const uint8_t* b) {
+        if (b[0] != 0xC0) return false;
+        for (int i = 1; i < 96; i++)
+            if (b[i]) return false;
+        return true;
+    };
+    const bool inf[2] = {g2_is_identity_encoding(a2), g2_is_identity_encoding(b2)};
+    uint8_t* h = w.h_buf;  // pinned: [a1 | b1 | a2 | b2] in, then flags and the program's output
+    memcpy(h, a1, 48);
+    memcpy(h + 48, b1, 48);
+    memcpy(h + 96, a2, 96);
+    memcpy(h + 192, b2, 96);
+    HIPCHK(hipMemcpyAsync(w.d_bytes, h, 96, hipMemcpyHostToDevice, s->s1));
+    HIPCHK(hipMemcpyAsync(t_g2b.p, h + 96, 192, hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_g1_decode, dim3(1), dim3(64), 0, s->s1, w.d_bytes, w.d_bytes, 2, w.d_points, w.d_pflag, 2, 0);
+    hipLaunchKernelGGL(k_g2_decompress_n, dim3(2), dim3(64), 0, s->s1, t_g2b.as<uint8_t>(), t_q.as<Fp>(), t_flag.as<uint32_t>());
+    HIPCHK(hipGetLastError());
+    uint32_t* hf = reinterpret_cast<uint32_t*>(h + 320);  // [g1 flags 2 | g2 flags 2 | out 72]
+    HIPCHK(hipMemcpyAsync(hf, w.d_pflag, 8, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipMemcpyAsync(hf + 2, t_flag.p, 8, hipMemcpyDeviceToHost, s->s1));
+    static const uint32_t one_flag = G1_INFINITY;
+    for (int k = 0; k < 2; k++)
+        if (inf[k]) {  // e(P, O) = 1: the pair leaves the product
+            hipLaunchKernelGGL(k_g2_generator, dim3(1), dim3(64), 0, s->s1, t_q.as<Fp>() + 4 * k);
+            HIPCHK(hipMemcpyAsync(w.d_pflag + k, &one_flag, 4, hipMemcpyHostToDevice, s->s1));
+        }
+    hipLaunchKernelGGL(k_aff_to_slp, dim3(1), dim3(64), 0, s->s1, w.d_points, w.d_pflag, w.d_slp_in);
+    HIPCHK(hipGetLastError());
+    if ((rc = run_program(s->prep, t_q.as<Fp>(), nullptr, t_lines.as<Fp>(), 2, s->s1)) != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[3], s->s1));
+    if (pairing_latency_form(1)) {
+        hipLaunchKernelGGL(k_fp_to_fp29mem, dim3((unsigned)((n_lines + 63) / 64)), dim3(64), 0, s->s1, t_lines.as<Fp>(), t_lines29.as<uint32_t>(), (int)n_lines);
+        HIPCHK(hipGetLastError());
+        rc = run_program2(s->verify2, w.d_slp_in, t_lines29.as<uint32_t>(), w.d_slp_out, 1, s->s1);
+    } else {
+        rc = run_program(s->verify, w.d_slp_in, t_lines.as<Fp>(), w.d_slp_out, 1, s->s1);
+    }
+    if (rc != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[4], s->s1));
+    HIPCHK(hipMemcpyAsync(hf + 4, w.d_slp_out, sizeof(Fp) * 6, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    elapsed(&s->timings[3], s->ev[3], s->ev[4]);
+    if (hf[0] == G1_INVALID || hf[1] == G1_INVALID) return fail(KZG_BADARGS, "invalid G1 point");
+    if (hf[2] == G1_INVALID || hf[3] == G1_INVALID) return fail(KZG_BADARGS, "invalid G2 point");
+    uint32_t any = 0;
+    for (int i = 0; i < 72; i++) any |= hf[4 + i];
+    *ok = any == 0;
+    return KZG_OK;
+}
+
 extern "C" KzgRet kzg_settings_root_of_unity(const KzgSettings* s, size_t i, uint8_t out[32]) {
     if (!s || !out || i >= FE_PER_BLOB) return fail(KZG_BADARGS, "bad argument");
     std::lock_guard<std::mutex> lk(s->mu);

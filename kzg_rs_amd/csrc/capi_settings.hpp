@@ -87,7 +87,14 @@ struct KzgSettings {
     mutable float timings[8] = {};
     mutable double tsum[8] = {};   // the same, summed over every group finished on this handle since the last reset
     mutable uint64_t tcount = 0;
+    // A multi-device handle (capi_multi.hpp): this handle is shard 0 on the first device of the list and a complete
+    // single-device handle in its own right; `peers` are the (private) single-device handles of the other entries, `multi`
+    // the device list and the exchange (in-process RCCL communicators, or host staging).
+    std::vector<KzgSettings*> peers;
+    struct MultiState* multi = nullptr;
+    mutable float multi_ms[8] = {};  // host wall-clock of the last sharded call: [0] whole call [1] copy + phase 1 [2] r hash [3] phase 2 [4] exchange [5] fold + pairing
 };
+static void multi_free(KzgSettings* s);
 
 static KzgRet upload_program(DevProgram& dp, const unsigned char* begin, const unsigned char* end) {
     size_t len = (size_t)(end - begin);
@@ -194,7 +201,7 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
     return KZG_OK;
 }
 static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
-    HIPCHK(hipGetDevice(&s->device));
+    HIPCHK(hipGetDevice(&s->device));  // the calling thread's current device (multi_build sets it per shard)
     HIPCHK(hipStreamCreateWithFlags(&s->s_plain[0], hipStreamNonBlocking));
     s->s1 = s->s_sha = s->s_plain[0];
     HIPCHK(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->device));
@@ -326,19 +333,77 @@ static KzgRet settings_load_points(KzgSettings* s, const std::vector<uint8_t>& g
     return KZG_OK;
 }
 
-extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char* txt, size_t len) {
-    if (!out || !txt) return fail(KZG_BADARGS, "null argument");
+// Device list of a new handle: explicit (the _devices constructors), or from the environment for the reference-shaped
+// constructors - KZG_DEVICES = "all" | "0,1,2,..." makes the handle of an UNCHANGED caller a multi-device one (capi_multi.hpp);
+// unset: the calling thread's current device, as before.
+static KzgRet multi_build(KzgSettings* s, const uint8_t tau_g2[96], const std::vector<int>& devices);
+static KzgRet device_list(std::vector<int>& out, const int* devices, size_t n_devices, bool from_env) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        (void)hipGetLastError();
+        return fail(KZG_ERROR, "no HIP device: this library has no CPU fallback");
+    }
+    out.clear();
+    if (from_env) {
+        const char* e = getenv("KZG_DEVICES");
+        if (!e || !*e) return KZG_OK;  // current device only
+        if (strcmp(e, "all") == 0) {
+            for (int i = 0; i < ndev; i++) out.push_back(i);
+        } else {
+            for (const char* p = e; *p;) {
+                char* end = nullptr;
+                long v = strtol(p, &end, 10);
+                if (end == p) return fail(KZG_BADARGS, "KZG_DEVICES: expected \"all\" or a comma-separated list of device ordinals");
+                out.push_back((int)v);
+                p = *end == ',' ? end + 1 : end;
+                if (*end && *end != ',') return fail(KZG_BADARGS, "KZG_DEVICES: expected \"all\" or a comma-separated list of device ordinals");
+            }
+        }
+    } else if (!devices || !n_devices) {
+        for (int i = 0; i < ndev; i++) out.push_back(i);  // every visible device
+    } else {
+        out.assign(devices, devices + n_devices);
+    }
+    if (out.size() > MAX_WORLD) return fail(KZG_BADARGS, "more than 64 devices in one handle");
+    for (int d : out)
+        if (d < 0 || d >= ndev) return fail(KZG_BADARGS, "device ordinal out of range");
+    return KZG_OK;
+}
+
+// shard 0 on devs[0] (or the current device), then the peers; the caller's current device is restored
+static KzgRet settings_on_devices(KzgSettings** out, const uint8_t tau_g2[96], const std::vector<int>& devs) {
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    if (!have_prev) (void)hipGetLastError();
+    if (!devs.empty()) HIPCHK(hipSetDevice(devs[0]));
+    KzgSettings* s = nullptr;
+    KzgRet rc = settings_common(&s, tau_g2);
+    if (rc == KZG_OK && !devs.empty() && (rc = multi_build(s, tau_g2, devs)) != KZG_OK) {
+        const std::string msg = g_err;
+        kzg_settings_free(s);
+        g_err = msg;
+        s = nullptr;
+    }
+    if (have_prev) (void)hipSetDevice(prev);
+    if (rc == KZG_OK) *out = s;
+    return rc;
+}
+
+static KzgRet load_trusted_setup_on(KzgSettings** out, const char* txt, size_t len, const std::vector<int>& devs) {
     std::vector<uint8_t> g1b, g2b;
     uint8_t first[2][48];
     long n1 = 0, n2 = 0;
     std::string perr;
     if (!hostparse::trusted_setup_text(txt, len, g1b, g2b, first, n1, n2, perr)) return fail(KZG_BAD_SETUP, perr);
-    KzgRet rc = settings_common(out, g2b.data() + 96);
+    KzgSettings* s = nullptr;
+    KzgRet rc = settings_on_devices(&s, g2b.data() + 96, devs);
     if (rc != KZG_OK) return rc;
-    KzgSettings* s = *out;
-    *out = nullptr;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(s->device);  // the full point tables live on shard 0 only (verification does not read them)
     memcpy(s->g1_first, first, sizeof first);
     rc = settings_load_points(s, g1b, g2b, (int)n1, (size_t)n2);
+    (void)hipSetDevice(prev);
     if (rc != KZG_OK) {  // any failure below settings_common releases the whole handle (and keeps the first message)
         const std::string msg = g_err;
         kzg_settings_free(s);
@@ -349,9 +414,30 @@ extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char*
     return KZG_OK;
 }
 
+extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char* txt, size_t len) {
+    if (!out || !txt) return fail(KZG_BADARGS, "null argument");
+    std::vector<int> devs;
+    KzgRet rc = device_list(devs, nullptr, 0, /*from_env=*/true);
+    return rc != KZG_OK ? rc : load_trusted_setup_on(out, txt, len, devs);
+}
+extern "C" KzgRet kzg_settings_load_trusted_setup_devices(KzgSettings** out, const char* txt, size_t len, const int* devices, size_t n_devices) {
+    if (!out || !txt) return fail(KZG_BADARGS, "null argument");
+    std::vector<int> devs;
+    KzgRet rc = device_list(devs, devices, n_devices, false);
+    return rc != KZG_OK ? rc : load_trusted_setup_on(out, txt, len, devs);
+}
+
 extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_g2[96]) {
     if (!out || !tau_g2) return fail(KZG_BADARGS, "null argument");
-    return settings_common(out, tau_g2);
+    std::vector<int> devs;
+    KzgRet rc = device_list(devs, nullptr, 0, /*from_env=*/true);
+    return rc != KZG_OK ? rc : settings_on_devices(out, tau_g2, devs);
+}
+extern "C" KzgRet kzg_settings_from_tau_g2_devices(KzgSettings** out, const uint8_t tau_g2[96], const int* devices, size_t n_devices) {
+    if (!out || !tau_g2) return fail(KZG_BADARGS, "null argument");
+    std::vector<int> devs;
+    KzgRet rc = device_list(devs, devices, n_devices, false);
+    return rc != KZG_OK ? rc : settings_on_devices(out, tau_g2, devs);
 }
 
 static void ws_free(Workspace& w) {
@@ -366,6 +452,10 @@ static void ws_free(Workspace& w) {
 
 extern "C" void kzg_settings_free(KzgSettings* s) {
     if (!s) return;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    multi_free(s);  // communicators and peer handles first (each on its own device)
+    (void)hipSetDevice(s->device);
     ws_free(s->ws);
     void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_eval_scratch, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob, s->verify2.blob, s->d_prep29};
     for (void* p : ptrs)
@@ -377,4 +467,6 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     for (hipStream_t st : {s->s_plain[0], s->s_plain[1], s->s_half[0], s->s_half[1], s->s_copy})
         if (st) (void)hipStreamDestroy(st);
     delete s;
+    if (prev >= 0) (void)hipSetDevice(prev);
+    (void)hipGetLastError();
 }

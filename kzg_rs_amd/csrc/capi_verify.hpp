@@ -26,9 +26,11 @@ static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const F
     // otherwise pairs workgroups on half the CUs, two wavefronts per SIMD, and the single batch waits twice as long.
     const unsigned eval_blocks = (unsigned)((T + EVAL_BLOBS_PER_BLOCK - 1) / EVAL_BLOBS_PER_BLOCK);
     size_t spread_lds = 0;
-    if (eval_blocks <= (unsigned)s->n_cus &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate), hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_SPREAD_LDS) == hipSuccess)
-        spread_lds = EVAL_SPREAD_LDS;
+    if (eval_blocks <= (unsigned)s->n_cus) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate), hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_SPREAD_LDS) == hipSuccess)
+            spread_lds = EVAL_SPREAD_LDS;
+        else (void)hipGetLastError();  // the launch below goes without the spreading request; nothing sticky is left for the callers' checks
+    }
     hipLaunchKernelGGL(k_blob_evaluate, dim3(eval_blocks), dim3(64 * EVAL_BLOBS_PER_BLOCK), spread_lds, s->s1,
                        (const uint8_t*)d_blobs, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, s->d_eval_scratch, d_status, (int)T);
     hipLaunchKernelGGL(k_eval_finish, dim3(per_lane), dim3(64), 0, s->s1, s->d_eval_scratch, d_y, (int)T);
@@ -462,7 +464,7 @@ static KzgRet phase2_launch_locked(const uint8_t* all_records, size_t n_total, s
     } else {
         uint8_t* h_r = w.h_buf + w.off_r;  // pinned staging for the async H2D copy
         if (r_le) memcpy(h_r, r_le, 32 * B);
-        else host_batch_challenges(h_r, all_records, B, n, n_total, world);
+        else if (!host_batch_challenges(h_r, all_records, B, n, n_total, world)) return fail(KZG_MALLOC, "batch transcript buffer");
         const Fr* d_r = w.d_r;
         if (n * B <= LATENCY_MAX_BLOBS) d_r = reinterpret_cast<const Fr*>(h_r);  // a small launch reads r where the host wrote it (pinned memory)
         else HIPCHK(hipMemcpyAsync(w.d_r, h_r, 32 * B, hipMemcpyHostToDevice, s->s1));
@@ -488,12 +490,15 @@ static KzgRet phase2_wait_locked(uint8_t* partial_out /* B x 288 */, const KzgSe
 
 // Finish: fold `world` partial sets ([world][B] x 288 B), or take the handle's own (A, B)_b when partials == nullptr,
 // and run one pairing instance per batch.
-static KzgRet finish_launch_locked(const uint8_t* partials, size_t world, size_t B, const KzgSettings* s) {
+// parts_on_device: the [world][B] partial sets already lie in ws.d_parts (an in-process RCCL all-gather put them there, capi_multi.hpp)
+static KzgRet finish_launch_locked(const uint8_t* partials, size_t world, size_t B, const KzgSettings* s, bool parts_on_device = false) {
     Workspace& w = s->ws;
-    if (partials) {
+    if (partials || parts_on_device) {
         if (world > MAX_WORLD) return fail(KZG_BADARGS, "world size above 64");
-        memcpy(w.h_buf + w.off_parts, partials, 288 * world * B);
-        HIPCHK(hipMemcpyAsync(w.d_parts, w.h_buf + w.off_parts, 288 * world * B, hipMemcpyHostToDevice, s->s1));
+        if (!parts_on_device) {
+            memcpy(w.h_buf + w.off_parts, partials, 288 * world * B);
+            HIPCHK(hipMemcpyAsync(w.d_parts, w.h_buf + w.off_parts, 288 * world * B, hipMemcpyHostToDevice, s->s1));
+        }
         hipLaunchKernelGGL(k_fold_partials, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_parts, (int)world, (int)B, w.d_ab);
     }
     hipLaunchKernelGGL(k_jac_to_slp, dim3((unsigned)B), dim3(64), 0, s->s1, w.d_ab, w.d_slp_in);
@@ -523,6 +528,7 @@ static KzgRet finish_wait_locked(bool* ok /* B */, const KzgSettings* s) {
     elapsed(&s->timings[0], s->ev[0], s->ev[9]);
     for (int i = 0; i < 8; i++) s->tsum[i] += s->timings[i];
     s->tcount++;
+    w.pending_n = w.pending_b = w.finish_b = 0;  // the group is done: the handle holds no live state (kzg_shard_finish_launch tests this)
     return KZG_OK;
 }
 
@@ -573,7 +579,16 @@ extern "C" KzgRet kzg_shard_phase2_launch_r(const uint8_t* r_le, size_t n_total,
 // the hash half of compute_r_powers on the host, without a handle or a GPU: see include/kzg_rs_amd.h
 extern "C" KzgRet kzg_batch_challenges(uint8_t* r_le_out, const uint8_t* records, size_t world, size_t n_batches, size_t n_local) {
     if (!r_le_out || !records || !n_batches || !n_local) return fail(KZG_BADARGS, "bad argument");
-    host_batch_challenges(r_le_out, records, n_batches, n_local, (world ? world : 1) * n_local, world);
+    // sizes that cannot be a transcript: (world n_local) blobs of 128 KiB each would not fit any memory, and the products must not wrap
+    const size_t w1 = world ? world : 1, lim = (size_t)1 << 40;
+    if (world > MAX_WORLD || n_local > lim / w1 || n_batches > lim || w1 * n_local > (lim / 160) / n_batches)
+        return fail(KZG_BADARGS, "kzg_batch_challenges: sizes out of range");
+    try {  // (the buffers are allocated without throwing; what is left is thread creation)
+        if (!host_batch_challenges(r_le_out, records, n_batches, n_local, w1 * n_local, world))
+            return fail(KZG_MALLOC, "kzg_batch_challenges: transcript buffer");
+    } catch (const std::exception& e) {
+        return fail(KZG_ERROR, std::string("kzg_batch_challenges: ") + e.what());
+    }
     return KZG_OK;
 }
 extern "C" KzgRet kzg_shard_records_device(void* d_records_out, const KzgSettings* s) {
@@ -640,6 +655,11 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batches_device(bool* ok_out, uint8_t
     return KZG_OK;
 }
 
+// a handle over several devices (capi_multi.hpp): does a call of n blobs go through its shards, and the sharded call itself
+static bool multi_takes(const KzgSettings* s, size_t n);
+static KzgRet multi_array_locked(bool* ok, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n, bool host,
+                                 const KzgSettings* s);
+
 extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_device(bool* ok, const void* d_blobs, const void* d_commitments,
                                                          const void* d_proofs, size_t n, const KzgSettings* s) {
     if (!ok || !s) return fail(KZG_BADARGS, "null argument");
@@ -650,6 +670,9 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_device(bool* ok, const void* d
     if (!d_blobs || !d_commitments || !d_proofs) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    // several devices: the arrays lie on the first one, the other shards' slices cross xGMI (per-device resident shards:
+    // kzg_verify_blob_kzg_proof_batch_sharded)
+    if (multi_takes(s, n)) return multi_array_locked(ok, (const uint8_t*)d_blobs, (const uint8_t*)d_commitments, (const uint8_t*)d_proofs, n, false, s);
     KzgRet rc = ws_reserve(s, n, 1, STAGE_NONE);
     if (rc != KZG_OK) return rc;
     return batch_device_locked(ok, d_blobs, d_commitments, d_proofs, n, s);
@@ -665,6 +688,8 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
     if (!blobs || !commitments || !proofs) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    // several devices: contiguous slices of the Vec<Blob>, each over its own device's PCIe link (capi_multi.hpp)
+    if (multi_takes(s, n)) return multi_array_locked(ok, blobs, commitments, proofs, n, true, s);
     KzgRet rc = ws_reserve(s, n, 1, STAGE_BLOBS);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
@@ -741,6 +766,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batches(bool* ok_out, uint8_t* err_o
         (void)hipStreamSynchronize(s->s_copy);
         (void)hipStreamSynchronize(s->s1);
         (void)hipStreamSynchronize(s->s2);
+        if (s->s_sha) (void)hipStreamSynchronize(s->s_sha);  // the CU-masked challenge stream of a small chunk
         (void)hipGetLastError();
         g_err = msg;
         return code;
@@ -765,6 +791,23 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batches(bool* ok_out, uint8_t* err_o
                 if (err[b]) ok_out[c * G + b] = false;
     }
     HIPCHK(hipStreamSynchronize(s->s_copy));
+    // The staging sets are grow-only inside a call but not kept beyond it when they are large (2 x up to 16 GiB would starve
+    // later workspaces on this device): above KZG_HSTAGE_KEEP_MIB per set (default 4608 MiB - the default chunk of 32
+    // batches of 1 024 blobs is 4.1 GiB) they are released here and allocated again by the next stream call, which costs
+    // tens of ms per GiB (measured: a stream of 64 host batches fell from 0.37 M to 0.12 M blobs/s when every call
+    // reallocated its 2 x 4.1 GiB); below it they stay with the handle until kzg_settings_free: at most 9 GiB retained.
+    static const size_t keep_bytes = [] {
+        const char* e = getenv("KZG_HSTAGE_KEEP_MIB");
+        long v = e ? atol(e) : 4608;
+        return (size_t)(v < 0 ? 0 : v) << 20;
+    }();
+    if (w.cap_hstage * ((size_t)BLOB_BYTES + 96) > keep_bytes) {
+        for (auto& p : w.d_hstage) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+        }
+        w.cap_hstage = 0;
+    }
     return KZG_OK;
 }
 
@@ -821,6 +864,11 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
     // caller's memory is pageable), the MSM waits for it through an event, and the point flags are looked at after the
     // pairing (flagged points have identity table rows: the work on them is wasted, not wrong).
     const bool chained = n <= LATENCY_MAX_BLOBS;
+    struct RestoreS2 {  // the chained form aliases s2 to s1 for this call only
+        const KzgSettings* s;
+        hipStream_t keep;
+        ~RestoreS2() { s->s2 = keep; }
+    } restore_s2{s, s->s2};
     if (chained) {
         uint8_t* h_cp = w.h_buf + 72 * n;
         memcpy(h_cp, commitments, 48 * n);
@@ -843,10 +891,15 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
     // n == 1: r^0 = 1 whatever the transcript hashes to, which is phase 2's n_total == 1 branch (scalars 1, z, -y)
     if ((rc = phase2_launch_locked(records.data(), n, 0, s, 0, nullptr, false)) != KZG_OK) return rc;
     if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;
-    if ((rc = finish_wait_locked(ok, s)) != KZG_OK) return rc;
+    bool paired = false;  // *ok is written only once the inputs are known to be valid
+    if ((rc = finish_wait_locked(&paired, s)) != KZG_OK) return rc;
     if (chained) {  // (finish_wait_locked has waited for the stream the flags were copied on)
         for (size_t i = 0; i < 2 * n; i++)
-            if (h_pflag[i] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+            if (h_pflag[i] == G1_INVALID) {
+                *ok = false;
+                return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+            }
     }
+    *ok = paired;
     return KZG_OK;
 }

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -202,9 +203,17 @@ static bool trusted_setup_text(const char* txt, size_t len, std::vector<uint8_t>
 // independent, so they are spread over a few host threads (KZG_HOST_THREADS, default 16).  Record layouts:
 //   world == 0 : [B][n_total]       every batch's records in global blob order
 //   world  > 0 : [world][B][n]      as an all-gather / all-to-all of equal shards leaves them (n_total = world n)
-static void host_batch_challenges(uint8_t* r_out, const uint8_t* all_records, size_t B, size_t n, size_t n_total, size_t world) {
+// Returns false when a transcript buffer could not be allocated (nothing is thrown, in a worker thread or out of it).
+static bool host_batch_challenges(uint8_t* r_out, const uint8_t* all_records, size_t B, size_t n, size_t n_total, size_t world) {
+    std::atomic<bool> failed{false};
     auto digest_range = [&](size_t b0, size_t b1) {
-        std::vector<uint8_t> t(32 + 160 * n_total);
+        std::vector<uint8_t> t;
+        try {
+            t.resize(32 + 160 * n_total);
+        } catch (...) {
+            failed = true;
+            return;
+        }
         memcpy(t.data(), "RCKZGBATCH___V1_", 16);
         memset(t.data() + 16, 0, 16);
         t[22] = (uint8_t)(KZG_HOST_FE_PER_BLOB >> 8);
@@ -234,5 +243,6 @@ static void host_batch_challenges(uint8_t* r_out, const uint8_t* all_records, si
         digest_range(0, B / nthr);
         for (auto& th : pool) th.join();
     }
+    return !failed;
 }
 

@@ -46,6 +46,7 @@ extern "C" const unsigned char kzg_slp_prep_begin[], kzg_slp_prep_end[], kzg_slp
 #include "capi_host_util.hpp"
 #include "capi_settings.hpp"
 #include "capi_verify.hpp"
+#include "capi_multi.hpp"
 #include "capi_pieces.hpp"
 #include "capi_prover.hpp"
 #include "capi_debug.hpp"

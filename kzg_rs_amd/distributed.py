@@ -63,8 +63,10 @@ class HipBackend:
         """r of n_batches batches (32 little-endian bytes each) from records laid out [n_batches][n_local] (world = 0)
         or [world][n_batches][n_local] (world > 0); `records` is bytes or a host address."""
         out = C.create_string_buffer(32 * n_batches)
-        src = C.cast(C.c_char_p(records), C.c_void_p) if isinstance(records, (bytes, bytearray)) else C.c_void_p(records)
+        keep = []
+        src = api._host_ptr(records, 160 * max(world, 1) * n_batches * n_local, "records", keep)
         api._chk(api.lib().kzg_batch_challenges(out, src, world, n_batches, n_local))
+        del keep
         return out.raw
 
     def phase2_r(self, r_le, n_total, offset, n_local):

@@ -307,3 +307,73 @@ def test_throughput_layout_special_batches():
     torch.cuda.synchronize()
     got = api.verify_blob_kzg_proof_batches_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, B, st)
     assert got == want
+
+
+def test_launch_group_of_65536_blobs_with_poisoned_batches():
+    """The benchmarked shape, unforced: ONE launch group of 64 batches x 1 024 blobs = 65 536 blobs (8 GiB) - above the
+    49 152-blob switch to the throughput-form challenge kernel (k_blob_challenge, one lane per blob), with the merged-chunk
+    MSM blocks (>= 32 batches) and the one-wave pairing program (> 32 instances), none of them forced by an environment
+    variable.  Every batch is a different permutation of 1 024 valid tuples; three batches are poisoned:
+        batch 11: a valid G1 point that is not its blob's proof          -> false   (src/kzg_proof.rs:436-444)
+        batch 29: a field element equal to r in one blob                  -> Err     (src/dtypes.rs:48-57)
+        batch 47: a commitment on the curve but outside G1                -> Err     (src/kzg_proof.rs:17-25)
+    all other 61 batches -> true.  16 (z, y) records spread over the group (first and last blob included, one from each
+    poisoned batch that still has a record) are compared with the oracle, and the whole group again through the
+    launch/wait phases gives the same results."""
+    import torch
+    from kzg_rs_amd import synth
+    from kzg_rs_amd.distributed import HipBackend
+    n, B = 1024, 64
+    NOT_IN_G1 = bytes.fromhex("8123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef0123456789abcdef")
+    blobs, cs, ps, st = synth.make_valid_batch(n, seed=99, chunk=1024)
+    ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])
+    with pytest.raises(O.OracleError):
+        O.g1_decompress(NOT_IN_G1)
+    gen = torch.Generator(device="cpu").manual_seed(12)
+    perms = [torch.randperm(n, generator=gen) for _ in range(B)]
+    order = torch.cat(perms)
+    idx = order.cuda()
+    d_blobs = torch.from_numpy(blobs).cuda()[idx].contiguous()  # 8 GiB
+    d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).cuda().view(n, 48)[idx].contiguous()
+    d_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).cuda().view(n, 48)[idx].contiguous()
+    bf, be, bs = 11, 29, 47
+    i_f, i_e, i_s = bf * n + 500, be * n + 1023, bs * n
+    d_p[i_f] = d_p[i_f + 1]  # another blob's proof
+    d_blobs[i_e, 4064:4096] = torch.tensor(list(R.to_bytes(32, "big")), dtype=torch.uint8, device="cuda")
+    d_c[i_s] = torch.tensor(list(NOT_IN_G1), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    res = api.verify_blob_kzg_proof_batches_device(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, B, st)
+    want = [True] * B
+    want[bf], want[be], want[bs] = False, None, None
+    assert res == want
+    # the oracle agrees on the three poisoned batches (1 024 blobs each: a few seconds of CPU per batch on 8 threads)
+    host_c, host_p = d_c.cpu().numpy(), d_p.cpu().numpy()
+    for b in (bf, be, bs):
+        o = order[b * n: (b + 1) * n].tolist()
+        bl = [blobs[j].tobytes() for j in o]
+        if b == be:
+            x = bytearray(bl[1023])
+            x[4064:4096] = R.to_bytes(32, "big")
+            bl[1023] = bytes(x)
+        cc = [host_c[b * n + k].tobytes() for k in range(n)]
+        pp = [host_p[b * n + k].tobytes() for k in range(n)]
+        try:
+            ores = O.verify_blob_kzg_proof_batch(bl, cc, pp, ost, nthreads=8)
+        except O.OracleError:
+            ores = None
+        assert ores == want[b], b
+    # records of the same group through the launch / wait phases: (z, y) of 16 blobs against the oracle
+    hb = HipBackend(st)
+    hb.phase1_launch((d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n), B)
+    recs = hb.phase1_wait()
+    assert hb.bad == [w is None for w in want]
+    sample = [0, 1, 63, 64, 1023, 1024, i_f, i_f + 1, be * n, i_s + 1, 31 * n + 17, 40000, 49151, 49152, 65000, n * B - 1]
+    for i in sample:
+        j = int(order[i])
+        z = O.compute_challenge(blobs[j].tobytes(), host_c[i].tobytes())
+        y = O.evaluate_polynomial_in_evaluation_form(blobs[j].tobytes(), z, ost)
+        assert recs[160 * i: 160 * i + 160] == host_c[i].tobytes() + z[::-1] + y[::-1] + host_p[i].tobytes(), i
+    hb.phase2_launch(None, n, 0)
+    hb.finish_launch(None, 1)
+    got = hb.finish_wait()
+    assert [None if e else r for r, e in zip(got, hb.bad)] == want

@@ -1,0 +1,215 @@
+"""Multi-GPU behind the reference's own signature (include/kzg_rs_amd.h: kzg_settings_*_devices, capi_multi.hpp).
+
+One process, one settings handle over a device list; KzgProof::verify_blob_kzg_proof_batch (src/kzg_proof.rs:472-525)
+through the UNCHANGED entry points shards the batch by blob over the list.  The test box has one GPU, so the list names
+device 0 several times - logical shards with their own handles, streams, workspaces, power offsets r^offset, partial sums,
+fold and pairing; the partial sums then travel through host memory (ncclCommInitAll refuses duplicate devices).  The
+in-process RCCL exchange itself (dlopen, communicator, ncclAllGather on the library's stream, fold from the gathered
+buffer) runs in a child process over a list of ONE device (KZG_MULTI_FORCE=1).  Every result is compared with the oracle.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+G1_GEN = bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import golden_data as G
+    import oracle_lib as O
+    from kzg_rs_amd import api
+
+    os.environ["KZG_MULTI_MIN_BLOBS"] = "2"  # read when a handle is made: shard even the 7-blob mainnet batches
+    st3 = api.KzgSettings.load_trusted_setup_file(devices=[0, 0, 0])
+    st1 = api.KzgSettings.load_trusted_setup_file()
+    os.environ.pop("KZG_MULTI_MIN_BLOBS")
+    return {"torch": torch, "G": G, "O": O, "api": api, "st3": st3, "st1": st1, "ost": O.Settings.mainnet()}
+
+
+def _mainnet(G):
+    return [list(x) for x in zip(*G.valid_blob_tuples())]
+
+
+def _call(api, blobs, cs, ps, st):
+    return api.KzgProof.verify_blob_kzg_proof_batch([api.Blob(b) for b in blobs], [api.Bytes48(c) for c in cs], [api.Bytes48(p) for p in ps], st)
+
+
+def test_handle_shape(env):
+    api = env["api"]
+    devs, ex = env["st3"].devices()
+    assert devs == [0, 0, 0] and ex == "host"
+    assert env["st1"].devices() == ([0], "none")
+    # the multi-device handle is a complete single-device handle as well: settings accessors, single proofs
+    assert env["st3"].root_of_unity(1) == env["st1"].root_of_unity(1)
+    assert env["st3"].g1_point(5) == env["st1"].g1_point(5)
+    with pytest.raises(api.KzgError):
+        api.KzgSettings.from_tau_g2(env["st1"].tau_g2(), devices=[0, 99])
+
+
+def test_mainnet_batches_sharded_over_three_logical_devices(env):
+    """7 blobs over 3 shards (3 + 2 + 2, an uneven split): valid, corrupted proof -> False, non-canonical element ->
+    Err, off-curve commitment -> Err, each equal to the oracle and to the single-device handle."""
+    api, O, G = env["api"], env["O"], env["G"]
+    blobs, cs, ps = _mainnet(G)
+    assert _call(api, blobs, cs, ps, env["st3"]) is True is O.verify_blob_kzg_proof_batch(blobs, cs, ps, env["ost"])
+    t = env["st3"].multi_last_timings()
+    assert t[0] > 0 and t[1] > 0  # the call went through the shards
+    for where in (0, 3, 6):  # a corrupted proof in each shard
+        p2 = list(ps)
+        p2[where] = O.g1_add(ps[where], G1_GEN)
+        assert _call(api, blobs, cs, p2, env["st3"]) is False is O.verify_blob_kzg_proof_batch(blobs, cs, p2, env["ost"])
+        assert _call(api, blobs, cs, p2, env["st1"]) is False
+    for where in (1, 4, 6):  # a non-canonical field element in each shard
+        b2 = list(blobs)
+        bb = bytearray(b2[where])
+        bb[96:128] = R.to_bytes(32, "big")
+        b2[where] = bytes(bb)
+        with pytest.raises(api.KzgError) as e:
+            _call(api, b2, cs, ps, env["st3"])
+        assert e.value.kind == "BadArgs"
+        with pytest.raises(O.OracleError):
+            O.verify_blob_kzg_proof_batch(b2, cs, ps, env["ost"])
+    c2 = list(cs)
+    c2[5] = bytes([c2[5][0]]) + bytes(46) + b"\x01"  # x = 1 is not on the curve
+    with pytest.raises(api.KzgError):
+        _call(api, blobs, c2, ps, env["st3"])
+    # rotations: every blob visits every shard and every power offset
+    for rot in range(1, 7):
+        b, c, p = (x[rot:] + x[:rot] for x in (blobs, cs, ps))
+        assert _call(api, b, c, p, env["st3"]) is True
+
+
+def test_all_committed_batch_vectors_through_the_sharded_handle(env):
+    """The 24 c-kzg-4844 batch vectors the reference ships (tests/golden), strict null <=> Err, through three shards."""
+    api, G = env["api"], env["G"]
+    seen = 0
+    for c in G.vectors()["verify_blob_kzg_proof_batch"]:
+        try:
+            blobs = [api.Blob.from_slice(G.blob(b)) for b in c["blobs"]]
+            cs = [api.Bytes48.from_hex(x) for x in c["commitments"]]
+            ps = [api.Bytes48.from_hex(x) for x in c["proofs"]]
+            got = api.KzgProof.verify_blob_kzg_proof_batch(blobs, cs, ps, env["st3"])
+        except api.KzgError:
+            got = None
+        assert got == c["output"], c["name"]
+        seen += 1
+    assert seen == 24
+
+
+def test_fewer_blobs_than_shards_and_single_blob(env):
+    api, O, G = env["api"], env["O"], env["G"]
+    blobs, cs, ps = _mainnet(G)
+    # 2 blobs over 3 shards: the last shard is empty
+    assert _call(api, blobs[2:4], cs[2:4], ps[2:4], env["st3"]) is True
+    p2 = [ps[2], O.g1_add(ps[3], G1_GEN)]
+    assert _call(api, blobs[2:4], cs[2:4], p2, env["st3"]) is False is O.verify_blob_kzg_proof_batch(blobs[2:4], cs[2:4], p2, env["ost"])
+    # 1 blob: the single-blob branch (src/kzg_proof.rs:482-489) on the first device
+    assert _call(api, blobs[4:5], cs[4:5], ps[4:5], env["st3"]) is True
+    assert _call(api, [], [], [], env["st3"]) is True
+
+
+def test_synthetic_batch_host_device_and_per_device_shards(env):
+    """300 synthetic blobs under the known-tau setup: the host form, the device form (arrays on the first device) and the
+    per-device form (three resident shards of 128 + 100 + 72 blobs) against the oracle; a corrupted proof in the last
+    shard; z / y of the records unaffected by sharding is implied by the equality of the boolean on the corrupted batch."""
+    import ctypes as C
+    api, O, torch = env["api"], env["O"], env["torch"]
+    from kzg_rs_amd import synth
+
+    n = 300
+    blobs, cs, ps, sst = synth.make_valid_batch(n, seed=4242)
+    os.environ["KZG_MULTI_MIN_BLOBS"] = "2"
+    st3 = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1], devices=[0, 0, 0])
+    os.environ.pop("KZG_MULTI_MIN_BLOBS")
+    ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])
+    bl = [blobs[i].tobytes() for i in range(n)]
+    assert O.verify_blob_kzg_proof_batch(bl, cs, ps, ost) is True
+    ok = C.c_bool(False)
+    L = api.lib()
+    hc, hp = b"".join(cs), b"".join(ps)
+    api._chk(L.kzg_verify_blob_kzg_proof_batch(C.byref(ok), blobs.ctypes.data_as(C.c_char_p), hc, hp, n, st3._h))
+    assert ok.value is True
+    bad = list(ps)
+    bad[290] = O.g1_add(ps[290], G1_GEN)
+    hb = b"".join(bad)
+    api._chk(L.kzg_verify_blob_kzg_proof_batch(C.byref(ok), blobs.ctypes.data_as(C.c_char_p), hc, hb, n, st3._h))
+    assert ok.value is False and O.verify_blob_kzg_proof_batch(bl, cs, bad, ost) is False
+    # device form
+    d_b = torch.from_numpy(blobs).cuda()
+    d_c = torch.frombuffer(bytearray(hc), dtype=torch.uint8).cuda()
+    d_p = torch.frombuffer(bytearray(hp), dtype=torch.uint8).cuda()
+    d_pb = torch.frombuffer(bytearray(hb), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    assert api.KzgProof.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, st3) is True
+    assert api.KzgProof.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_pb.data_ptr(), n, st3) is False
+    assert api.KzgProof.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_pb.data_ptr(), n, sst) is False
+    # per-device resident shards of unequal size, one of them empty in a second call
+    cuts = [0, 128, 228, 300]
+
+    def shards(dp, cuts):
+        return [(d_b.data_ptr() + 131072 * lo, d_c.data_ptr() + 48 * lo, dp.data_ptr() + 48 * lo, hi - lo) for lo, hi in zip(cuts, cuts[1:])]
+
+    assert api.verify_blob_kzg_proof_batch_sharded(shards(d_p, cuts), st3) is True
+    assert api.verify_blob_kzg_proof_batch_sharded(shards(d_pb, cuts), st3) is False
+    assert api.verify_blob_kzg_proof_batch_sharded(shards(d_p, [0, 0, 150, 300]), st3) is True
+    assert api.verify_blob_kzg_proof_batch_sharded(shards(d_pb, [0, 300, 300, 300]), st3) is False
+    with pytest.raises(api.KzgError):  # one shard per device of the handle
+        api.verify_blob_kzg_proof_batch_sharded(shards(d_p, [0, 150, 300]), st3)
+    st3.close()
+
+
+_RCCL_CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+import torch
+import golden_data as G, oracle_lib as O
+from kzg_rs_amd import api
+st = api.KzgSettings.load_trusted_setup_file(devices=[0])
+devs, ex = st.devices()
+assert devs == [0] and ex == "rccl", (devs, ex)
+blobs, cs, ps = [list(x) for x in zip(*G.valid_blob_tuples())]
+call = lambda p: api.KzgProof.verify_blob_kzg_proof_batch([api.Blob(b) for b in blobs], [api.Bytes48(c) for c in cs], [api.Bytes48(x) for x in p], st)
+assert call(ps) is True
+assert st.multi_last_timings()[0] > 0
+g = bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+p2 = list(ps); p2[3] = O.g1_add(ps[3], g)
+assert call(p2) is False
+st.close()
+print("rccl-exchange-ok")
+"""
+
+
+def test_in_process_rccl_exchange_world_of_one():
+    """The RCCL leg of the exchange on the one-GPU box: a device list of one entry forced through the sharded path
+    (KZG_MULTI_FORCE=1, KZG_MULTI_EXCHANGE=rccl makes a fallback to host staging an error) - librccl bound at run time,
+    ncclCommInitAll, the warm-up collective, ncclAllGather of the 288-byte partial sums on the library's stream, the fold
+    from the gathered device buffer, the pairing."""
+    e = dict(os.environ, KZG_MULTI_FORCE="1", KZG_MULTI_EXCHANGE="rccl", KZG_MULTI_MIN_BLOBS="2")
+    r = subprocess.run([sys.executable, "-c", _RCCL_CHILD % {"root": ROOT, "here": HERE}], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "rccl-exchange-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_env_selected_devices_for_an_unchanged_caller():
+    """KZG_DEVICES in the environment turns the reference-shaped constructor's handle into a multi-device one."""
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch, golden_data as G\n"
+        "from kzg_rs_amd import api\n"
+        "st = api.KzgSettings.load_trusted_setup_file()\n"
+        "assert st.devices() == ([0, 0], 'host'), st.devices()\n"
+        "b, c, p = [list(x) for x in zip(*G.valid_blob_tuples())]\n"
+        "assert api.KzgProof.verify_blob_kzg_proof_batch([api.Blob(x) for x in b], [api.Bytes48(x) for x in c], [api.Bytes48(x) for x in p], st) is True\n"
+        "assert st.multi_last_timings()[0] > 0\n"
+        "print('env-devices-ok')\n" % (ROOT, HERE))
+    e = dict(os.environ, KZG_DEVICES="0,0", KZG_MULTI_MIN_BLOBS="2")
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "env-devices-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
