@@ -477,6 +477,59 @@ def test_pairing_check(settings, osettings):
     assert outcomes == {True, False}
 
 
+def test_pairings_verify_general_g2_arguments(settings, osettings):
+    """pairings_verify(a1, a2, b1, b2) (src/pairings.rs:5-9, src/lib.rs:15) with ARBITRARY G2 points - the public function
+    of the reference, not only the verifier's two fixed G2 arguments: e(a1, a2) == e(b1, b2).  Bilinear identities give
+    true cases ([k]G1, [m]G2) vs ([km]G1, G2) and their perturbations false ones; identity arguments on either side and in
+    either group; the verifier's own orientation (a valid mainnet proof against [tau]G2 and G2); undecodable points are
+    BadArgs.  Every outcome equals the oracle's."""
+    g2, tau_g2 = osettings.g2(0), osettings.g2(1)
+    G2_INF = bytes([0xC0]) + bytes(95)
+    rng = random.Random(77)
+    k, m = rng.randrange(1, R), rng.randrange(1, R)
+    kb, mb, kmb = (x.to_bytes(32, "big") for x in (k, m, k * m % R))
+    kG, kmG, mQ = O.g1_mul(G1_GEN, kb), O.g1_mul(G1_GEN, kmb), O.g2_mul(g2, mb)
+    kQ = O.g2_mul(g2, kb)
+    cases = [
+        (kG, mQ, kmG, g2),            # e(kG, mQ) = e(kmG, Q)
+        (kmG, g2, kG, mQ),            # swapped sides
+        (G1_GEN, mQ, O.g1_mul(G1_GEN, mb), g2),
+        (kG, mQ, kG, g2),             # false
+        (kG, mQ, kmG, mQ),            # false
+        (kG, kQ, O.g1_mul(G1_GEN, (k * k % R).to_bytes(32, "big")), g2),
+        (G1_INF, mQ, G1_INF, g2),     # 1 == 1
+        (G1_INF, mQ, kG, g2),         # 1 == e(kG, Q): false
+        (kG, G2_INF, G1_INF, kQ),     # identity G2 on the left, identity G1 on the right: 1 == 1
+        (kG, G2_INF, kG, g2),         # 1 == e(kG, Q): false
+        (kG, G2_INF, kmG, G2_INF),    # both pairs trivial
+        (kG, mQ, G1_INF, G2_INF),     # e(kG, mQ) == 1: false
+    ]
+    for c in G.vectors()["verify_kzg_proof"]:
+        if c["output"] is True and len(cases) < 16:
+            pi, cm = bytes.fromhex(c["proof"]), bytes.fromhex(c["commitment"])
+            z, y = int(c["z"], 16), int(c["y"], 16)
+            b = O.g1_add(O.g1_add(cm, O.g1_mul(G1_GEN, ((R - y) % R).to_bytes(32, "big"))), O.g1_mul(pi, z.to_bytes(32, "big")))
+            cases.append((pi, tau_g2, b, g2))
+    outcomes = set()
+    for a1, a2, b1, b2 in cases:
+        want = O.pairings_verify(a1, a2, b1, b2)
+        assert api.pairings_verify(a1, a2, b1, b2, settings) == want, (a1.hex(), a2.hex()[:16])
+        outcomes.add(want)
+    assert outcomes == {True, False}
+    # undecodable arguments: x = 1 is not on either curve's x range for these flags / junk flag bits
+    bad_g1 = bytes([0x80]) + bytes(46) + b"\x01"
+    bad_g2 = bytes([0xE0]) + bytes(95)
+    for args in ((bad_g1, mQ, kmG, g2), (kG, bad_g2, kmG, g2), (kG, mQ, bytes(48), g2), (kG, mQ, kmG, bytes(96))):
+        with pytest.raises(api.KzgError) as e:
+            api.pairings_verify(*args, settings)
+        assert e.value.kind == "BadArgs"
+        with pytest.raises(O.OracleError):
+            O.pairings_verify(*args)
+    with pytest.raises(api.KzgError) as e:
+        api.pairings_verify(kG[:47], mQ, kmG, g2, settings)
+    assert e.value.kind == "InvalidBytesLength"
+
+
 @pytest.mark.parametrize("form", ["1", "2"])
 def test_pairing_forms_in_child_process(form):
     """Both pairing programs on the GPU, each forced for a whole process (KZG_PAIRING=1: the one-wave throughput program
