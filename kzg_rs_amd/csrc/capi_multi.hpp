@@ -221,11 +221,10 @@ static KzgRet multi_batch_locked(bool* ok, const std::vector<ShardIn>& in, Multi
             Workspace& w = c->ws;
             select_streams(c, nk);
             const void *db = in[k].blobs, *dc = in[k].c, *dp = in[k].p;
+            const HostBatch hb{in[k].blobs, in[k].c, in[k].p};
             if (copy) {
                 if (kind == MultiSrc::Host) {
-                    HIPCHK(hipMemcpyAsync(w.d_stage_cp, in[k].c, 48 * nk, hipMemcpyHostToDevice, c->s1));
-                    HIPCHK(hipMemcpyAsync(w.d_stage_cp + 48 * nk, in[k].p, 48 * nk, hipMemcpyHostToDevice, c->s1));
-                    HIPCHK(hipMemcpyAsync(w.d_stage_blobs, in[k].blobs, (size_t)BLOB_BYTES * nk, hipMemcpyHostToDevice, c->s1));
+                    // phase 1 brings the shard over itself, in slices across its blobs (capi_verify.hpp host_slices)
                 } else {  // resident on the first device: the slice crosses xGMI (a caller that can should hand over per-device shards)
                     HIPCHK(hipMemcpyPeerAsync(w.d_stage_cp, c->device, in[k].c, s->device, 48 * nk, c->s1));
                     HIPCHK(hipMemcpyPeerAsync(w.d_stage_cp + 48 * nk, c->device, in[k].p, s->device, 48 * nk, c->s1));
@@ -235,13 +234,14 @@ static KzgRet multi_batch_locked(bool* ok, const std::vector<ShardIn>& in, Multi
                 dc = w.d_stage_cp;
                 dp = w.d_stage_cp + 48 * nk;
             }
-            if ((rc = phase1_launch_locked(db, dc, dp, nk, 1, c)) != KZG_OK) return rc;
+            if ((rc = phase1_launch_locked(db, dc, dp, nk, 1, c, kind == MultiSrc::Host ? &hb : nullptr)) != KZG_OK) return rc;
             return phase1_wait_locked(records.data() + 160 * off[k], &bad[k], c);
         };
         rcs[k] = body();
         if (rcs[k] != KZG_OK) {
             msgs[k] = g_err;
             (void)hipStreamSynchronize(c->s1);  // nothing of this shard stays in flight behind an error
+            if (c->s_copy) (void)hipStreamSynchronize(c->s_copy);
             (void)hipGetLastError();
         }
     };

@@ -13,9 +13,24 @@ extern "C" KzgRet kzg_compute_challenges(uint8_t* z_out, const uint8_t* blobs, c
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     select_streams(s, n);  // before the staging copies: they must be on the stream the kernels of this launch run on
-    HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
-    HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
-    if ((rc = launch_challenge(s, w.d_stage_blobs, w.d_stage_cp, w.d_z, n)) != KZG_OK) return rc;
+    const unsigned S = host_slices(n);
+    if (S > 1) {  // the same sliced hand-over as the batch entry point (capi_verify.hpp): segments of the chain behind the slices
+        const HostBatch host{blobs, commitments, nullptr};
+        HIPCHK(hipEventRecord(s->ev[0], s->s1));
+        if ((rc = sliced_points_copy(s, host, w.d_stage_cp, nullptr, n, s->ev[0])) != KZG_OK ||
+            (rc = sliced_segments(s, host, w.d_stage_blobs, w.d_stage_cp, w.d_z, n, S, s->s1)) != KZG_OK) {
+            const std::string msg = g_err;
+            (void)hipStreamSynchronize(s->s_copy);
+            (void)hipStreamSynchronize(s->s1);
+            (void)hipGetLastError();
+            g_err = msg;
+            return rc;
+        }
+    } else {
+        HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
+        HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
+        if ((rc = launch_challenge(s, w.d_stage_blobs, w.d_stage_cp, w.d_z, n)) != KZG_OK) return rc;
+    }
     HIPCHK(hipMemcpyAsync(w.h_buf, w.d_z, 32 * n, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
     for (size_t i = 0; i < n; i++) reverse32(z_out + 32 * i, w.h_buf + 32 * i);

@@ -16,6 +16,7 @@ constexpr size_t MAX_WORLD = 64;
 constexpr size_t LATENCY_PAIRING_MAX = 32;  // launches of up to this many pairing checks run the multi-wave latency program
 constexpr size_t MAX_BATCHES_PER_LAUNCH = 16384;
 constexpr unsigned MSM_MAX_SLICES = 32;
+constexpr size_t SLICED_MAX_BLOBS = 16384;  // host batches up to this size arrive in slices across the blobs (the range of the two-lane challenge form, which runs in segments)
 constexpr size_t LATENCY_MAX_BLOBS = 4096;  // launches up to this size: CU-split stream pair + the latency MSM layout
 struct Workspace {
     size_t cap_n = 0;       // batch capacity
@@ -37,6 +38,7 @@ struct Workspace {
     bool mult_affine = false;      // format of d_mult as the last decode left it
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
     uint8_t *d_stage_blobs = nullptr, *d_stage_cp = nullptr, *d_bytes = nullptr, *d_records = nullptr;
+    uint32_t* d_sha_mid = nullptr;  // SHA-256 midstates between the segments of a sliced challenge chain, 32 B per blob
     // host-fed stream of batches (kzg_verify_blob_kzg_proof_batches): two staging sets, each [blobs | commitments | proofs]
     // of one chunk, filled on the copy stream while the other one is verified
     uint8_t* d_hstage[2] = {nullptr, nullptr};
@@ -80,6 +82,7 @@ struct KzgSettings {
     hipEvent_t ev[12] = {};
     mutable hipStream_t s_copy = nullptr;  // host -> device staging copies of the host-fed stream (made on first use)
     mutable hipEvent_t ev_copy[2] = {nullptr, nullptr};
+    mutable hipEvent_t ev_slice[17] = {};  // a host Vec<Blob> arriving in slices: [0] commitments + proofs landed, [1 + j] slice j landed
     mutable std::mutex mu;
     mutable Workspace ws;
     mutable uint32_t* d_eval_scratch = nullptr;  // between the three evaluation kernels (launch_evaluate)
@@ -443,7 +446,7 @@ extern "C" KzgRet kzg_settings_from_tau_g2_devices(KzgSettings** out, const uint
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
                     w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_mult, w.d_jtmp, w.d_ktime, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
-                    w.d_records, w.d_hstage[0], w.d_hstage[1], w.d_msm_save};
+                    w.d_records, w.d_hstage[0], w.d_hstage[1], w.d_msm_save, w.d_sha_mid};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w.h_buf) (void)hipHostFree(w.h_buf);
@@ -463,6 +466,8 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : s->ev_copy)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : s->ev_slice)
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {s->s_plain[0], s->s_plain[1], s->s_half[0], s->s_half[1], s->s_copy})
         if (st) (void)hipStreamDestroy(st);

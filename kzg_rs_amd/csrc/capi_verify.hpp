@@ -64,7 +64,7 @@ static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const 
     } else if (form == 2) {
         hipLaunchKernelGGL(k_blob_challenge_split, dim3((unsigned)((T + 63) / 64)), dim3(128), 0, st, bl, cm, d_z, (int)T);
     } else {
-        hipLaunchKernelGGL(k_blob_challenge_split2, dim3((unsigned)((T + 63) / 64)), dim3(192), 0, st, bl, cm, d_z, (int)T);
+        hipLaunchKernelGGL(k_blob_challenge_split2_t<false>, dim3((unsigned)((T + 63) / 64)), dim3(192), 0, st, bl, cm, d_z, (int)T, 0, 1024, (uint32_t*)nullptr);
     }
     HIPCHK(hipGetLastError());
     return KZG_OK;
@@ -115,6 +115,7 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, int stage) {
         HIPCHK(hipMalloc(&w.d_slp_out, sizeof(Fp) * 6 * capB));
         HIPCHK(hipMalloc(&w.d_bytes, 96 * np));
         HIPCHK(hipMalloc(&w.d_records, 160 * capT));
+        HIPCHK(hipMalloc(&w.d_sha_mid, 32 * std::min(capT, (size_t)SLICED_MAX_BLOBS)));
         w.off_r = 256 * capT + 4096;                 // pinned layout: [per-blob area | r | own partials | out | gathered partials]
         w.off_part = w.off_r + 32 * capB;
         w.off_out = w.off_part + 288 * capB;
@@ -193,6 +194,12 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     d.stride = 2 * T + 1;
     d.chunks = w.chunks;
     d.chunks_per_block = w.chunks == MSM_CHUNKS ? msm_chunks_per_block(B) : 1;
+    static const int msm_flags = [] {  // KZG_MSM_ROTATE=0 / KZG_MSM_XCD=0: A/B measurement of the two placements (msm.hpp MSM_FLAG_*)
+        const char *r = getenv("KZG_MSM_ROTATE"), *x = getenv("KZG_MSM_XCD");
+        // measured (profiles/r3_ab_msm.txt): XCD placement +2 % throughput; the rotation LOSES 6 % of the kernel - off unless asked for
+        return ((r && r[0] == '1') ? MSM_FLAG_ROTATE : 0) | ((x && x[0] == '0') ? 0 : MSM_FLAG_XCD);
+    }();
+    d.flags = msm_flags;
     const unsigned slots = d.chunks / d.chunks_per_block, W = MSM_WINDOWS / d.chunks;
     // one large batch: slice the terms of an output over several workgroups until the launch has ~1000 of them
     // (each slice keeps >= 1024 terms of the smaller output)
@@ -358,16 +365,90 @@ static void select_streams(const KzgSettings* s, size_t T) {
     s->s2 = use_half ? s->s_half[1] : s->s_plain[1];
 }
 
+// A batch that still lies in HOST memory (the by-value Vec<Blob> of src/kzg_proof.rs:472-477; pageable): phase 1 brings it
+// over itself, into the staging buffers it is given as d_blobs / d_commitments / d_proofs.
+struct HostBatch {
+    const uint8_t *blobs, *commitments, *proofs;
+};
+// In how many slices ACROSS the blobs (slice j = bytes [j W, (j + 1) W) of every blob, W = 128 KiB / S) a host batch of n
+// blobs crosses PCIe.  One copy of the whole array first and the 2.8 ms SHA-256 chains after it cost copy + chain; SHA-256
+// consumes a blob front to back, so the chain's segment j (k_blob_challenge_split2_t<true>) runs while slice j + 1 is on the
+// link and the call costs ~ copy + chain / S.  Measured on MI355X (profiles/r3_hostslicebench.txt): hipMemcpy2DAsync from
+// pageable memory returns at once and 8 slices of a 128 MiB batch land 0.31 ms apart, 2.44 ms in all against 2.38 ms for
+// one copy.  A slice costs a dispatch and an event wait (~20 us): small batches take fewer.  KZG_HOST_SLICES = 1 | 2 | 4 |
+// 8 | 16 forces S (1: one copy, the round-2 behaviour).
+static unsigned host_slices(size_t n) {
+    static const unsigned forced = [] {
+        const char* e = getenv("KZG_HOST_SLICES");
+        const unsigned v = e ? (unsigned)atoi(e) : 0;
+        return v == 1 || v == 2 || v == 4 || v == 8 || v == 16 ? v : 0u;
+    }();
+    static const bool lane_forced = getenv("KZG_CHALLENGE_KERNEL") && strcmp(getenv("KZG_CHALLENGE_KERNEL"), "split2") != 0;
+    if (n > SLICED_MAX_BLOBS || lane_forced) return 1;
+    if (forced) return forced;
+    return n >= 512 ? 8 : n >= 128 ? 4 : 1;
+}
+
+// A sliced hand-over, in two steps.  The copies run on the handle's copy stream, the chain's segments on stream st.
+// ORDER OF THE HOST CALLS MATTERS: a wait on an event of the copy stream is issued right after the event is recorded and
+// BEFORE the next copy is enqueued there.  With all eight slice copies enqueued first and the waits issued afterwards, every
+// waiting kernel (the point decode behind the 96-KB copy included) started only when the LAST slice had landed
+// (profiles/r3_host_timeline.txt, first form: copies 0.08 .. 2.65 ms, first kernel at 2.67 ms) - the runtime resolves such a
+// wait against what the copy stream holds when the wait is made, not against the recorded point.
+//   sliced_points_copy: commitments and proofs (96 bytes per blob; d_proofs may be null) -> ev_slice[0]; the copy stream first
+//                       waits for `after`, an event of the stream whose earlier work used the staging buffers
+//   sliced_segments:    for j < S: slice j of every blob -> ev_slice[1 + j], st waits for it, segment j of the chains
+static KzgRet sliced_points_copy(const KzgSettings* s, const HostBatch& host, void* d_commitments, void* d_proofs, size_t T, hipEvent_t after) {
+    if (!s->s_copy) {
+        HIPCHK(hipStreamCreateWithFlags(&s->s_copy, hipStreamNonBlocking));
+        for (auto& e : s->ev_copy) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (!s->ev_slice[0])
+        for (auto& e : s->ev_slice) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipStreamWaitEvent(s->s_copy, after, 0));
+    HIPCHK(hipMemcpyAsync(d_commitments, host.commitments, 48 * T, hipMemcpyHostToDevice, s->s_copy));
+    if (d_proofs) HIPCHK(hipMemcpyAsync(d_proofs, host.proofs, 48 * T, hipMemcpyHostToDevice, s->s_copy));
+    HIPCHK(hipEventRecord(s->ev_slice[0], s->s_copy));
+    return KZG_OK;
+}
+static KzgRet sliced_segments(const KzgSettings* s, const HostBatch& host, void* d_blobs, const void* d_commitments, Fr* d_z, size_t T, unsigned S,
+                              hipStream_t st) {
+    s->ws.ktime_valid = false;
+    HIPCHK(hipStreamWaitEvent(st, s->ev_slice[0], 0));  // (the last segment reads the commitments)
+    const size_t W = (size_t)BLOB_BYTES / S;
+    for (unsigned j = 0; j < S; j++) {
+        HIPCHK(hipMemcpy2DAsync((uint8_t*)d_blobs + j * W, BLOB_BYTES, host.blobs + j * W, BLOB_BYTES, W, T, hipMemcpyHostToDevice, s->s_copy));
+        HIPCHK(hipEventRecord(s->ev_slice[1 + j], s->s_copy));
+        HIPCHK(hipStreamWaitEvent(st, s->ev_slice[1 + j], 0));
+        hipLaunchKernelGGL(k_blob_challenge_split2_t<true>, dim3((unsigned)((T + 63) / 64)), dim3(192), 0, st, (const uint8_t*)d_blobs,
+                           (const uint8_t*)d_commitments, d_z, (int)T, (int)(1024 / S * j), (int)(1024 / S * (j + 1)), s->ws.d_sha_mid);
+    }
+    HIPCHK(hipGetLastError());
+    return KZG_OK;
+}
+
 // Phase 1 (no communication): point decode + multiples || (challenge -> evaluate) for all T = B n blobs.
 static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n, size_t B,
-                                   const KzgSettings* s) {
+                                   const KzgSettings* s, const HostBatch* host = nullptr) {
     if (B > MAX_BATCHES_PER_LAUNCH) return fail(KZG_BADARGS, "more than 16384 batches in one launch group");  // gridDim.z = 2 B
     Workspace& w = s->ws;
     const size_t T = n * B;
     KzgRet rc;
     select_streams(s, T);
+    const unsigned S = host ? host_slices(T) : 1;
     HIPCHK(hipEventRecord(s->ev[0], s->s1));
-    HIPCHK(hipStreamWaitEvent(s->s2, s->ev[0], 0));
+    if (host && S == 1) {  // one copy of everything, on the stream the kernels follow on
+        HIPCHK(hipMemcpyAsync(const_cast<void*>(d_commitments), host->commitments, 48 * T, hipMemcpyHostToDevice, s->s1));
+        HIPCHK(hipMemcpyAsync(const_cast<void*>(d_proofs), host->proofs, 48 * T, hipMemcpyHostToDevice, s->s1));
+        HIPCHK(hipMemcpyAsync(const_cast<void*>(d_blobs), host->blobs, (size_t)BLOB_BYTES * T, hipMemcpyHostToDevice, s->s1));
+        HIPCHK(hipEventRecord(s->ev[0], s->s1));  // (the kernels' interval starts when the data is there, as before)
+    }
+    if (host && S > 1) {
+        if ((rc = sliced_points_copy(s, *host, const_cast<void*>(d_commitments), const_cast<void*>(d_proofs), T, s->ev[0])) != KZG_OK) return rc;
+        HIPCHK(hipStreamWaitEvent(s->s2, s->ev_slice[0], 0));  // the point decode starts while the blobs are still crossing
+    } else {
+        HIPCHK(hipStreamWaitEvent(s->s2, s->ev[0], 0));
+    }
     HIPCHK(hipEventRecord(s->ev[5], s->s2));
     if ((rc = launch_decode(s, d_commitments, d_proofs, T)) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[6], s->s2));
@@ -376,7 +457,9 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
         HIPCHK(hipEventRecord(s->ev[11], s->s1));
         HIPCHK(hipStreamWaitEvent(s->s_sha, s->ev[11], 0));
     }
-    if ((rc = launch_challenge(s, d_blobs, d_commitments, w.d_z, T, s->s_sha)) != KZG_OK) return rc;
+    if (host && S > 1) {
+        if ((rc = sliced_segments(s, *host, const_cast<void*>(d_blobs), d_commitments, w.d_z, T, S, s->s_sha)) != KZG_OK) return rc;
+    } else if ((rc = launch_challenge(s, d_blobs, d_commitments, w.d_z, T, s->s_sha)) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[7], s->s_sha));
     if (s->s_sha != s->s1) {  // both joins in one place: each wait on another stream's event is a ~13 us bubble, even when it has long fired
         HIPCHK(hipStreamWaitEvent(s->s1, s->ev[7], 0));
@@ -533,9 +616,9 @@ static KzgRet finish_wait_locked(bool* ok /* B */, const KzgSettings* s) {
 }
 
 static KzgRet batch_device_locked(bool* ok, const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n,
-                                  const KzgSettings* s) {
+                                  const KzgSettings* s, const HostBatch* host = nullptr) {
     KzgRet rc;
-    if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, 1, s)) != KZG_OK) return rc;
+    if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, 1, s, host)) != KZG_OK) return rc;
     if ((rc = phase1_wait_locked(nullptr, nullptr, s)) != KZG_OK) return rc;
     if ((rc = phase2_launch_locked(nullptr, n, 0, s, 0, nullptr, false)) != KZG_OK) return rc;
     if ((rc = finish_launch_locked(nullptr, 1, 1, s)) != KZG_OK) return rc;  // same stream: no host round trip needed
@@ -693,11 +776,15 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
     KzgRet rc = ws_reserve(s, n, 1, STAGE_BLOBS);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
-    select_streams(s, n);  // before the staging copies: they must be on the stream the kernels of this launch run on
-    HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, (size_t)BLOB_BYTES * n, hipMemcpyHostToDevice, s->s1));
-    HIPCHK(hipMemcpyAsync(w.d_stage_cp, commitments, 48 * n, hipMemcpyHostToDevice, s->s1));
-    HIPCHK(hipMemcpyAsync(w.d_stage_cp + 48 * n, proofs, 48 * n, hipMemcpyHostToDevice, s->s1));
-    return batch_device_locked(ok, w.d_stage_blobs, w.d_stage_cp, w.d_stage_cp + 48 * n, n, s);
+    const HostBatch host{blobs, commitments, proofs};  // phase 1 brings the batch over, in slices across the blobs (host_slices)
+    rc = batch_device_locked(ok, w.d_stage_blobs, w.d_stage_cp, w.d_stage_cp + 48 * n, n, s, &host);
+    if (rc != KZG_OK && s->s_copy) {  // nothing may still read the caller's memory when the error goes back
+        const std::string msg = g_err;
+        (void)hipStreamSynchronize(s->s_copy);
+        (void)hipGetLastError();
+        g_err = msg;
+    }
+    return rc;
 }
 
 // A STREAM of host-resident batches: n_batches independent verify_blob_kzg_proof_batch calls (src/kzg_proof.rs:472-525) of n

@@ -275,12 +275,22 @@ __global__ __launch_bounds__(128) void k_blob_challenge_split(const uint8_t* __r
 // one lane of a pair on the a-chain, the lane four further on the e-chain.  ~690 instructions per block on the serial
 // chain instead of ~930.  The (K + W) tile is read by both lanes of a pair at the same address; the even lanes read a row of
 // zeros instead (their sum takes no message word).
-__global__ __launch_bounds__(192) void k_blob_challenge_split2(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
-                                                               Fr* __restrict__ z_out, int n) {
+//
+// SEG = true is the same chain in SEGMENTS, for a blob that is still arriving (capi_verify.hpp: a host Vec<Blob> crosses PCIe
+// in slices ACROSS the blobs - SHA-256 consumes a blob front to back, so lines [m0, m1) of every blob can be hashed while the
+// next slice is on the link): the launch covers the 128-byte lines [m0, m1) of every blob - blocks 2 m0 .. 2 m1 - 1, and
+// the two tail blocks when m1 = 1024.  What travels between two launches is the 32-byte midstate per blob (`mid`, word k of
+// blob i at mid[8 i + k]); the 32 blob bytes a block carries over from the line before are re-read from the slice that has
+// already landed.  SEG = false compiles to the one-launch kernel (m0 = 0, m1 = 1024, no midstate).
+template <bool SEG>
+__global__ __launch_bounds__(192) void k_blob_challenge_split2_t(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
+                                                                 Fr* __restrict__ z_out, int n, int m0_arg, int m1_arg, uint32_t* __restrict__ mid) {
     __shared__ uint4 tile[CHALLENGE_TILE_U4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // 0, 1 consumers; 2 producer
-    constexpr int NBLK = 2050;
+    const int M0 = SEG ? m0_arg : 0, M1 = SEG ? m1_arg : 1024;
+    const bool last_seg = !SEG || M1 == 1024;
+    const int NBLK = 2 * (M1 - M0) + (last_seg ? 2 : 0);
     if (wave == 2) {
         int i = blockIdx.x * 64 + lane;
         if (i >= n) i = n - 1;  // redundant work keeps the barriers uniform
@@ -303,9 +313,13 @@ __global__ __launch_bounds__(192) void k_blob_challenge_split2(const uint8_t* __
         // it from L2 up to eight times once the CU's producers outrun the 32 KiB L1.
         uint4 L[8], c0, c1;
 #pragma unroll
-        for (int j = 0; j < 8; j++) L[j] = blob[j];
+        for (int j = 0; j < 8; j++) L[j] = blob[8 * M0 + j];
+        if (SEG && M0 > 0) {  // the last 32 bytes of line M0 - 1
+            c0 = blob[8 * M0 - 2];
+            c1 = blob[8 * M0 - 1];
+        }
 #pragma unroll 1
-        for (int m = 0; m < 1024; m++) {
+        for (int m = M0; m < M1; m++) {
             uint32_t w[16];
             if (m == 0) {
                 w[0] = 0x4653424c; w[1] = 0x4f425645; w[2] = 0x52494659; w[3] = 0x5f56315f;  // "FSBLOBVERIFY_V1_"
@@ -316,29 +330,29 @@ __global__ __launch_bounds__(192) void k_blob_challenge_split2(const uint8_t* __
             }
             bswap4(w + 8, L[0]);
             bswap4(w + 12, L[1]);
-            emit(w, 2 * m);
+            emit(w, 2 * (m - M0));
             bswap4(w, L[2]); bswap4(w + 4, L[3]); bswap4(w + 8, L[4]); bswap4(w + 12, L[5]);
             c0 = L[6];
             c1 = L[7];
-            if (m + 1 < 1024) {  // the next line, in flight while block 2m + 1 is expanded
+            if (m + 1 < M1) {  // the next line, in flight while block 2m + 1 is expanded (never beyond the segment: it may not have landed)
                 const uint4* p = blob + 8 * (m + 1);
 #pragma unroll
                 for (int j = 0; j < 8; j++) L[j] = p[j];
-            } else {
+            } else if (last_seg) {
                 L[0] = cm[0]; L[1] = cm[1]; L[2] = cm[2];
             }
-            emit(w, 2 * m + 1);
+            emit(w, 2 * (m - M0) + 1);
         }
-        {
+        if (last_seg) {
             uint32_t w[16];
             bswap4(w, c0); bswap4(w + 4, c1); bswap4(w + 8, L[0]); bswap4(w + 12, L[1]);  // blob tail | commitment[0..32)
-            emit(w, 2048);
+            emit(w, 2 * (M1 - M0));
             bswap4(w, L[2]);  // commitment[32..48) + 0x80 pad + bit length
             w[4] = 0x80000000u;
 #pragma unroll
             for (int k = 5; k < 15; k++) w[k] = 0;
             w[15] = 131152u * 8u;
-            emit(w, 2049);
+            emit(w, 2 * (M1 - M0) + 1);
         }
         __syncthreads();
     } else {
@@ -355,6 +369,11 @@ __global__ __launch_bounds__(192) void k_blob_challenge_split2(const uint8_t* __
         // this lane's half of the state: h0..h3 (a-chain) or h4..h7 (e-chain)
         uint32_t H0 = a_lane ? 0x6a09e667u : 0x510e527fu, H1 = a_lane ? 0xbb67ae85u : 0x9b05688cu, H2 = a_lane ? 0x3c6ef372u : 0x1f83d9abu,
                  H3 = a_lane ? 0xa54ff53au : 0x5be0cd19u;
+        uint32_t* my_mid = SEG ? mid + 8 * (size_t)(live ? i : n - 1) + (a_lane ? 0 : 4) : nullptr;
+        if (SEG && M0 > 0) {
+            const uint4 q = *reinterpret_cast<const uint4*>(my_mid);
+            H0 = q.x; H1 = q.y; H2 = q.z; H3 = q.w;
+        }
         __syncthreads();
 #pragma unroll 1
         for (int b = 0; b < NBLK; b++) {
@@ -382,6 +401,10 @@ __global__ __launch_bounds__(192) void k_blob_challenge_split2(const uint8_t* __
             H2 += r.x2;
             H3 += a_lane ? r.dd : r.hk;  // d sits in dd on the a-lanes, h in hk on the e-lanes
             __syncthreads();
+        }
+        if (SEG && !last_seg) {  // the midstate of the chain so far: this lane's four words
+            if (live) *reinterpret_cast<uint4*>(my_mid) = make_uint4(H0, H1, H2, H3);
+            return;
         }
         // the e-lane's words to the a-lane (row_shl:4: lane i reads lane i + 4), which reduces the digest and writes z
         const uint32_t e0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H0, 0x104, 0xF, 0xF, true), e1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)H1, 0x104, 0xF, 0xF, true);

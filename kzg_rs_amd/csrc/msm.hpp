@@ -360,10 +360,21 @@ struct MsmDesc {
                                   // writes per thread)
     int z0;                       // logical blockIdx.z of this launch's first z-layer (a grid too large for the save area
                                   // is launched in pieces)
+    int flags;                    // MSM_FLAG_*
     int chunks_per_block;         // 1: a block per (window, chunk) - most parallel, lowest latency;  4: a block per window
                                   // sums the four chunks' terms into ONE bucket set - a quarter of the reductions and
                                   // fuller, better balanced buckets (throughput mode).  gridDim.y = chunks / chunks_per_block
 };
+
+// MSM_FLAG_ROTATE: which wavefront of a block takes the fullest buckets rotates with the block.  The buckets are handed out
+//   by rank (wavefront 0 the 64 fullest ... wavefront 3 the 64 emptiest) and a workgroup's wavefronts are dealt to the CU's
+//   four SIMDs in order, so without the rotation one SIMD of every CU collects the long bucket lists of every block resident
+//   there and another one the short ones.
+// MSM_FLAG_XCD: the 8 window blocks of one (batch, output) run on the SAME XCD, one after the other in dispatch order - they
+//   read the same table rows (each row once per window), which then come out of that XCD's L2 instead of crossing the fabric 8
+//   times.  Workgroups go to the 8 XCDs round-robin by linear id, so (with gridDim = (8, 1, gz), gz a multiple of 8) the block
+//   with linear id L works on window (L / 8) % 8 of z = (L / 64) * 8 + L % 8.
+constexpr int MSM_FLAG_ROTATE = 1, MSM_FLAG_XCD = 2;
 
 __device__ __forceinline__ void lds_store_jac(uint32_t* base, int slot, const G1Jac& p) {
     uint32_t* d = base + slot * 36;
@@ -802,13 +813,28 @@ struct Curve29Aff : Curve29 {
 // write traffic once the launch's lists outgrow the L2 (measured: 25 M stores -> 3.2 GB written per launch group).
 template <class CV>
 constexpr int msm_lds_sort_capacity() { return MSM_BUCKETS * CV::WORDS; }
+// TWO PASSES (round 3; the radix-2^29 throughput variants - every CV with SPLIT and without QUADS): the window kernel ends
+// with the bucket sums, written to the save area, and k_msm_reduce turns them into the window sum.  In one kernel the 16
+// levels of the reduction ran on one or two of a block's four wavefronts while the block held its 43 KB of LDS - a third
+// of a block's life at a quarter of its lanes (SIMD utilisation of the kernel 58 %: profiles/r2_pmc.json, 7.4 cycles per
+// instruction against 4.3); as a kernel of its own the reduction needs no LDS and no barrier, half the additions, and the
+// bucket kernel's blocks leave as soon as their longest bucket is done.
+template <class CV>
+constexpr bool msm_two_pass() { return CV::SPLIT && !CV::QUADS; }
 template <class CV, bool LDSSORT = false>
 __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window(MsmDesc d) {  // (the latency variant has a CU to itself)
     using Pt = typename CV::Pt;
+    constexpr bool TWOPASS = msm_two_pass<CV>();
     // blockIdx.z = (2*batch + output) * slices + slice
-    const int zz = (int)blockIdx.z + d.z0;  // logical z: (2 batch + output) * slices + slice
+    int zz = (int)blockIdx.z + d.z0;  // logical z: (2 batch + output) * slices + slice
+    int w = blockIdx.x;
+    if ((d.flags & MSM_FLAG_XCD) && gridDim.x == 8 && gridDim.y == 1 && (gridDim.z & 7) == 0) {
+        const unsigned L = blockIdx.x + 8u * blockIdx.z, i = L >> 3;
+        w = (int)(i & 7);
+        zz = (int)((i >> 3) * 8 + (L & 7)) + d.z0;
+    }
     const int S = d.slices, bo = zz / S, slice = zz % S;
-    const int w = blockIdx.x, o = bo & 1, tid = threadIdx.x;
+    const int o = bo & 1, tid = threadIdx.x;
     const int cpb = d.chunks_per_block, j0 = blockIdx.y * cpb;
     const int W = gridDim.x;                                              // windows (digit bytes) per chunk
     const int wi = ((bo * gridDim.y + blockIdx.y) * S + slice) * W + w;  // window slot
@@ -819,7 +845,9 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     __shared__ uint32_t cnt[MSM_BUCKETS], off[MSM_BUCKETS + 1], cur[MSM_BUCKETS];
     __shared__ uint32_t long_buckets[MSM_BUCKETS], n_long;  // (CV::QUADS) buckets with more than MSM_QUADS_BUCKET_CAP entries
     extern __shared__ __attribute__((aligned(16))) uint32_t msm_dyn_lds[];  // (CV::QUADS) quad scratch | second R | C vector
-    __shared__ uint32_t pts[MSM_BUCKETS * CV::WORDS];  // 36 / 42 KiB: one Jacobian point per thread
+    // 36 / 42 KiB: one Jacobian point per thread for the reduction levels; before that the block's sorted term list (LDSSORT).
+    // The two-pass form keeps only the list here.
+    __shared__ uint32_t pts[(TWOPASS && !LDSSORT) ? 1 : MSM_BUCKETS * CV::WORDS];
     uint32_t* const sorted_global = d.sorted + ((size_t)(bo * gridDim.y + blockIdx.y) * W + w) * cpb * d.max_terms + (size_t)cpb * t0;
     // (compile-time choice: an LDS pointer or a global one, never a flat one)
     cnt[tid] = 0;
@@ -869,7 +897,8 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
         cur[rank] = tid;  // cur[] is free after the sort: bucket handled by thread `rank`
     }
     __syncthreads();
-    const int bucket = cur[tid];
+    const int rot = (d.flags & MSM_FLAG_ROTATE) ? (int)((blockIdx.x + blockIdx.z) & 3) : 0;
+    const int bucket = cur[(tid + 64 * rot) & 255];
     const typename CV::Mem* mult = static_cast<const typename CV::Mem*>(d.mult);
     auto sorted_at = [&](uint32_t k) -> uint32_t {
         if constexpr (LDSSORT) return pts[k];
@@ -930,6 +959,19 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     //      kind 1 cols  : dst = 16 (2 s k) + lo, src = dst + 16 s     (ops = 128 / s)   on a fresh copy of the buckets
     //      kind 2 scan  : suffix scan over the two 16-element vectors R (slots 0..15) and C (slots 16..31)
     //      kind 3 tree  : tree sum of the two scanned vectors (slot 0 / 16 of each zeroed first)
+    if constexpr (TWOPASS) {
+        // the bucket sum to the save area, word-major ([WORDS][256] per block; slot = this block's place in the launch):
+        // k_msm_reduce takes it from there
+        const size_t slot = ((size_t)(zz - d.z0) * gridDim.y + blockIdx.y) * W + w;
+        uint32_t* const out = d.save + slot * CV::WORDS * 256 + bucket;
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            out[(size_t)i * 256] = acc.x.l[i];
+            out[(size_t)(14 + i) * 256] = acc.y.l[i];
+            out[(size_t)(28 + i) * 256] = acc.z.l[i];
+        }
+        return;
+    }
     if constexpr (LDSSORT) __syncthreads();  // every list has been read: the region becomes the bucket points
     CV::lds_store(pts, bucket, acc);
     __syncthreads();
@@ -954,7 +996,7 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     // From here on thread tid looks after bucket tid.  The row trees run in place and destroy the bucket sums the column
     // trees need: a copy waits in global memory (d.save; word-major, so a wavefront writes and reads whole lines).
     // R and C get their own small LDS vectors for the scans.
-    __shared__ uint32_t rc[32 * CV::WORDS];  // R_0..R_15 | C_0..C_15
+    __shared__ uint32_t rc[TWOPASS ? 1 : 32 * CV::WORDS];  // R_0..R_15 | C_0..C_15
     uint32_t* const save = d.save + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * CV::WORDS) * 256 + tid;
 #pragma unroll
     for (int i = 0; i < CV::WORDS; i++) save[(size_t)i * 256] = pts[tid * CV::WORDS + i];
@@ -1074,6 +1116,82 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     }
 }
 
+// ---- pass 2 of the two-pass form: sum_b b B_b of one window block from its 256 bucket sums in the save area.
+// b = 16 hi + lo:  16 * sum_hi hi R_hi + sum_lo lo C_lo  with the row sums R_hi and the column sums C_lo of the 16 x 16 bucket
+// matrix.  HALF A WAVEFRONT PER WINDOW BLOCK: lane hi < 16 sums row hi, lane 16 + lo sums column lo - 15 additions each, all
+// 32 lanes busy - then the two weighted sums by a suffix scan and a tree over the 16 lanes of each vector (8 levels, the
+// partner's point fetched with 42 shuffles - no LDS, no barrier), four doublings and one addition on the half's first lane.
+// 28 addition times per two window blocks instead of 21 wave-level additions + 16 barriers per block.
+// The bucket sums are any Jacobian points (empty buckets: the identity, common only in small batches); the rare endings
+// (identity operand, same x) leave the straight-line path through the complete formula, out of line.
+__device__ __noinline__ G1Jac29 g1j29_add_complete_outlined(const G1Jac29& p, const G1Jac29& q) { return g1j29_add(p, q); }
+__device__ __forceinline__ G1Jac29 g1j29_add_fast(const G1Jac29& x, const G1Jac29& y) {
+    Fp29 Z1Z1, Z2Z2;
+    bool p_inf, q_inf;
+    g1j29_inf_flags(x, y, Z1Z1, Z2Z2, p_inf, q_inf);
+    G1AddHead h = g1j29_add_head(x, y, Z1Z1, Z2Z2);
+    if (p_inf | q_inf | g1j29_add_same_x(h)) return g1j29_add_complete_outlined(x, y);
+    return g1j29_add_tail(h);
+}
+__device__ __forceinline__ G1Jac29 g1j29_shfl(const G1Jac29& p, int src_lane) {
+    G1Jac29 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        r.x.l[i] = (uint32_t)__shfl((int)p.x.l[i], src_lane, 64);
+        r.y.l[i] = (uint32_t)__shfl((int)p.y.l[i], src_lane, 64);
+        r.z.l[i] = (uint32_t)__shfl((int)p.z.l[i], src_lane, 64);
+    }
+    return r;
+}
+// slot q of this launch piece = the window block ((q / W / gy) + z0, (q / W) % gy, q % W) of k_msm_window
+__global__ __launch_bounds__(256) void k_msm_reduce(const uint32_t* __restrict__ save, G1Jac* __restrict__ window_sums, int W, int gy, int S, int z0,
+                                                    int nslots) {
+    const int tid = threadIdx.x, lane = tid & 63, l = tid & 31;
+    int q = (int)blockIdx.x * 8 + (tid >> 5);
+    const bool live = q < nslots;
+    if (!live) q = nslots - 1;  // (redundant work: the shuffles below want whole wavefronts)
+    const bool is_col = l >= 16;
+    const int k = l & 15;
+    const uint32_t* base = save + (size_t)q * 42 * 256;
+    G1Jac29 acc = g1j29_identity();
+#pragma unroll 1
+    for (int t = 0; t < 16; t++) {
+        const int b = is_col ? 16 * t + k : 16 * k + t;
+        G1Jac29 pnt;
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            pnt.x.l[i] = base[(size_t)i * 256 + b];
+            pnt.y.l[i] = base[(size_t)(14 + i) * 256 + b];
+            pnt.z.l[i] = base[(size_t)(28 + i) * 256 + b];
+        }
+        acc = t == 0 ? pnt : g1j29_add_fast(acc, pnt);
+    }
+    // suffix scan over each 16-lane vector: V_k <- sum_{j >= k} V_j
+#pragma unroll 1
+    for (int s = 1; s < 16; s <<= 1) {
+        const G1Jac29 other = g1j29_shfl(acc, (lane + s) & 63);
+        if (k + s < 16) acc = g1j29_add_fast(acc, other);
+    }
+    // sum_{k >= 1} S_k = sum_j j V_j: slot 0 leaves the sum, then a tree
+    if (k == 0) acc = g1j29_identity();
+#pragma unroll 1
+    for (int s = 8; s >= 1; s >>= 1) {
+        const G1Jac29 other = g1j29_shfl(acc, (lane + s) & 63);
+        if (k < s) acc = g1j29_add_fast(acc, other);
+    }
+    const G1Jac29 colsum = g1j29_shfl(acc, (lane + 16) & 63);  // lane 0 of the half: sum lo C_lo from lane 16
+    if (l == 0) {
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) acc = g1j29_dbl(acc);
+        acc = g1j29_add(acc, colsum);
+        if (live) {
+            const int w = q % W, by = (q / W) % gy, zz = q / (W * gy) + z0;
+            const int bo = zz / S, slice = zz % S;
+            window_sums[((size_t)(bo * gy + by) * S + slice) * W + w] = g1j29_to_std(acc);
+        }
+    }
+}
+
 // Host side: launch the window kernel over grid (gx, gy, gz) in z-pieces that fit the save area (save_bytes >= one z-layer).
 template <class CV, bool LDSSORT>
 inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, uint32_t* save, size_t save_bytes, hipStream_t st) {
@@ -1084,7 +1202,13 @@ inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_window<CV, LDSSORT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_QUADS_LDS_BYTES);
     for (unsigned z = 0; z < gz; z += per) {
         d.z0 = (int)z;
-        hipLaunchKernelGGL((k_msm_window<CV, LDSSORT>), dim3(gx, gy, std::min(per, gz - z)), dim3(256), CV::QUADS ? MSM_QUADS_LDS_BYTES : 0, st, d);
+        const unsigned nz = std::min(per, gz - z);
+        hipLaunchKernelGGL((k_msm_window<CV, LDSSORT>), dim3(gx, gy, nz), dim3(256), CV::QUADS ? MSM_QUADS_LDS_BYTES : 0, st, d);
+        if constexpr (msm_two_pass<CV>()) {
+            const int nslots = (int)(gx * gy * nz);
+            hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)((nslots + 7) / 8)), dim3(256), 0, st, (const uint32_t*)save, d.window_sums, (int)gx, (int)gy,
+                               d.slices, (int)z, nslots);
+        }
     }
 }
 constexpr size_t msm_save_layer_bytes(unsigned gx, unsigned gy, int words) { return (size_t)gx * gy * 256 * words * 4; }

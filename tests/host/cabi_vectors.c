@@ -53,7 +53,8 @@ static uint8_t *read_file(const char *path, size_t *len) {
     return buf;
 }
 
-/* 1 true, 0 false, -1 error */
+/* 1 true, 0 false, -1 error.  (The call and the read of *ok are two statements at every use: as two arguments of one
+ * call their order of evaluation would be unspecified.) */
 static int outcome(KzgRet rc, bool ok) { return rc == KZG_OK ? (ok ? 1 : 0) : -1; }
 
 static int run_batch(uint32_t nb, const field *blobs, uint32_t nc, const field *cs, uint32_t np, const field *ps, const KzgSettings *s) {
@@ -68,7 +69,8 @@ static int run_batch(uint32_t nb, const field *blobs, uint32_t nc, const field *
     if (nb == 0) return 1;                      /* src/kzg_proof.rs:478-480 */
     if (nb == 1) {                              /* :482-489 */
         if (nc < 1 || np < 1) return -1;        /* the reference panics on [0] */
-        return outcome(kzg_verify_blob_kzg_proof(&ok, blobs[0].p, cs[0].p, ps[0].p, s), ok);
+        KzgRet rc1 = kzg_verify_blob_kzg_proof(&ok, blobs[0].p, cs[0].p, ps[0].p, s);
+        return outcome(rc1, ok);
     }
     if (nb != nc || nb != np) return -1;        /* :491-501 */
     uint8_t *b = (uint8_t *)malloc((size_t)nb * KZG_BYTES_PER_BLOB), *c = (uint8_t *)malloc((size_t)nb * 48), *p = (uint8_t *)malloc((size_t)nb * 48);
@@ -78,7 +80,8 @@ static int run_batch(uint32_t nb, const field *blobs, uint32_t nc, const field *
         memcpy(c + 48 * (size_t)i, cs[i].p, 48);
         memcpy(p + 48 * (size_t)i, ps[i].p, 48);
     }
-    int r = outcome(kzg_verify_blob_kzg_proof_batch(&ok, b, c, p, nb, s), ok);
+    KzgRet rcb = kzg_verify_blob_kzg_proof_batch(&ok, b, c, p, nb, s);
+    int r = outcome(rcb, ok);
     free(b);
     free(c);
     free(p);
@@ -141,13 +144,19 @@ int main(int argc, char **argv) {
             if (take_field(&c) || take_field(&z) || take_field(&y) || take_field(&p)) return 2;
             bool ok = false;
             if (c.len != 48 || z.len != 32 || y.len != 32 || p.len != 48) got = -1; /* from_slice: InvalidBytesLength */
-            else got = outcome(kzg_verify_kzg_proof(&ok, c.p, z.p, y.p, p.p, s), ok);
+            else {
+                KzgRet r1 = kzg_verify_kzg_proof(&ok, c.p, z.p, y.p, p.p, s);
+                got = outcome(r1, ok);
+            }
         } else if (kind == 2) {
             field b, c, p;
             if (take_field(&b) || take_field(&c) || take_field(&p)) return 2;
             bool ok = false;
             if (b.len != KZG_BYTES_PER_BLOB || c.len != 48 || p.len != 48) got = -1;
-            else got = outcome(kzg_verify_blob_kzg_proof(&ok, b.p, c.p, p.p, s), ok);
+            else {
+                KzgRet r2 = kzg_verify_blob_kzg_proof(&ok, b.p, c.p, p.p, s);
+                got = outcome(r2, ok);
+            }
         } else if (kind == 3) {
             uint32_t n[3];
             field *f[3];

@@ -73,3 +73,25 @@ def test_serde_rkyv_wire_formats_round_trip():
         for bad in (json.dumps(list(raw[:-1])), json.dumps(list(raw[:-1]) + [256]), json.dumps(list(raw[:-1]) + [-1]), json.dumps({"a": 1})):
             with pytest.raises(KzgError):
                 cls.from_json(bad)
+
+
+def test_host_stream_wrapper_checks_buffer_lengths_before_the_call():
+    """verify_blob_kzg_proof_batches (the host-memory stream form): bytes-like arguments whose length is not exactly
+    n * n_batches entries raise InvalidBytesLength (the reference's error for mismatched lengths, src/kzg_proof.rs:491-501)
+    BEFORE anything is handed to the C entry point - it would read n * n_batches * 131072 bytes whatever the object holds.
+    bytearray is accepted (no copy); other types are a TypeError.  No GPU is touched: the checks come first."""
+    from kzg_rs_amd import api
+    n, B = 2, 3
+    blobs, cs, ps = bytes(131072 * n * B), bytes(48 * n * B), bytes(48 * n * B)
+    for bad in ((blobs[:-1], cs, ps), (blobs, cs[:-48], ps), (blobs, cs, ps + b"\0"), (bytearray(blobs[:131072]), cs, ps)):
+        with pytest.raises(api.KzgError) as e:
+            api.verify_blob_kzg_proof_batches(*bad, n, B, None)
+        assert e.value.kind == "InvalidBytesLength"
+    with pytest.raises(TypeError):
+        api.verify_blob_kzg_proof_batches([1, 2, 3], cs, ps, n, B, None)
+    keep = []
+    p = api._host_ptr(bytearray(b"abc"), 3, "x", keep)
+    assert p.value and len(keep) == 1
+    from kzg_rs_amd.distributed import HipBackend
+    with pytest.raises(api.KzgError):
+        HipBackend.batch_challenges(bytes(159), 0, 1, 1)

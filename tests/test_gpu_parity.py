@@ -876,12 +876,21 @@ def test_host_fed_stream_of_batches():
                 out.append(None)
         return out
 
-    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 1, 40, st) == want(1, 40)   # two chunks of 20
+    def run(n_, B_):  # (bytes arguments are length-checked by the mirror: exactly n B entries)
+        t = n_ * B_
+        return api.verify_blob_kzg_proof_batches(hb[: 131072 * t], hc[: 48 * t], hp[: 48 * t], n_, B_, st)
+
+    assert run(1, 40) == want(1, 40)   # two chunks of 20
     w65 = want(6, 5)
     assert w65 == [True, False, None, None, True]
-    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 6, 5, st) == w65            # one chunk, larger staging sets
-    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 2, 19, st) == want(2, 19)    # two uneven chunks: 10, 9
-    assert api.verify_blob_kzg_proof_batches(hb, hc, hp, 1, 1, st) == want(1, 1)      # a stream of one
+    assert run(6, 5) == w65            # one chunk, larger staging sets
+    assert run(2, 19) == want(2, 19)   # two uneven chunks: 10, 9
+    assert run(1, 1) == want(1, 1)     # a stream of one
+    with pytest.raises(KzgError) as e:  # a short buffer is the reference's Err(InvalidBytesLength), not a read past the object
+        api.verify_blob_kzg_proof_batches(hb[: 131072 * 29], hc[: 48 * 30], hp[: 48 * 30], 6, 5, st)
+    assert e.value.kind == "InvalidBytesLength"
+    ba = bytearray(hb[: 131072 * 6])   # bytearray inputs are taken without a copy
+    assert api.verify_blob_kzg_proof_batches(ba, bytearray(hc[: 48 * 6]), bytearray(hp[: 48 * 6]), 6, 1, st) == [True]
 
 
 def test_host_entry_full_size_batch():
@@ -912,6 +921,69 @@ def test_host_entry_full_size_batch():
     three = np.concatenate([blobs, blobs, bad_blobs])
     got = api.verify_blob_kzg_proof_batches(three.ctypes.data, hc + hc + hc, hp + hbp + hp, n, 3, st)
     assert got == [True, False, None]
+
+
+def test_sliced_host_handover_gives_the_same_challenges():
+    """A host Vec<Blob> crosses PCIe in slices ACROSS the blobs and the SHA-256 chains run in segments behind the slices
+    (capi_verify.hpp: sliced_copies / sliced_segments, k_blob_challenge_split2_t<true>, the 32-byte midstate per blob):
+    the challenge z of every one of 700 blobs (8 slices; 700 is not a multiple of the 64 blobs a workgroup serves) equals
+    the one-launch form's (the same entry point on chunks of 100 blobs, which are below the slicing threshold) and the
+    oracle's on a sample; a byte flipped in the LAST slice of a blob changes exactly that blob's z."""
+    from kzg_rs_amd import synth
+    st = KzgSettings.load_trusted_setup_file()
+    n = 700
+    blobs = synth.random_blobs(n, seed=1234)
+    cs = [O.g1_mul(G1_GEN, (i + 1).to_bytes(32, "big")) for i in range(8)]
+    cs = [cs[i % 8] for i in range(n)]
+    bl = [blobs[i].tobytes() for i in range(n)]
+    z_sliced = api.compute_challenges(bl, cs, st)
+    z_plain = []
+    for lo in range(0, n, 100):
+        z_plain += api.compute_challenges(bl[lo: lo + 100], cs[lo: lo + 100], st)
+    assert z_sliced == z_plain
+    for i in (0, 1, 63, 64, 127, 128, 333, 639, 640, 698, 699):
+        assert z_sliced[i] == O.compute_challenge(bl[i], cs[i]), i
+    b2 = bytearray(bl[650])
+    b2[131072 - 5] ^= 1
+    bl2 = list(bl)
+    bl2[650] = bytes(b2)
+    z2 = api.compute_challenges(bl2, cs, st)
+    assert [i for i in range(n) if z2[i] != z_sliced[i]] == [650]
+    assert z2[650] == O.compute_challenge(bl2[650], cs[650])
+
+
+@pytest.mark.parametrize("slices", ["1", "2", "16"])
+def test_host_slices_forced_in_child_process(slices):
+    """KZG_HOST_SLICES = 1 (one copy, the round-2 behaviour), 2 and 16: the host entry point on a 200-blob batch (valid,
+    a corrupted proof, a non-canonical element in the last field element of a blob) and the challenges of 130 blobs against
+    the oracle - every slicing must give the same results as the default (4 and 8, covered by the tests above)."""
+    import subprocess
+    import sys
+    ROOT, HERE = O.ROOT, os.path.join(O.ROOT, "tests")
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import ctypes as C, torch, oracle_lib as O\n"
+        "from kzg_rs_amd import api, synth\n"
+        "R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001\n"
+        "n = 200\n"
+        "blobs, cs, ps, st = synth.make_valid_batch(n, seed=31)\n"
+        "hc, hp = b''.join(cs), b''.join(ps)\n"
+        "def call(bl, c, p):\n"
+        "    ok = C.c_bool(False)\n"
+        "    rc = api.lib().kzg_verify_blob_kzg_proof_batch(C.byref(ok), bl.ctypes.data_as(C.c_char_p), c, p, n, st._h)\n"
+        "    return None if rc == api.KZG_BADARGS else bool(ok.value) if rc == api.KZG_OK else 'rc%%d' %% rc\n"
+        "assert call(blobs, hc, hp) is True\n"
+        "bad = list(ps); bad[150] = ps[151]\n"
+        "assert call(blobs, hc, b''.join(bad)) is False\n"
+        "bb = blobs.copy(); bb[199, 32 * 4095:] = list(R.to_bytes(32, 'big'))\n"
+        "assert call(bb, hc, hp) is None\n"
+        "bl = [blobs[i].tobytes() for i in range(130)]\n"
+        "z = api.compute_challenges(bl, cs[:130], st)\n"
+        "assert all(z[i] == O.compute_challenge(bl[i], cs[i]) for i in (0, 1, 63, 64, 65, 129))\n"
+        "print('slices-ok')\n" % (ROOT, HERE))
+    e = dict(os.environ, KZG_HOST_SLICES=slices)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "slices-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_handles_release_device_memory_and_oom_is_malloc():

@@ -23,6 +23,15 @@ if sys.argv[1] == "run":
         for _ in range(4):
             time.sleep(0.005)
             assert KzgProof.verify_kzg_proof(Bytes48(cs[0]), Bytes32(zs[0]), Bytes32(ys[0]), Bytes48(ps[0]), st)
+    elif sys.argv[2] == "hostbatch":  # the reference's call shape: a host Vec<Blob> (pageable), copies included
+        import ctypes as C
+        n = 1024
+        blobs, cs, ps, st = synth.make_valid_batch(n, seed=3, chunk=1024)
+        hc, hp, ok = b"".join(cs), b"".join(ps), C.c_bool(False)
+        for _ in range(4):
+            time.sleep(0.005)
+            api._chk(api.lib().kzg_verify_blob_kzg_proof_batch(C.byref(ok), blobs.ctypes.data_as(C.c_char_p), hc, hp, n, st._h))
+            assert ok.value
     else:
         n = 1024
         blobs, cs, ps, st = synth.make_valid_batch(n, seed=3, chunk=1024)
@@ -37,7 +46,12 @@ else:
     import csv
     import glob
     f = glob.glob(sys.argv[2] + "/**/*kernel_trace.csv", recursive=True)[0]
-    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    rows = list(csv.DictReader(open(f)))
+    for m in glob.glob(sys.argv[2] + "/**/*memory_copy_trace.csv", recursive=True):  # (--memory-copy-trace) copies join the timeline
+        for r in csv.DictReader(open(m)):
+            r["Kernel_Name"] = "[copy %s %s B]" % (r.get("Direction", "?"), r.get("Bytes", r.get("Size", "?")))
+            rows.append(r)
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     start = 0
     for i in range(1, len(rows)):
         if int(rows[i]["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"]) > 3e6:
