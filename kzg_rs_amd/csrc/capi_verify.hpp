@@ -160,7 +160,7 @@ static int msm_chunks_per_block(size_t B) {
 // is launched in z-pieces by msm_window_launch.
 static KzgRet msm_save_reserve(const KzgSettings* s, unsigned gx, unsigned gy, unsigned gz) {
     Workspace& w = s->ws;
-    const size_t layer = msm_save_layer_bytes(gx, gy, fp29_enabled() ? Curve29::WORDS : Curve32::WORDS);
+    const size_t layer = msm_save_layer_bytes(gx, gy, fp29_enabled() ? MSM_SAVE2_WORDS : Curve32::WORDS);  // (the larger of the forms' point sizes)
     const size_t want = std::max(layer, std::min(layer * gz, (size_t)512 << 20));
     if (want > w.cap_msm_save) {
         if (w.d_msm_save) (void)hipFree(w.d_msm_save);

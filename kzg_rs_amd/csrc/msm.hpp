@@ -374,6 +374,7 @@ struct MsmDesc {
 //   read the same table rows (each row once per window), which then come out of that XCD's L2 instead of crossing the fabric 8
 //   times.  Workgroups go to the 8 XCDs round-robin by linear id, so (with gridDim = (8, 1, gz), gz a multiple of 8) the block
 //   with linear id L works on window (L / 8) % 8 of z = (L / 64) * 8 + L % 8.
+constexpr int MSM_SAVE2_WORDS = 48;  // a point of the two-pass form's save area: X | Y | Z, 16 words each (14 limbs + 2 of padding)
 constexpr int MSM_FLAG_ROTATE = 1, MSM_FLAG_XCD = 2;
 
 __device__ __forceinline__ void lds_store_jac(uint32_t* base, int slot, const G1Jac& p) {
@@ -813,6 +814,24 @@ struct Curve29Aff : Curve29 {
 // write traffic once the launch's lists outgrow the L2 (measured: 25 M stores -> 3.2 GB written per launch group).
 template <class CV>
 constexpr int msm_lds_sort_capacity() { return MSM_BUCKETS * CV::WORDS; }
+// A general addition for k_msm_reduce.  SAFE = false: straight-line code for finite operands with different x, an identity
+// operand passed through, and a same-x pair (P + P, P - P) only REPORTED - the complete formula inlined beside the fast path
+// cost the kernel 787 spilled registers at two wavefronts per SIMD, out of line its two 168-byte arguments were written to
+// scratch before every addition (1.5 GB per launch).  SAFE = true: the complete formula, for the rare redo.
+template <bool SAFE>
+__device__ __forceinline__ G1Jac29 g1j29_add_fast(const G1Jac29& x, const G1Jac29& y, bool& same_x_seen) {
+    if constexpr (SAFE) {
+        return g1j29_add(x, y);
+    } else {
+        Fp29 Z1Z1, Z2Z2;
+        bool p_inf, q_inf;
+        g1j29_inf_flags(x, y, Z1Z1, Z2Z2, p_inf, q_inf);
+        if (p_inf | q_inf) return p_inf ? y : x;  // (empty buckets: common only in small batches)
+        const G1AddHead h = g1j29_add_head(x, y, Z1Z1, Z2Z2);
+        same_x_seen |= g1j29_add_same_x(h);  // P + P or P - P: this result is wrong; the SAFE pass redoes the window
+        return g1j29_add_tail(h);
+    }
+}
 // TWO PASSES (round 3; the radix-2^29 throughput variants - every CV with SPLIT and without QUADS): the window kernel ends
 // with the bucket sums, written to the save area, and k_msm_reduce turns them into the window sum.  In one kernel the 16
 // levels of the reduction ran on one or two of a block's four wavefronts while the block held its 43 KB of LDS - a third
@@ -909,11 +928,58 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
         else sorted_global[k] = v;
     };
     Pt acc = CV::identity();
-    if constexpr (CV::SPLIT) {
+    if constexpr (TWOPASS) {
         // The common addition (accumulator finite, different x) is straight-line code; a pair that needs the complete
-        // formula - a repeated point (P + P) or its negative - is not added here: its entry moves to the front of the
-        // bucket's own list and the loop below, outside the hot one, takes care of it.  (Inlined, the complete formula's
-        // five exits kept the accumulator in scratch memory: 112 bytes loaded and stored per addition.)
+        // formula - a repeated point (P + P) or its negative - is not added in the hot loop: its entry moves to the front of
+        // the range and the loop behind it takes care of it.  (Inlined, the complete formula's five exits kept the
+        // accumulator in scratch memory: 112 bytes loaded and stored per addition.)
+        auto accumulate = [&](uint32_t k, const uint32_t kend) -> Pt {  // the sum of list entries [k, kend); only this thread touches them
+            Pt a = CV::identity();
+            const uint32_t first = k + 1;
+            uint32_t wr = k;
+            if (k < kend) {  // the first entry is a copy, not an addition to the identity
+                const uint32_t e = sorted_at(k++);
+                a = CV::from_entry(CV::load(mult[(size_t)(e >> MSM_ENTRY_CHUNK_SHIFT) * d.stride + (e & MSM_ENTRY_POINT_MASK)]));
+                wr = k;
+            }
+            for (; k < kend; k++) {
+                const uint32_t e = sorted_at(k);
+                const typename CV::Entry q = CV::load(mult[(size_t)(e >> MSM_ENTRY_CHUNK_SHIFT) * d.stride + (e & MSM_ENTRY_POINT_MASK)]);
+                const typename CV::EntryHead h = CV::entry_head(a, q);
+                if (CV::entry_special(h)) sorted_put(wr++, e);
+                else a = CV::entry_tail(a, q, h);
+            }
+            for (uint32_t j = first; j < wr; j++) {  // rare
+                const uint32_t e = sorted_at(j);
+                a = CV::add_entry(a, CV::load(mult[(size_t)(e >> MSM_ENTRY_CHUNK_SHIFT) * d.stride + (e & MSM_ENTRY_POINT_MASK)]));
+            }
+            return a;
+        };
+        // the block's slot of the save area, POINT-major (256 points of MSM_SAVE2_WORDS words, X | Y | Z at 16-word strides):
+        // k_msm_reduce takes the bucket sums from there - its row lanes read bucket 16 hi + t, its column lanes bucket 16 t + lo,
+        // and with every point in lines of its own both patterns fetch exactly the bytes they use (word-major, the row
+        // pattern pulled a 64-byte sector per word: 5.5 GB of traffic for 0.35 GB of points, profiles/r3b_pmc.json)
+        const size_t slot = ((size_t)(zz - d.z0) * gridDim.y + blockIdx.y) * W + w;
+        uint32_t* const out = d.save + slot * MSM_SAVE2_WORDS * 256;
+        auto put = [&](int col, const Pt& p) {
+            uint4* const o4 = reinterpret_cast<uint4*>(out + (size_t)col * MSM_SAVE2_WORDS);
+            const Fp29* const c[3] = {&p.x, &p.y, &p.z};
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                o4[4 * j] = make_uint4(c[j]->l[0], c[j]->l[1], c[j]->l[2], c[j]->l[3]);
+                o4[4 * j + 1] = make_uint4(c[j]->l[4], c[j]->l[5], c[j]->l[6], c[j]->l[7]);
+                o4[4 * j + 2] = make_uint4(c[j]->l[8], c[j]->l[9], c[j]->l[10], c[j]->l[11]);
+                o4[4 * j + 3] = make_uint4(c[j]->l[12], c[j]->l[13], 0u, 0u);
+            }
+        };
+        // (Tried and measured, profiles/r3_ab_msm_halves.txt: two threads per PAIR of buckets - rank t and rank 255 - t, each
+        // thread one half of either list, the halves exchanged through the save slot and completed with one general addition -
+        // evens out the threads' work (a block lives as long as its fullest bucket: 49 entries at an average of 32), but the
+        // second accumulator cost the hot loop 100 spilled registers and 4 GB of scratch writes: +0.2 %.  Not kept.)
+        put(bucket, accumulate(bucket > 0 ? off[bucket] : 0u, bucket > 0 ? off[bucket + 1] : 0u));
+        return;
+    } else if constexpr (CV::SPLIT) {
+        // (the latency variant: Curve29Quads) the same loop with the long buckets' tails left to the quads
         uint32_t k = bucket > 0 ? off[bucket] : 0u, w = k;
         const uint32_t kend_all = bucket > 0 ? off[bucket + 1] : 0u;
         // (CV::QUADS) a thread takes the first MSM_QUADS_BUCKET_CAP entries of its bucket; what a long bucket has beyond them
@@ -959,19 +1025,6 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     //      kind 1 cols  : dst = 16 (2 s k) + lo, src = dst + 16 s     (ops = 128 / s)   on a fresh copy of the buckets
     //      kind 2 scan  : suffix scan over the two 16-element vectors R (slots 0..15) and C (slots 16..31)
     //      kind 3 tree  : tree sum of the two scanned vectors (slot 0 / 16 of each zeroed first)
-    if constexpr (TWOPASS) {
-        // the bucket sum to the save area, word-major ([WORDS][256] per block; slot = this block's place in the launch):
-        // k_msm_reduce takes it from there
-        const size_t slot = ((size_t)(zz - d.z0) * gridDim.y + blockIdx.y) * W + w;
-        uint32_t* const out = d.save + slot * CV::WORDS * 256 + bucket;
-#pragma unroll
-        for (int i = 0; i < 14; i++) {
-            out[(size_t)i * 256] = acc.x.l[i];
-            out[(size_t)(14 + i) * 256] = acc.y.l[i];
-            out[(size_t)(28 + i) * 256] = acc.z.l[i];
-        }
-        return;
-    }
     if constexpr (LDSSORT) __syncthreads();  // every list has been read: the region becomes the bucket points
     CV::lds_store(pts, bucket, acc);
     __syncthreads();
@@ -1124,15 +1177,6 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
 // 28 addition times per two window blocks instead of 21 wave-level additions + 16 barriers per block.
 // The bucket sums are any Jacobian points (empty buckets: the identity, common only in small batches); the rare endings
 // (identity operand, same x) leave the straight-line path through the complete formula, out of line.
-__device__ __noinline__ G1Jac29 g1j29_add_complete_outlined(const G1Jac29& p, const G1Jac29& q) { return g1j29_add(p, q); }
-__device__ __forceinline__ G1Jac29 g1j29_add_fast(const G1Jac29& x, const G1Jac29& y) {
-    Fp29 Z1Z1, Z2Z2;
-    bool p_inf, q_inf;
-    g1j29_inf_flags(x, y, Z1Z1, Z2Z2, p_inf, q_inf);
-    G1AddHead h = g1j29_add_head(x, y, Z1Z1, Z2Z2);
-    if (p_inf | q_inf | g1j29_add_same_x(h)) return g1j29_add_complete_outlined(x, y);
-    return g1j29_add_tail(h);
-}
 __device__ __forceinline__ G1Jac29 g1j29_shfl(const G1Jac29& p, int src_lane) {
     G1Jac29 r;
 #pragma unroll
@@ -1143,48 +1187,66 @@ __device__ __forceinline__ G1Jac29 g1j29_shfl(const G1Jac29& p, int src_lane) {
     }
     return r;
 }
-// slot q of this launch piece = the window block ((q / W / gy) + z0, (q / W) % gy, q % W) of k_msm_window
-__global__ __launch_bounds__(256) void k_msm_reduce(const uint32_t* __restrict__ save, G1Jac* __restrict__ window_sums, int W, int gy, int S, int z0,
-                                                    int nslots) {
+// slot q of this launch piece = the window block ((q / W / gy) + z0, (q / W) % gy, q % W) of k_msm_window.
+// SAFE = false is the pass that always runs; it leaves flags[q] = 1 where it met a same-x pair.  SAFE = true runs behind it
+// over the same grid, returns at once unless one of its wavefront's two windows is flagged, and redoes those with the
+// complete formula.
+template <bool SAFE>
+__global__ __launch_bounds__(256, SAFE ? 1 : 2) void k_msm_reduce(const uint32_t* __restrict__ save, uint32_t* __restrict__ flags,
+                                                                    G1Jac* __restrict__ window_sums, int W, int gy, int S, int z0, int nslots) {
     const int tid = threadIdx.x, lane = tid & 63, l = tid & 31;
     int q = (int)blockIdx.x * 8 + (tid >> 5);
     const bool live = q < nslots;
     if (!live) q = nslots - 1;  // (redundant work: the shuffles below want whole wavefronts)
+    if constexpr (SAFE) {
+        if (!__any((int)flags[q])) return;
+    }
+    bool bad = false;
     const bool is_col = l >= 16;
     const int k = l & 15;
-    const uint32_t* base = save + (size_t)q * 42 * 256;
+    const uint32_t* base = save + (size_t)q * MSM_SAVE2_WORDS * 256;
     G1Jac29 acc = g1j29_identity();
 #pragma unroll 1
     for (int t = 0; t < 16; t++) {
         const int b = is_col ? 16 * t + k : 16 * k + t;
+        const uint4* const i4 = reinterpret_cast<const uint4*>(base + (size_t)b * MSM_SAVE2_WORDS);
         G1Jac29 pnt;
+        Fp29* const c[3] = {&pnt.x, &pnt.y, &pnt.z};
 #pragma unroll
-        for (int i = 0; i < 14; i++) {
-            pnt.x.l[i] = base[(size_t)i * 256 + b];
-            pnt.y.l[i] = base[(size_t)(14 + i) * 256 + b];
-            pnt.z.l[i] = base[(size_t)(28 + i) * 256 + b];
+        for (int j = 0; j < 3; j++) {
+            const uint4 a = i4[4 * j], bb = i4[4 * j + 1], cc = i4[4 * j + 2], dd = i4[4 * j + 3];
+            c[j]->l[0] = a.x; c[j]->l[1] = a.y; c[j]->l[2] = a.z; c[j]->l[3] = a.w;
+            c[j]->l[4] = bb.x; c[j]->l[5] = bb.y; c[j]->l[6] = bb.z; c[j]->l[7] = bb.w;
+            c[j]->l[8] = cc.x; c[j]->l[9] = cc.y; c[j]->l[10] = cc.z; c[j]->l[11] = cc.w;
+            c[j]->l[12] = dd.x; c[j]->l[13] = dd.y;
         }
-        acc = t == 0 ? pnt : g1j29_add_fast(acc, pnt);
+        acc = t == 0 ? pnt : g1j29_add_fast<SAFE>(acc, pnt, bad);
     }
     // suffix scan over each 16-lane vector: V_k <- sum_{j >= k} V_j
 #pragma unroll 1
     for (int s = 1; s < 16; s <<= 1) {
         const G1Jac29 other = g1j29_shfl(acc, (lane + s) & 63);
-        if (k + s < 16) acc = g1j29_add_fast(acc, other);
+        if (k + s < 16) acc = g1j29_add_fast<SAFE>(acc, other, bad);
     }
     // sum_{k >= 1} S_k = sum_j j V_j: slot 0 leaves the sum, then a tree
     if (k == 0) acc = g1j29_identity();
 #pragma unroll 1
     for (int s = 8; s >= 1; s >>= 1) {
         const G1Jac29 other = g1j29_shfl(acc, (lane + s) & 63);
-        if (k < s) acc = g1j29_add_fast(acc, other);
+        if (k < s) acc = g1j29_add_fast<SAFE>(acc, other, bad);
     }
     const G1Jac29 colsum = g1j29_shfl(acc, (lane + 16) & 63);  // lane 0 of the half: sum lo C_lo from lane 16
     if (l == 0) {
 #pragma unroll 1
         for (int i = 0; i < 4; i++) acc = g1j29_dbl(acc);
-        acc = g1j29_add(acc, colsum);
-        if (live) {
+        acc = g1j29_add_fast<SAFE>(acc, colsum, bad);
+    }
+    // a same-x pair anywhere in the window's 32 lanes flags the window
+    const unsigned long long any_bad = __ballot((int)bad);
+    const bool win_bad = ((any_bad >> (lane & 32)) & 0xffffffffull) != 0;
+    if (l == 0 && live) {
+        if constexpr (!SAFE) flags[q] = win_bad ? 1u : 0u;
+        if (SAFE ? flags[q] != 0 : !win_bad) {
             const int w = q % W, by = (q / W) % gy, zz = q / (W * gy) + z0;
             const int bo = zz / S, slice = zz % S;
             window_sums[((size_t)(bo * gy + by) * S + slice) * W + w] = g1j29_to_std(acc);
@@ -1195,7 +1257,7 @@ __global__ __launch_bounds__(256) void k_msm_reduce(const uint32_t* __restrict__
 // Host side: launch the window kernel over grid (gx, gy, gz) in z-pieces that fit the save area (save_bytes >= one z-layer).
 template <class CV, bool LDSSORT>
 inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, uint32_t* save, size_t save_bytes, hipStream_t st) {
-    const size_t layer = (size_t)gx * gy * 256 * CV::WORDS * 4;
+    const size_t layer = (size_t)gx * gy * (256 * (msm_two_pass<CV>() ? MSM_SAVE2_WORDS : CV::WORDS) + 1) * 4;  // (+ 1: the window's flag)
     unsigned per = (unsigned)std::min<size_t>(gz, std::max<size_t>(1, save_bytes / layer));
     d.save = save;
     if (CV::QUADS)  // static + dynamic LDS pass 64 KB (set per call: the attribute belongs to the current device's copy of the kernel)
@@ -1206,12 +1268,15 @@ inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, 
         hipLaunchKernelGGL((k_msm_window<CV, LDSSORT>), dim3(gx, gy, nz), dim3(256), CV::QUADS ? MSM_QUADS_LDS_BYTES : 0, st, d);
         if constexpr (msm_two_pass<CV>()) {
             const int nslots = (int)(gx * gy * nz);
-            hipLaunchKernelGGL(k_msm_reduce, dim3((unsigned)((nslots + 7) / 8)), dim3(256), 0, st, (const uint32_t*)save, d.window_sums, (int)gx, (int)gy,
-                               d.slices, (int)z, nslots);
+            uint32_t* const flags = save + (size_t)per * gx * gy * 256 * MSM_SAVE2_WORDS;  // behind the points of a full piece
+            hipLaunchKernelGGL(k_msm_reduce<false>, dim3((unsigned)((nslots + 7) / 8)), dim3(256), 0, st, (const uint32_t*)save, flags, d.window_sums, (int)gx,
+                               (int)gy, d.slices, (int)z, nslots);
+            hipLaunchKernelGGL(k_msm_reduce<true>, dim3((unsigned)((nslots + 7) / 8)), dim3(256), 0, st, (const uint32_t*)save, flags, d.window_sums, (int)gx,
+                               (int)gy, d.slices, (int)z, nslots);
         }
     }
 }
-constexpr size_t msm_save_layer_bytes(unsigned gx, unsigned gy, int words) { return (size_t)gx * gy * 256 * words * 4; }
+constexpr size_t msm_save_layer_bytes(unsigned gx, unsigned gy, int words) { return (size_t)gx * gy * (256 * words + 1) * 4; }
 
 // sums[(g * slices + k) * W + w] over the slices k -> out[g * W + w]; one 64-thread workgroup per (g, w) of every output
 __global__ __launch_bounds__(64) void k_msm_fold_slices(const G1Jac* __restrict__ sums, G1Jac* __restrict__ out, int slices, int W) {

@@ -443,6 +443,16 @@ def test_g1_msm_cancellation(settings):
     pts = _gen_multiples([3, 5, 7, 11])
     sc = [k.to_bytes(32, "big")] * 4
     assert api.g1_msm(pts, sc, settings) == O.g1_msm(b"".join(pts), b"".join(sc), 4)
+    # EQUAL BUCKET SUMS meet in the window reduction (msm.hpp k_msm_reduce: the fast pass only reports a same-x pair, the
+    # safe pass redoes the window): small scalars keep their digits in window 0 - the same point in two buckets of one
+    # row (P + P in the row sum and in the column scan), in one column (P + P in the row scan), P and -P (the identity in
+    # the middle of a scan), and the same four points under two digit patterns at once
+    m = _gen_multiples([rng.randrange(1, R)])[0]
+    neg = O.g1_mul(m, (R - 1).to_bytes(32, "big"))
+    for pts, ks in (([m, m], [1, 2]), ([m, m, m], [1, 0x11, 0x21]), ([m, neg], [1, 2]), ([m, neg, m], [0x13, 0x23, 0x33]),
+                    ([m, m, neg, neg, m], [5, 6, 7, 0x15, 0xF5]), ([m] * 16, list(range(16, 256, 15))[:16])):
+        sc = [k.to_bytes(32, "big") for k in ks]
+        assert api.g1_msm(pts, sc, settings) == O.g1_msm(b"".join(pts), b"".join(sc), len(pts)), ks
 
 
 def test_g1_mul_generator(settings):
