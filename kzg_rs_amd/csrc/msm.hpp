@@ -375,7 +375,9 @@ struct MsmDesc {
 //   times.  Workgroups go to the 8 XCDs round-robin by linear id, so (with gridDim = (8, 1, gz), gz a multiple of 8) the block
 //   with linear id L works on window (L / 8) % 8 of z = (L / 64) * 8 + L % 8.
 constexpr int MSM_SAVE2_WORDS = 48;  // a point of the two-pass form's save area: X | Y | Z, 16 words each (14 limbs + 2 of padding)
-constexpr int MSM_FLAG_ROTATE = 1, MSM_FLAG_XCD = 2;
+constexpr int MSM_FLAG_ROTATE = 1, MSM_FLAG_XCD = 2, MSM_FLAG_BFIRST = 4;
+// MSM_FLAG_BFIRST (set by msm_window_launch for a one-piece launch without slices): the blocks of the outputs B (2 n + 1 terms,
+//   twice the work) are dispatched before those of the outputs A, so that the launch ends on short blocks.
 
 __device__ __forceinline__ void lds_store_jac(uint32_t* base, int slot, const G1Jac& p) {
     uint32_t* d = base + slot * 36;
@@ -852,6 +854,10 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
         w = (int)(i & 7);
         zz = (int)((i >> 3) * 8 + (L & 7)) + d.z0;
     }
+    if (d.flags & MSM_FLAG_BFIRST) {  // (z0 = 0, S = 1, an even number of z-layers: the host checked)
+        const int half = (int)(gridDim.z >> 1);
+        zz = zz < half ? 2 * zz + 1 : 2 * (zz - half);
+    }
     const int S = d.slices, bo = zz / S, slice = zz % S;
     const int o = bo & 1, tid = threadIdx.x;
     const int cpb = d.chunks_per_block, j0 = blockIdx.y * cpb;
@@ -866,7 +872,11 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     extern __shared__ __attribute__((aligned(16))) uint32_t msm_dyn_lds[];  // (CV::QUADS) quad scratch | second R | C vector
     // 36 / 42 KiB: one Jacobian point per thread for the reduction levels; before that the block's sorted term list (LDSSORT).
     // The two-pass form keeps only the list here.
-    __shared__ uint32_t pts[(TWOPASS && !LDSSORT) ? 1 : MSM_BUCKETS * CV::WORDS];
+    // (two-pass form: the list lies in DYNAMIC shared memory sized to the launch's longest list - 33 KB for the 8 196 entries of
+    // a 1 024-blob batch's output B instead of the 43 KB of a bucket-point array - so that a CU takes a fourth block when
+    // the wavefronts of the resident ones have begun to leave)
+    __shared__ uint32_t pts[TWOPASS ? 1 : MSM_BUCKETS * CV::WORDS];
+    uint32_t* const lst = TWOPASS ? msm_dyn_lds : pts;
     uint32_t* const sorted_global = d.sorted + ((size_t)(bo * gridDim.y + blockIdx.y) * W + w) * cpb * d.max_terms + (size_t)cpb * t0;
     // (compile-time choice: an LDS pointer or a global one, never a flat one)
     cnt[tid] = 0;
@@ -897,7 +907,7 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
         for (int t = tid; t < nt; t += 256) {
             uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
             uint32_t pos = atomicAdd(&cur[dig], 1u);
-            if constexpr (LDSSORT) pts[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << MSM_ENTRY_CHUNK_SHIFT;
+            if constexpr (LDSSORT) lst[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << MSM_ENTRY_CHUNK_SHIFT;
             else sorted_global[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << MSM_ENTRY_CHUNK_SHIFT;
         }
     }
@@ -920,11 +930,11 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     const int bucket = cur[(tid + 64 * rot) & 255];
     const typename CV::Mem* mult = static_cast<const typename CV::Mem*>(d.mult);
     auto sorted_at = [&](uint32_t k) -> uint32_t {
-        if constexpr (LDSSORT) return pts[k];
+        if constexpr (LDSSORT) return lst[k];
         else return sorted_global[k];
     };
     auto sorted_put = [&](uint32_t k, uint32_t v) {
-        if constexpr (LDSSORT) pts[k] = v;
+        if constexpr (LDSSORT) lst[k] = v;
         else sorted_global[k] = v;
     };
     Pt acc = CV::identity();
@@ -1005,7 +1015,7 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
         if constexpr (CV::QUADS) {
             if (kend < kend_all) {
                 if constexpr (LDSSORT)  // the list's LDS region is about to become the bucket points: the rest of it to the global copy
-                    for (uint32_t j = kend; j < kend_all; j++) sorted_global[j] = pts[j];
+                    for (uint32_t j = kend; j < kend_all; j++) sorted_global[j] = lst[j];
                 long_buckets[atomicAdd(&n_long, 1u)] = (uint32_t)bucket;
             }
         }
@@ -1262,10 +1272,14 @@ inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, 
     d.save = save;
     if (CV::QUADS)  // static + dynamic LDS pass 64 KB (set per call: the attribute belongs to the current device's copy of the kernel)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_window<CV, LDSSORT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_QUADS_LDS_BYTES);
+    static const bool bfirst_on = !(getenv("KZG_MSM_BFIRST") && getenv("KZG_MSM_BFIRST")[0] == '0');
+    if (bfirst_on && msm_two_pass<CV>() && per == gz && d.slices == 1 && (gz & 1) == 0 && d.nterms[1] > d.nterms[0]) d.flags |= MSM_FLAG_BFIRST;
     for (unsigned z = 0; z < gz; z += per) {
         d.z0 = (int)z;
         const unsigned nz = std::min(per, gz - z);
-        hipLaunchKernelGGL((k_msm_window<CV, LDSSORT>), dim3(gx, gy, nz), dim3(256), CV::QUADS ? MSM_QUADS_LDS_BYTES : 0, st, d);
+        // dynamic LDS: the quads' scratch (latency variant), or the two-pass form's sorted list (chunks_per_block x the longest slice, + 1: slice boundaries round either way)
+        const size_t list_bytes = (msm_two_pass<CV>() && LDSSORT) ? 4 * ((size_t)d.chunks_per_block * ((size_t)(d.max_terms + d.slices - 1) / d.slices + 1) + 4) : 0;
+        hipLaunchKernelGGL((k_msm_window<CV, LDSSORT>), dim3(gx, gy, nz), dim3(256), CV::QUADS ? MSM_QUADS_LDS_BYTES : list_bytes, st, d);
         if constexpr (msm_two_pass<CV>()) {
             const int nslots = (int)(gx * gy * nz);
             uint32_t* const flags = save + (size_t)per * gx * gy * 256 * MSM_SAVE2_WORDS;  // behind the points of a full piece
