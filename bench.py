@@ -392,6 +392,7 @@ def main():
     standalone = None
     self_check = None
     proof_ms = None
+    solo_sums, solo_cnt = [0.0] * 8, 0
     if not args.no_self_check:
         os.environ["KZG_SINGLE_STREAM"] = "1"   # read when a handle is made
         solo = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1])
@@ -422,6 +423,7 @@ def main():
         false_b = [b for b, r in enumerate(res) if r is False]
         err_b = [b for b, r in enumerate(res) if r is None]
         want_f, want_e = ([bf], [be]) if bf != be else ([], [be])
+        solo_sums, solo_cnt = solo.timing_totals()
         self_check = {"batches": G, "blobs": n * G, "poisoned": {"wrong_proof_in_batch": bf, "non_canonical_element_in_batch": be},
                       "false_batches": false_b, "err_batches": err_b, "true_batches": sum(1 for r in res if r is True),
                       "passed": false_b == want_f and err_b == want_e and sum(1 for r in res if r is True) == G - len(set(want_f + want_e))}
@@ -481,7 +483,7 @@ def main():
                               "%d blobs - %s" % (pmc_file, pmc["blobs_per_launch"], "the same launch size as this run, not re-measured by it" if same else
                                                  "EXTRAPOLATED linearly to this run's %d blobs per launch" % units))
         path = list(PMC_NAME.values()) + ["kzg::k_msm_combine", "kzg::k_msm_combine_lanes", "kzg::k_batch_scalars", "kzg::k_glv_split", "kzg::k_mult_to_affine29",
-                                           "kzg::k_eval_powers", "kzg::k_eval_finish"]
+                                           "kzg::k_eval_powers", "kzg::k_eval_finish", "kzg::k_msm_reduce<false>", "kzg::k_msm_reduce<true>"]
         insts = sum(prof[k].get("SQ_INSTS_VALU", 0) for k in path if k in prof)
         per_blob = insts / pmc["blobs_per_launch"]  # wave-instructions per blob, all kernels of the path
         simds, clock = 1024, 2.4e9
@@ -525,6 +527,10 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": ALG_BYTES[dom] * units,
                      "launch_ms_incl_warmup": round((sums[5] + warm_sum5) / max(cnt + warm_cnt, 1), 4) if stamped else None,
+                     # every launch of this kernel at this size in the process: warm-up + timed groups in flight, and the stand-alone /
+                     # self-check groups - the population behind the kernel's AverageNs in a rocprofv3 --stats of this command
+                     "launch_ms_all_launches": round((sums[5] + warm_sum5 + solo_sums[5]) / max(cnt + warm_cnt + solo_cnt, 1), 4) if stamped else None,
+                     "launches": cnt + warm_cnt + solo_cnt if stamped else None,
                      "launch_ms_source": ("live: the kernel's own execution interval, stamped inside the kernel with s_memrealtime (first wavefront in, last "
                                           "wavefront out) and averaged over the %d launch groups of the timed region, %d groups in flight (residency, not cost); "
                                           "launch_ms_incl_warmup averages the %d warm-up groups in as well - the population rocprofv3 --kernel-trace --stats of "
@@ -535,7 +541,7 @@ def main():
         "path": {"algorithmic_bytes_per_blob": PATH_ALG_BYTES, "algorithmic_GBps": round(path_gbps, 2), "frac": round(path_gbps / HBM_PEAK_GBS, 6),
                  "hbm_traffic_ratio": path_ratio,
                  "note": "whole path per GPU: 131 232 algorithmic bytes per blob x blobs/s; hbm_traffic_ratio = PMC HBM bytes of every kernel of the path / "
-                         "algorithmic bytes (profiles/%s; the blob is streamed twice - hash, then evaluate - and the MSM re-reads its table rows)" % pmc_file},
+                         "algorithmic bytes (profiles/%s; the blob is streamed twice: hash, then evaluate)" % pmc_file},
         "valu": valu,
         "kernel_ms_standalone": {k: round(v, 4) for k, v in standalone.items()} if standalone else None,
         "kernel_ms_in_flight": {"k_blob_challenge": round(kernels["k_blob_challenge"], 4),
