@@ -1,9 +1,10 @@
 """Pure-Python big-int model of BLS12-381 + the KZG verification protocol.
 
 TEST INFRASTRUCTURE ONLY (part of oracle/): slow, naive, written from the public curve
-parameters and from the reference's protocol flow. Used to (a) derive every constant
-the C oracle and the HIP code embed (tools/gen_constants.py), (b) cross-check the C
-oracle's intermediates on small cases.  Never imported by the product path.
+parameters and from the reference's protocol flow. Used to (a) validate the pairing programs on the
+CPU (tests/test_slp_pairing.py) and (b) cross-check the C oracle's intermediates and constants on
+small cases (tests/test_constants.py).  Never imported by the product path or its build: the
+constants the HIP code embeds come from tools/gen_constants.py over tools/bls_params.py.
 
 Protocol flow follows /root/reference/src/kzg_proof.rs (cited per function).
 Curve definitions: p, r, x = -0xd201000000010000, E: y^2 = x^3 + 4,

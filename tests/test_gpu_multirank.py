@@ -160,6 +160,25 @@ def test_bench_script_two_ranks_shared_gpu():
     assert d["config"]["batches_per_step"] == 16 and d["multi_gpu"]["ranks"] == 2
 
 
+def test_bench_script_bare_command_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` WITHOUT a launcher (no WORLD_SIZE in the environment): the script must start the two
+    ranks itself - fresh child processes, before anything touched the GPU - run the same N > 1 path as under
+    torch.distributed.run and print rank 0's one JSON line (KZG_BENCH_SHARE_GPU=1: both ranks on the box's one GPU, gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["KZG_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--group", "4", "--blobs", "256",
+           "--no-cpu-baseline", "--no-latency", "--workload", "configs1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["multi_gpu"]["ranks"] == 2
+    assert d["self_check"]["passed"] is True
+
+
 def _nccl_worker(port, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, ROOT)
