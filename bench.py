@@ -263,9 +263,15 @@ def main():
     else:
         depth = (F - 1, 0, 1)
     n_handles = sum(depth) + 1
-    handles = [settings] + [api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1]) for _ in range(n_handles - 1)]
-    backends = [backend0] + [HipBackend(h) for h in handles[1:]]
-    pipe = PipelinedVerifier(backends, dist, coll_dev, depth, equal_shards=True)
+    if world == 1:
+        # ONE GPU: the groups are kept in flight INSIDE the library (kzg_verify_blob_kzg_proof_batch_groups_device,
+        # csrc/capi_pipeline.hpp: the same fixed-order pipeline behind one C call - the entry point a C / Rust caller with many
+        # batches has); the handle grows its own per-group lanes
+        handles, backends, pipe = [settings], [backend0], None
+    else:
+        handles = [settings] + [api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1]) for _ in range(n_handles - 1)]
+        backends = [backend0] + [HipBackend(h) for h in handles[1:]]
+        pipe = PipelinedVerifier(backends, dist, coll_dev, depth, equal_shards=True)
     # every batch is a different permutation of the rank's shard (different transcript and r), at its own HBM address:
     # one variant (G x n blobs = G x 128 MiB) per handle, so the groups in flight stream disjoint memory
     gen = torch.Generator(device="cpu").manual_seed(7 + rank)
@@ -289,7 +295,10 @@ def main():
         for i in range(k):
             v = variants[i % n_handles]
             groups.append(((v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), n), G))
-        res = pipe.run(groups)
+        if pipe is None:
+            res = api.verify_blob_kzg_proof_batch_groups_device([g[0][:3] for g in groups], n, G, settings, in_flight=F)
+        else:
+            res = pipe.run(groups)
         if not all(all(r) for r in res):
             raise SystemExit("verification of a valid synthetic batch returned false")
         return groups
@@ -523,7 +532,10 @@ def main():
                                   "BASELINE.json configs[1]" if n == 1024 and world == 1 else
                                   "BASELINE.json configs[4]" + ("" if world == 8 else " shard shape: 32 768 blobs per GPU") if n == 32768 else "custom size", G, n * G),
                    "blobs_per_gpu_per_batch": n, "batch": n * world, "batches_per_step": G, "blobs_per_step": n * world * G,
-                   "parallelism": "shard-by-blob x%d" % world, "groups_in_flight": F},
+                   "parallelism": "shard-by-blob x%d" % world, "groups_in_flight": F,
+                   "entry_point": "kzg_verify_blob_kzg_proof_batch_groups_device: ONE C call for all %d launch groups of the timed region, %d in flight "
+                                  "inside the library" % (K, F) if world == 1 else
+                                  "kzg_shard_*_launch/_wait phases driven by kzg_rs_amd.distributed.PipelinedVerifier, one process per GPU"},
         # launch_ms / achieved / frac: the kernel's average duration over the launches of the timed region - what rocprofv3
         # --kernel-trace --stats reports for this command (with %d groups in flight that is its RESIDENCY: it shares the chip);
         # standalone_ms / frac_standalone: the same kernel with the chip to itself - its cost.

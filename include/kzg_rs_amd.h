@@ -186,6 +186,16 @@ KzgRet kzg_verify_blob_kzg_proof_batches_device(bool *ok_out, uint8_t *err_out, 
                                                 const void *d_commitments, const void *d_proofs, size_t n,
                                                 size_t n_batches, const KzgSettings *s);
 
+/* MANY launch groups through one call, kept in flight inside the library (csrc/capi_pipeline.hpp): n_groups groups of
+ * batches_per_group independent batches of n blobs each, group g at d_blobs[g] / d_commitments[g] / d_proofs[g] (device
+ * memory, the group's batches contiguous; pointers may repeat); `in_flight` groups overlap on private per-group handles of
+ * the same device (0 = the default, 3).  ok_out / err_out (optional): [n_groups][batches_per_group], as in the one-group form.
+ * This is the entry point behind the benchmark's headline: 256 batches of 1 024 blobs per group, 3 groups in flight. */
+KzgRet kzg_verify_blob_kzg_proof_batch_groups_device(bool *ok_out, uint8_t *err_out, const void *const *d_blobs,
+                                                     const void *const *d_commitments, const void *const *d_proofs, size_t n,
+                                                     size_t batches_per_group, size_t n_groups, size_t in_flight,
+                                                     const KzgSettings *s);
+
 /* The same for HOST-resident inputs (n_batches Vec<Blob>s back to back): the batches cross PCIe in chunks on a copy stream
  * while the previous chunk is verified, so a stream of host batches runs at the link's rate (~56 GB/s = ~0.43 M blobs/s on
  * MI355X) instead of copy + compute per call.  Same result convention as the device form. */

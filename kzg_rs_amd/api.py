@@ -91,6 +91,7 @@ def lib():
         L.kzg_verify_blob_kzg_proof_batch_device.argtypes = [bp, vp, vp, vp, sz, vp]
         L.kzg_verify_blob_kzg_proof_batches_device.argtypes = [bp, u8, vp, vp, vp, sz, sz, vp]
         L.kzg_verify_blob_kzg_proof_batches.argtypes = [bp, u8, vp, vp, vp, sz, sz, vp]
+        L.kzg_verify_blob_kzg_proof_batch_groups_device.argtypes = [bp, u8, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), sz, sz, sz, sz, vp]
         L.kzg_compute_challenges.argtypes = [u8, u8, u8, sz, vp]
         L.kzg_evaluate_polynomials.argtypes = [u8, u8, u8, sz, vp]
         L.kzg_evaluate_polynomials_device.argtypes = [vp, vp, vp, sz, vp]
@@ -377,6 +378,20 @@ def verify_blob_kzg_proof_batches_device(d_blobs, d_commitments, d_proofs, n, n_
     _chk(lib().kzg_verify_blob_kzg_proof_batches_device(ok, err, d_blobs, d_commitments, d_proofs, n, n_batches,
                                                         kzg_settings._h))
     return [None if err.raw[b] else bool(ok[b]) for b in range(n_batches)]
+
+
+def verify_blob_kzg_proof_batch_groups_device(groups, n, batches_per_group, kzg_settings, in_flight=3):
+    """Many launch groups through ONE C call, `in_flight` of them overlapping inside the library: groups = [(d_blobs,
+    d_commitments, d_proofs), ...] device pointers of groups of `batches_per_group` batches of n blobs.  Returns one list per
+    group with True / False per batch, or None where the reference would return Err."""
+    k, B, vp = len(groups), batches_per_group, C.c_void_p
+    if k == 0:
+        return []
+    b, c, p = (vp * k)(*[g[0] for g in groups]), (vp * k)(*[g[1] for g in groups]), (vp * k)(*[g[2] for g in groups])
+    ok = (C.c_bool * (k * B))()
+    err = C.create_string_buffer(k * B)
+    _chk(lib().kzg_verify_blob_kzg_proof_batch_groups_device(ok, err, b, c, p, n, B, k, in_flight, kzg_settings._h))
+    return [[None if err.raw[g * B + i] else bool(ok[g * B + i]) for i in range(B)] for g in range(k)]
 
 
 def verify_blob_kzg_proof_batches(blobs, commitments, proofs, n, n_batches, kzg_settings):

@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
 # 3.7 minutes of a build) is cached under build/devcache, keyed by the device-side sources and by the kernel
 # instantiations the host files launch.  `--force` (and any cold build) runs every step.
 HOST_ONLY = ("capi_host_util.hpp", "capi_pieces.hpp", "capi_prover.hpp", "capi_settings.hpp", "capi_verify.hpp",
-             "capi_multi.hpp", "host_only.hpp", "kzg_capi.hip")
+             "capi_multi.hpp", "capi_pipeline.hpp", "host_only.hpp", "kzg_capi.hip")
 
 
 def _device_key(csrc, flags):

@@ -100,9 +100,17 @@ extern "C" KzgRet kzg_timing_totals(const KzgSettings* s, double out_sum_ms[8], 
     std::lock_guard<std::mutex> lk(s->mu);
     memcpy(out_sum_ms, s->tsum, sizeof(double) * 8);
     *count = s->tcount;
+    for (const KzgSettings* l : s->lanes) {  // the groups that ran on the handle's pipeline lanes (capi_pipeline.hpp) count as its own
+        for (int i = 0; i < 8; i++) out_sum_ms[i] += l->tsum[i];
+        *count += l->tcount;
+    }
     if (reset) {
         memset(s->tsum, 0, sizeof s->tsum);
         s->tcount = 0;
+        for (const KzgSettings* l : s->lanes) {
+            memset(l->tsum, 0, sizeof l->tsum);
+            l->tcount = 0;
+        }
     }
     return KZG_OK;
 }

@@ -95,6 +95,9 @@ struct KzgSettings {
     // the device list and the exchange (in-process RCCL communicators, or host staging).
     std::vector<KzgSettings*> peers;
     struct MultiState* multi = nullptr;
+    // further private handles on THIS device (capi_pipeline.hpp): one per launch group kept in flight beyond the first
+    mutable std::vector<KzgSettings*> lanes;
+    uint8_t tau_g2_bytes[96] = {};  // g2_points[1] as given: what a lane is built from
     mutable float multi_ms[8] = {};  // host wall-clock of the last sharded call: [0] whole call [1] copy + phase 1 [2] r hash [3] phase 2 [4] exchange [5] fold + pairing
 };
 static void multi_free(KzgSettings* s);
@@ -204,6 +207,7 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
     return KZG_OK;
 }
 static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
+    memcpy(s->tau_g2_bytes, tau_g2, 96);
     HIPCHK(hipGetDevice(&s->device));  // the calling thread's current device (multi_build sets it per shard)
     HIPCHK(hipStreamCreateWithFlags(&s->s_plain[0], hipStreamNonBlocking));
     s->s1 = s->s_sha = s->s_plain[0];
@@ -458,6 +462,8 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     multi_free(s);  // communicators and peer handles first (each on its own device)
+    for (KzgSettings* l : s->lanes) kzg_settings_free(l);
+    s->lanes.clear();
     (void)hipSetDevice(s->device);
     ws_free(s->ws);
     void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_eval_scratch, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob, s->verify2.blob, s->d_prep29};

@@ -1102,3 +1102,56 @@ def test_msm_sum_quads(settings):
     run([G1_INF] * 8)
     run([gen[0], neg(gen[0])])
     assert neg(neg(gen[3])) == gen[3]
+
+
+def test_launch_groups_pipelined_inside_the_library():
+    """kzg_verify_blob_kzg_proof_batch_groups_device (csrc/capi_pipeline.hpp): many launch groups through ONE C call, several
+    of them in flight on the handle's private lanes.  Seven groups of three 6-blob batches built from the mainnet tuples -
+    among them a corrupted proof, a non-canonical field element and an off-curve commitment, in different groups and lanes -
+    must give, batch by batch, what the oracle gives, at every pipeline depth (1: in sequence on the handle itself; 2, 3,
+    5: lanes), twice on the same handle (lanes reused), and repeated group pointers are allowed."""
+    import torch
+    st = KzgSettings.load_trusted_setup_file()
+    ost = O.Settings.mainnet()
+    tuples = G.valid_blob_tuples()
+    n, B, K = 6, 3, 7
+    groups, want, keep = [], [], []
+    rng = random.Random(41)
+    for g in range(K):
+        gb, gc, gp, wg = [], [], [], []
+        for b in range(B):
+            t = tuples[:]
+            rng.shuffle(t)
+            bl, c, p = [list(x) for x in zip(*t[:n])]
+            kind = (g * B + b) % 7
+            if kind == 2:
+                k = rng.randrange(n)
+                p[k] = O.g1_add(p[k], G1_GEN)
+            elif kind == 4:
+                x = bytearray(bl[3])
+                x[32 * 100: 32 * 101] = R.to_bytes(32, "big")
+                bl[3] = bytes(x)
+            elif kind == 6:
+                c[5] = bytes([0x81]) + bytes(range(1, 48))
+            try:
+                wg.append(O.verify_blob_kzg_proof_batch(bl, c, p, ost))
+            except O.OracleError:
+                wg.append(None)
+            gb += bl
+            gc += c
+            gp += p
+        t3 = [torch.frombuffer(bytearray(b"".join(x)), dtype=torch.uint8).cuda() for x in (gb, gc, gp)]
+        keep.append(t3)
+        groups.append(tuple(t.data_ptr() for t in t3))
+        want.append(wg)
+    torch.cuda.synchronize()
+    flat = [x for w in want for x in w]
+    assert flat.count(None) >= 4 and flat.count(False) >= 2 and flat.count(True) >= 8
+    for depth in (1, 2, 3, 5, 3):
+        assert api.verify_blob_kzg_proof_batch_groups_device(groups, n, B, st, in_flight=depth) == want, depth
+    twice = groups + groups[:2]
+    assert api.verify_blob_kzg_proof_batch_groups_device(twice, n, B, st, in_flight=3) == want + want[:2]
+    assert api.verify_blob_kzg_proof_batch_groups_device([], n, B, st) == []
+    # the one-group form on the same handle still works after the lanes exist, and the totals include the lanes' groups
+    assert api.verify_blob_kzg_proof_batches_device(groups[1][0], groups[1][1], groups[1][2], n, B, st) == want[1]
+    assert st.timing_totals()[1] >= 7 * 5
