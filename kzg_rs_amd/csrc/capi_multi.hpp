@@ -247,17 +247,32 @@ static KzgRet multi_batch_locked(bool* ok, const std::vector<ShardIn>& in, Multi
     };
     if (active > 1) {
         std::vector<std::thread> pool;
-        for (size_t k = 1; k < D; k++) pool.emplace_back(stage_a, k);
+        for (size_t k = 1; k < D; k++) {
+            try {
+                pool.emplace_back(stage_a, k);
+            } catch (const std::system_error&) {  // no thread to be had: this shard runs on the calling thread
+                stage_a(k);
+            }
+        }
         stage_a(0);
         for (auto& th : pool) th.join();
     } else {
         for (size_t k = 0; k < D; k++) stage_a(k);
     }
     HIPCHK(hipSetDevice(s->device));
+    auto clear_groups = [&] {  // no shard keeps a group "in flight" behind a call that has ended
+        for (size_t k = 0; k < D; k++) shard_of(s, k)->ws.pending_n = shard_of(s, k)->ws.pending_b = shard_of(s, k)->ws.finish_b = 0;
+    };
     for (size_t k = 0; k < D; k++)
-        if (rcs[k] != KZG_OK) return fail(rcs[k], msgs[k]);
+        if (rcs[k] != KZG_OK) {
+            clear_groups();
+            return fail(rcs[k], msgs[k]);
+        }
     for (size_t k = 0; k < D; k++)  // the reference's Err for an undecodable point / non-canonical element, whichever shard holds it
-        if (bad[k]) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+        if (bad[k]) {
+            clear_groups();
+            return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+        }
     s->multi_ms[1] = (float)ms_since(t_call);
     // ---- r: the whole transcript hashed once, here
     auto t0 = std::chrono::steady_clock::now();
@@ -276,6 +291,7 @@ static KzgRet multi_batch_locked(bool* ok, const std::vector<ShardIn>& in, Multi
         }
         (void)hipGetLastError();
         (void)hipSetDevice(s->device);
+        clear_groups();
         g_err = msg;
         return code;
     };
@@ -349,9 +365,13 @@ static bool multi_takes(const KzgSettings* s, size_t n) { return s->multi && n >
 // one array of n blobs (host memory, or device memory of the first device) through the shards; the caller holds s->mu
 static KzgRet multi_array_locked(bool* ok, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n, bool host,
                                  const KzgSettings* s) {
-    std::vector<ShardIn> in;
-    multi_split(in, blobs, commitments, proofs, n, shard_count(s));
-    return multi_batch_locked(ok, in, host ? MultiSrc::Host : MultiSrc::Primary, s);
+    try {  // (host buffers of the call: 160 bytes per blob of transcript records; nothing may be thrown across the C ABI)
+        std::vector<ShardIn> in;
+        multi_split(in, blobs, commitments, proofs, n, shard_count(s));
+        return multi_batch_locked(ok, in, host ? MultiSrc::Host : MultiSrc::Primary, s);
+    } catch (const std::bad_alloc&) {
+        return fail(KZG_MALLOC, "host buffers of the sharded call");
+    }
 }
 
 // ---- entry points (include/kzg_rs_amd.h)
@@ -390,14 +410,18 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_sharded(bool* ok, const void* 
         return kzg_verify_blob_kzg_proof_batch_device(ok, d_blobs[k], d_commitments[k], d_proofs[k], n_local[k], s);
     }
     std::lock_guard<std::mutex> lk(s->mu);
-    std::vector<ShardIn> in(n_shards);
-    for (size_t k = 0; k < n_shards; k++) {
-        in[k].blobs = (const uint8_t*)d_blobs[k];
-        in[k].c = (const uint8_t*)d_commitments[k];
-        in[k].p = (const uint8_t*)d_proofs[k];
-        in[k].n = n_local[k];
+    try {
+        std::vector<ShardIn> in(n_shards);
+        for (size_t k = 0; k < n_shards; k++) {
+            in[k].blobs = (const uint8_t*)d_blobs[k];
+            in[k].c = (const uint8_t*)d_commitments[k];
+            in[k].p = (const uint8_t*)d_proofs[k];
+            in[k].n = n_local[k];
+        }
+        return multi_batch_locked(ok, in, MultiSrc::PerDevice, s);
+    } catch (const std::bad_alloc&) {
+        return fail(KZG_MALLOC, "host buffers of the sharded call");
     }
-    return multi_batch_locked(ok, in, MultiSrc::PerDevice, s);
 }
 
 // the shape of a handle: its devices (shard k on devices_out[k]), and how the partial sums travel (0 single device, 1 host

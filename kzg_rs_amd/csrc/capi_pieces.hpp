@@ -89,7 +89,7 @@ extern "C" KzgRet kzg_evaluate_polynomials(uint8_t* ys_out, const uint8_t* blobs
     return KZG_OK;
 }
 
-extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const uint8_t* points48, size_t n, const KzgSettings* s) {
+extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const uint8_t* points48, size_t n, const KzgSettings* s) try {
     if (!s || !status_out || !points48) return fail(KZG_BADARGS, "null argument");
     if (n == 0) return KZG_OK;
     std::lock_guard<std::mutex> lk(s->mu);
@@ -113,9 +113,11 @@ extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const 
         HIPCHK(hipStreamSynchronize(s->s1));
     }
     return KZG_OK;
+} catch (const std::bad_alloc&) {
+    return fail(KZG_MALLOC, "host buffers of the call");  // (nothing is thrown across the C ABI)
 }
 
-extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uint8_t* scalars, size_t n, const KzgSettings* s) {
+extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uint8_t* scalars, size_t n, const KzgSettings* s) try {
     if (!s || !out || (n && (!points48 || !scalars))) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
@@ -186,9 +188,11 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     HIPCHK(hipStreamSynchronize(s->s1));
     elapsed(&s->timings[2], s->ev[2], s->ev[3]);
     return KZG_OK;
+} catch (const std::bad_alloc&) {
+    return fail(KZG_MALLOC, "host buffers of the call");  // (nothing is thrown across the C ABI)
 }
 
-extern "C" KzgRet kzg_g1_mul_generator(uint8_t* out48, const uint8_t* scalars, size_t n, const KzgSettings* s) {
+extern "C" KzgRet kzg_g1_mul_generator(uint8_t* out48, const uint8_t* scalars, size_t n, const KzgSettings* s) try {
     if (!s || (n && (!out48 || !scalars))) return fail(KZG_BADARGS, "null argument");
     if (n == 0) return KZG_OK;
     std::lock_guard<std::mutex> lk(s->mu);
@@ -212,6 +216,8 @@ extern "C" KzgRet kzg_g1_mul_generator(uint8_t* out48, const uint8_t* scalars, s
     HIPCHK(hipMemcpyAsync(out48, d_o, 48 * n, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
     return KZG_OK;
+} catch (const std::bad_alloc&) {
+    return fail(KZG_MALLOC, "host buffers of the call");  // (nothing is thrown across the C ABI)
 }
 
 extern "C" KzgRet kzg_pairing_check(bool* ok, const uint8_t a[48], const uint8_t b[48], const KzgSettings* s) {

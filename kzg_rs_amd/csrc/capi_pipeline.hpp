@@ -37,7 +37,11 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_groups_device(bool* ok_out, ui
     for (size_t i = 0; i < std::min(S, K); i++)
         if ((rc = ws_reserve(lane(i), n * B, B, STAGE_NONE)) != KZG_OK) return rc;
     std::vector<uint8_t> err_local;
-    if (!err_out) err_local.resize(K * B);
+    try {
+        if (!err_out) err_local.resize(K * B);
+    } catch (const std::bad_alloc&) {
+        return fail(KZG_MALLOC, "per-batch error flags");
+    }
     uint8_t* const err = err_out ? err_out : err_local.data();
     // an error leaves groups in flight on the lanes: drain every stream before it goes back (the first message is kept)
     auto drained = [&](KzgRet code) {

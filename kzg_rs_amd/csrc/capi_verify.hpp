@@ -917,7 +917,7 @@ extern "C" KzgRet kzg_verify_kzg_proof(bool* ok, const uint8_t commitment[48], c
 // KzgProof::verify_kzg_proof_batch (src/kzg_proof.rs:399-444) over byte inputs: n (commitment, z, y, proof) tuples checked
 // with ONE random linear combination and ONE pairing.  Same pipeline as the blob batch minus challenge + evaluation.
 extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitments, const uint8_t* zs, const uint8_t* ys,
-                                             const uint8_t* proofs, size_t n, const KzgSettings* s) {
+                                             const uint8_t* proofs, size_t n, const KzgSettings* s) try {
     if (!ok || !s) return fail(KZG_BADARGS, "null argument");
     if (n == 0) {  // compute_r_powers on an empty batch: both MSMs are the identity, e(O, .) == e(O, .)
         *ok = true;
@@ -989,4 +989,6 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
     }
     *ok = paired;
     return KZG_OK;
+} catch (const std::bad_alloc&) {
+    return fail(KZG_MALLOC, "host buffers of the call");  // (nothing is thrown across the C ABI)
 }
