@@ -585,8 +585,9 @@ def main():
                                     "times of rank 0, overlapped with the GPU work of the other groups in flight"}
         # ONE process over all the GPUs through a multi-device handle and the reference's call shape (the ranks have left the
         # GPUs by now).  A child process: a failure or a hang there costs this leg, not the line.
-        if not share and os.environ.get("KZG_BENCH_SINGLE_PROCESS", "1") != "0":
-            out["multi_gpu"]["single_process"] = run_single_process_child(",".join(str(i) for i in range(world)), n)
+        sp = os.environ.get("KZG_BENCH_SINGLE_PROCESS", "1")
+        if sp != "0" and (not share or sp == "force"):  # (ranks sharing one GPU: only when a test asks for it - the list then names device 0 `world` times)
+            out["multi_gpu"]["single_process"] = run_single_process_child(",".join("0" if share else str(i) for i in range(world)), n)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blobs, cs, ps, synth.synthetic_setup()[1], args.cpu_sample)
     print(json.dumps(out))

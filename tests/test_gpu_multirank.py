@@ -168,6 +168,7 @@ def test_bench_script_bare_command_starts_its_own_ranks():
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["KZG_BENCH_SHARE_GPU"] = "1"
+    env["KZG_BENCH_SINGLE_PROCESS"] = "force"  # also the one-process leg (a child process over the device list "0,0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--group", "4", "--blobs", "256",
            "--no-cpu-baseline", "--no-latency", "--workload", "configs1"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
@@ -177,6 +178,8 @@ def test_bench_script_bare_command_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["multi_gpu"]["ranks"] == 2
     assert d["self_check"]["passed"] is True
+    sp = d["multi_gpu"]["single_process"]
+    assert sp.get("ok") is True and sp["corrupted_proof_on_last_device"] is False and sp["batch"] == 512 and sp["devices"] == [0, 0], sp
 
 
 def _nccl_worker(port, q):
