@@ -74,7 +74,10 @@ KzgRet kzg_settings_from_tau_g2(KzgSettings **out, const uint8_t tau_g2[96]);
  * other entry point runs there.  The plain constructors above read KZG_DEVICES ("all" or "0,1,2,...") from the
  * environment, so an unchanged caller gets the same handle without a source change.  If librccl cannot be loaded, or
  * the list names a device twice (test rigs), the partial sums travel through pinned host memory instead
- * (KZG_MULTI_EXCHANGE=host forces that, =rccl makes the fallback an error). */
+ * (KZG_MULTI_EXCHANGE=host forces that, =rccl makes the fallback an error).  kzg_verify_blob_kzg_proof_batches (the
+ * host-fed STREAM of independent batches) on such a handle deals contiguous ranges of whole batches to the devices, each
+ * streamed over its own PCIe link; the other many-batch forms (_batches_device, _batch_groups_device, kzg_shard_*) run on
+ * devices[0]. */
 KzgRet kzg_settings_load_trusted_setup_devices(KzgSettings **out, const char *txt, size_t len, const int *devices,
                                                size_t n_devices);
 KzgRet kzg_settings_from_tau_g2_devices(KzgSettings **out, const uint8_t tau_g2[96], const int *devices, size_t n_devices);

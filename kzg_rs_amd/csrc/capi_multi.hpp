@@ -374,6 +374,45 @@ static KzgRet multi_array_locked(bool* ok, const uint8_t* blobs, const uint8_t* 
     }
 }
 
+// A STREAM of host batches over the shards: batches [k B / D, (k + 1) B / D) go to shard k, which runs the single-device stream
+// (chunked copies on its own copy stream overlapped with verification) on a host thread of its own.  Batches are independent,
+// so there is no exchange at all.  The caller holds s->mu.
+static KzgRet multi_host_stream_locked(bool* ok_out, uint8_t* err_out, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs,
+                                       size_t n, size_t n_batches, const KzgSettings* s) {
+    const size_t D = shard_count(s);
+    std::vector<KzgRet> rcs(D, KZG_OK);
+    std::vector<std::string> msgs(D);
+    auto run = [&](size_t k) {
+        const size_t b0 = n_batches * k / D, b1 = n_batches * (k + 1) / D;
+        if (b0 == b1) return;
+        const KzgSettings* c = shard_of(s, k);
+        if (hipSetDevice(c->device) != hipSuccess) {
+            rcs[k] = KZG_ERROR;
+            msgs[k] = "HIP: hipSetDevice";
+            return;
+        }
+        rcs[k] = host_stream_locked(ok_out + b0, err_out ? err_out + b0 : nullptr, blobs + b0 * n * (size_t)BLOB_BYTES, commitments + 48 * b0 * n,
+                                    proofs + 48 * b0 * n, n, b1 - b0, c);
+        if (rcs[k] != KZG_OK) msgs[k] = g_err;
+    };
+    {
+        std::vector<std::thread> pool;
+        for (size_t k = 1; k < D; k++) {
+            try {
+                pool.emplace_back(run, k);
+            } catch (const std::system_error&) {
+                run(k);
+            }
+        }
+        run(0);
+        for (auto& th : pool) th.join();
+    }
+    HIPCHK(hipSetDevice(s->device));
+    for (size_t k = 0; k < D; k++)
+        if (rcs[k] != KZG_OK) return fail(rcs[k], msgs[k]);
+    return KZG_OK;
+}
+
 // ---- entry points (include/kzg_rs_amd.h)
 // One batch whose shards are ALREADY resident on the devices of the handle: shard k = n_local[k] blobs on devices[k], global
 // blob order = shard order (BASELINE configs[4]: 8 x 32 768).  The per-device form of kzg_verify_blob_kzg_proof_batch_device.

@@ -794,9 +794,21 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
 // hipMemcpyAsync holds the calling thread until the data has left (measured: 2.4 ms per 128 MiB either way), so each chunk's
 // copy is issued in two halves around the host-side steps of the chunk in flight (flags, transcript hashes, launches).
 // KZG_HOST_CHUNK = batches per chunk (default: half the stream, at most 32).
+static KzgRet multi_host_stream_locked(bool* ok_out, uint8_t* err_out, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs,
+                                       size_t n, size_t n_batches, const KzgSettings* s);
+static KzgRet host_stream_locked(bool* ok_out, uint8_t* err_out, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n,
+                                 size_t n_batches, const KzgSettings* s);
 extern "C" KzgRet kzg_verify_blob_kzg_proof_batches(bool* ok_out, uint8_t* err_out, const uint8_t* blobs, const uint8_t* commitments,
                                                     const uint8_t* proofs, size_t n, size_t n_batches, const KzgSettings* s) {
     KZG_ENTER(s && ok_out && blobs && commitments && proofs && n && n_batches);
+    // a handle over several devices: contiguous ranges of whole batches, one per device, each streamed over that device's own
+    // PCIe link on a thread of its own (capi_multi.hpp) - the stream form is bound by the link, so the links add up
+    if (s->multi && n_batches >= 2) return multi_host_stream_locked(ok_out, err_out, blobs, commitments, proofs, n, n_batches, s);
+    return host_stream_locked(ok_out, err_out, blobs, commitments, proofs, n, n_batches, s);
+}
+// the stream on ONE device (the handle's own); the caller holds the handle's lock (or owns the handle) and has set the device
+static KzgRet host_stream_locked(bool* ok_out, uint8_t* err_out, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n,
+                                 size_t n_batches, const KzgSettings* s) {
     static const size_t chunk_forced = [] {
         const char* e = getenv("KZG_HOST_CHUNK");
         long v = e ? atol(e) : 0;

@@ -213,3 +213,36 @@ def test_env_selected_devices_for_an_unchanged_caller():
     e = dict(os.environ, KZG_DEVICES="0,0", KZG_MULTI_MIN_BLOBS="2")
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "env-devices-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_host_stream_of_batches_dealt_to_the_shards(env):
+    """kzg_verify_blob_kzg_proof_batches on a multi-device handle: contiguous ranges of whole batches per shard, each shard
+    running the single-device stream on its own thread - 7 batches of 6 mainnet blobs (2 + 2 + 3 over three shards) with a
+    corrupted proof in one batch and a non-canonical element in another, against the oracle and the single-device handle;
+    also fewer batches than shards."""
+    api, O, G = env["api"], env["O"], env["G"]
+    tuples = G.valid_blob_tuples()
+    n, B = 6, 7
+    hb, hc, hp, want = [], [], [], []
+    for b in range(B):
+        t = (tuples[b % 7:] + tuples[:b % 7])[:n]
+        bl, c, p = [list(x) for x in zip(*t)]
+        if b == 3:
+            p[2] = O.g1_add(p[2], G1_GEN)
+        if b == 5:
+            x = bytearray(bl[4])
+            x[0:32] = R.to_bytes(32, "big")
+            bl[4] = bytes(x)
+        try:
+            want.append(O.verify_blob_kzg_proof_batch(bl, c, p, env["ost"]))
+        except O.OracleError:
+            want.append(None)
+        hb += bl
+        hc += c
+        hp += p
+    assert want == [True, True, True, False, True, None, True]
+    args = (b"".join(hb), b"".join(hc), b"".join(hp))
+    assert api.verify_blob_kzg_proof_batches(*args, n, B, env["st3"]) == want
+    assert api.verify_blob_kzg_proof_batches(*args, n, B, env["st1"]) == want
+    two = (args[0][: 131072 * n * 2], args[1][: 48 * n * 2], args[2][: 48 * n * 2])
+    assert api.verify_blob_kzg_proof_batches(*two, n, 2, env["st3"]) == want[:2]
