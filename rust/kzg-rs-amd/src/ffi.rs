@@ -47,13 +47,7 @@ pub fn last_error() -> String {
 /// `KzgRet` -> `Result`: KZG_OK is "the boolean is valid" (`Ok(true)` / `Ok(false)`), everything else one of the
 /// reference's `Err(KzgError::...)` (include/kzg_rs_amd.h, "Conventions").
 pub fn check(rc: c_int) -> Result<(), KzgError> {
-    match rc {
-        KZG_OK => Ok(()),
-        KZG_BADARGS => Err(KzgError::BadArgs(last_error())),
-        KZG_INVALID_LENGTH => Err(KzgError::InvalidBytesLength(last_error())),
-        KZG_BAD_SETUP => Err(KzgError::InvalidTrustedSetup(last_error())),
-        _ => Err(KzgError::InternalError), // KZG_ERROR, KZG_MALLOC
-    }
+    KzgError::from_ret(rc, last_error)
 }
 
 /// Owner of one `KzgSettings*` of the library.  The library serialises calls on a handle internally and the handle is

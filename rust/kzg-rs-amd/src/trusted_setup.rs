@@ -134,7 +134,9 @@ pub fn get_kzg_settings() -> KzgSettings {
     KzgSettings::load_trusted_setup_file().expect("failed to load default trusted setup")
 }
 
-/// kzg-rs `src/trusted_setup.rs:52-92`, with its identity-based `PartialEq` / `Hash`.
+/// kzg-rs `src/trusted_setup.rs:52-92`: the default (mainnet) settings or a caller's own behind an `Arc`.  Two values are
+/// equal when both are `Default` or both hold the SAME `Arc` (pointer identity, not table contents), and they hash
+/// accordingly - what a revm-style cache keyed by settings relies on.
 #[derive(Debug, Clone, Default, Eq)]
 pub enum EnvKzgSettings {
     #[default]
@@ -142,34 +144,36 @@ pub enum EnvKzgSettings {
     Custom(Arc<KzgSettings>),
 }
 
+impl EnvKzgSettings {
+    /// The address that identifies a custom value (`None` for `Default`).
+    fn identity(&self) -> Option<*const KzgSettings> {
+        match self {
+            EnvKzgSettings::Default => None,
+            EnvKzgSettings::Custom(arc) => Some(Arc::as_ptr(arc)),
+        }
+    }
+
+    /// The settings to verify against; the default ones are loaded once per process, on first use.
+    pub fn get(&self) -> &KzgSettings {
+        static MAINNET: Once<KzgSettings> = Once::new();
+        match self {
+            EnvKzgSettings::Custom(arc) => arc,
+            EnvKzgSettings::Default => MAINNET.call_once(|| KzgSettings::load_trusted_setup_file().expect("failed to load default trusted setup")),
+        }
+    }
+}
+
 impl PartialEq for EnvKzgSettings {
     fn eq(&self, other: &Self) -> bool {
-        match (self, other) {
-            (Self::Default, Self::Default) => true,
-            (Self::Custom(a), Self::Custom(b)) => Arc::ptr_eq(a, b),
-            _ => false,
-        }
+        self.identity() == other.identity()
     }
 }
 
 impl Hash for EnvKzgSettings {
     fn hash<H: Hasher>(&self, state: &mut H) {
         core::mem::discriminant(self).hash(state);
-        match self {
-            Self::Default => {}
-            Self::Custom(settings) => Arc::as_ptr(settings).hash(state),
-        }
-    }
-}
-
-impl EnvKzgSettings {
-    pub fn get(&self) -> &KzgSettings {
-        match self {
-            Self::Default => {
-                static DEFAULT: Once<KzgSettings> = Once::new();
-                DEFAULT.call_once(|| KzgSettings::load_trusted_setup_file().expect("failed to load default trusted setup"))
-            }
-            Self::Custom(settings) => settings,
+        if let Some(p) = self.identity() {
+            p.hash(state);
         }
     }
 }
