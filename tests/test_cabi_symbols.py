@@ -100,3 +100,21 @@ def test_batch_challenges_is_host_code_and_matches_the_oracle():
             want = O.compute_r(b"".join(x[:48] for x in rec), b"".join(x[48:80][::-1] for x in rec), b"".join(x[80:112][::-1] for x in rec),
                                b"".join(x[112:] for x in rec), n_total)
             assert out.raw[32 * b: 32 * b + 32][::-1] == want, (world, B, n, b)
+
+
+def test_library_asks_for_eight_hardware_queues_unless_the_caller_chose():
+    """The load-time constructor (csrc/capi_host_util.hpp): GPU_MAX_HW_QUEUES=8 in the process environment once the library
+    is loaded - ROCm's default of 4 costs the many-groups entry point 5 % - and a value the caller has set is left alone."""
+    import subprocess
+    import sys
+    from kzg_rs_amd import api, build
+    build.build()
+    LIB = api.LIB_PATH
+    code = ("import ctypes, os\n"
+            "ctypes.CDLL(%r)\n"
+            "g = ctypes.CDLL(None).getenv; g.restype = ctypes.c_char_p\n"
+            "print(g(b'GPU_MAX_HW_QUEUES').decode())\n" % LIB)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "5"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "5"
