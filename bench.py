@@ -411,9 +411,8 @@ def main():
     proof_ms = None
     solo_sums, solo_cnt = [0.0] * 8, 0
     if not args.no_self_check:
-        os.environ["KZG_SINGLE_STREAM"] = "1"   # read when a handle is made
-        solo = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1])
-        os.environ.pop("KZG_SINGLE_STREAM")
+        with api.options(single_stream=1):   # read when a handle is made
+            solo = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1])
         v = variants[0]
         solo_res = None
         for _ in range(2):  # first pass: workspace allocation

@@ -22,6 +22,10 @@
  *   - there is NO CPU fallback: without a usable gfx950 device every call returns KZG_ERROR.
  *   - thread safety: entry points may be called concurrently with one shared settings handle
  *     (calls on one handle are serialised internally); handles are immutable after creation.
+ *   - environment: the library reads KZG_DEVICES (below) and KZG_OPTIONS ("key=value;key=value": tuning and test switches,
+ *     listed in INTEGRATION.md) and writes nothing.  The launch-group pipeline wants 8 HIP hardware queues: set
+ *     GPU_MAX_HW_QUEUES=8 in the host's environment before the HIP runtime initialises (ROCm's default is 4, ~5 % slower); a
+ *     constructor that sees fewer returns KZG_OK and leaves a note in kzg_last_error().
  */
 #ifndef KZG_RS_AMD_H
 #define KZG_RS_AMD_H
@@ -65,19 +69,28 @@ KzgRet kzg_settings_load_trusted_setup(KzgSettings **out, const char *txt, size_
 KzgRet kzg_settings_from_tau_g2(KzgSettings **out, const uint8_t tau_g2[96]);
 /* The same two constructors over a DEVICE LIST: one process, one handle, several GPUs.  A Rust caller of
  * KzgProof::verify_blob_kzg_proof_batch (src/kzg_proof.rs:472-477) is one process and passes one &KzgSettings; a handle
- * made here shards every batch of at least KZG_MULTI_MIN_BLOBS (default 256) blobs by blob, in contiguous index ranges,
- * over `devices` (HIP ordinals; shard k on devices[k]; devices == NULL or n_devices == 0: every visible device) behind the
- * UNCHANGED kzg_verify_blob_kzg_proof_batch / _device signatures: phase 1 per device (each slice over its own PCIe link),
- * one host hash of the whole transcript (:291-334), phase 2 per device from r^offset, then the north star's "G1
- * all-reduce" - an in-process RCCL all-gather (ncclCommInitAll + ncclAllGather over xGMI) of the 288-byte partial sums,
- * folded on the first device - and ONE pairing.  The handle is also a complete single-device handle on devices[0]: every
- * other entry point runs there.  The plain constructors above read KZG_DEVICES ("all" or "0,1,2,...") from the
- * environment, so an unchanged caller gets the same handle without a source change.  If librccl cannot be loaded, or
- * the list names a device twice (test rigs), the partial sums travel through pinned host memory instead
- * (KZG_MULTI_EXCHANGE=host forces that, =rccl makes the fallback an error).  kzg_verify_blob_kzg_proof_batches (the
- * host-fed STREAM of independent batches) on such a handle deals contiguous ranges of whole batches to the devices, each
- * streamed over its own PCIe link; the other many-batch forms (_batches_device, _batch_groups_device, kzg_shard_*) run on
- * devices[0]. */
+ * made here puts the whole device list (HIP ordinals; shard k on devices[k]; devices == NULL or n_devices == 0: every
+ * visible device) behind the UNCHANGED signatures:
+ *   - ONE batch (kzg_verify_blob_kzg_proof_batch / _device, at least multi_min_blobs = 256 blobs) is sharded by blob: the
+ *     array is cut into chunks dealt to the devices interleaved (chunk c -> device c mod D, ~8 chunks per device, each
+ *     crossing that device's own PCIe link); phase 1 per chunk; ONE streaming host hash consumes the transcript records
+ *     in global order while later chunks are still on their way (:291-334); phase 2 per chunk from r^offset; then the north
+ *     star's "G1 all-reduce" - the 288-byte partial sums gathered and folded on the first device - and ONE pairing.
+ *     kzg_verify_blob_kzg_proof_batch_sharded takes shards that are already resident per device (contiguous ranges), and
+ *     kzg_verify_blob_kzg_proof_batch_sharded_stream keeps several such batches in flight so that one batch's hash runs
+ *     beside the device phases of the next.
+ *   - MANY INDEPENDENT batches need no exchange: kzg_verify_blob_kzg_proof_batch_groups_device and _batches_device run
+ *     every launch group on the device that owns its memory (a pipeline and a host thread per device; a group whose
+ *     arrays lie on different devices, or on a device outside the list, is KZG_BADARGS), and
+ *     kzg_verify_blob_kzg_proof_batches (host-fed) deals contiguous ranges of whole batches to the devices, each streamed
+ *     over its own PCIe link.
+ * The handle is also a complete single-device handle on devices[0]: the single-proof, prover-side and kzg_shard_* entry
+ * points (the one-process-per-GPU form) run there.  The plain constructors above read KZG_DEVICES ("all" or "0,1,2,...")
+ * from the environment, so an unchanged caller gets the same handle without a source change.
+ * Exchange of the partial sums: through pinned host memory by default (288 bytes per chunk); KZG_OPTIONS
+ * multi_exchange=rccl selects an in-process RCCL all-gather over xGMI (ncclCommInitAll + ncclAllGather) instead - an
+ * opt-in because this project's test boxes have one GPU, so that leg has only ever run in a world of one; with =rccl a
+ * handle on which RCCL is unusable (librccl missing, a device named twice) fails to construct. */
 KzgRet kzg_settings_load_trusted_setup_devices(KzgSettings **out, const char *txt, size_t len, const int *devices,
                                                size_t n_devices);
 KzgRet kzg_settings_from_tau_g2_devices(KzgSettings **out, const uint8_t tau_g2[96], const int *devices, size_t n_devices);
@@ -129,8 +142,19 @@ KzgRet kzg_verify_blob_kzg_proof_batch_device(bool *ok, const void *d_blobs, con
 KzgRet kzg_verify_blob_kzg_proof_batch_sharded(bool *ok, const void *const *d_blobs, const void *const *d_commitments,
                                                const void *const *d_proofs, const size_t *n_local, size_t n_shards,
                                                const KzgSettings *s);
+/* A STREAM of such batches: batch j's shard k = n_local[j * n_shards + k] blobs at d_blobs[j * n_shards + k] (etc.) on the
+ * handle's k-th device; `in_flight` batches (0 = the default, 4; at most 8) run at once on private lanes, each driven by
+ * a host thread of its own, so the serial transcript hash of one batch (:291-334: 42 MB = ~20 ms at 262 144 blobs) runs
+ * beside the device phases of the others.  ok_out[j] per batch; err_out[j] (optional) = 1 where the reference would return
+ * Err (then ok_out[j] = false); without err_out an invalid input in any batch fails the call. */
+KzgRet kzg_verify_blob_kzg_proof_batch_sharded_stream(bool *ok_out, uint8_t *err_out, const void *const *d_blobs,
+                                                      const void *const *d_commitments, const void *const *d_proofs,
+                                                      const size_t *n_local, size_t n_shards, size_t n_batches, size_t in_flight,
+                                                      const KzgSettings *s);
 /* Host wall-clock stages of the last sharded call on a multi-device handle, milliseconds: [0] whole call, [1] inputs onto
- * the devices + phase 1 (all shards), [2] transcript hash, [3] phase-2 launches, [4] exchange, [5] fold + pairing. */
+ * the devices + phase 1 (until the last piece's records are back), [2] what the transcript hash added after that (it runs
+ * beside [1]), [3] phase-2 launches, [4] exchange, [5] fold + pairing, [6] the hash's own busy time, [7] pieces.  After
+ * kzg_verify_blob_kzg_proof_batch_sharded_stream: [0] the whole stream, [1..6] per-batch averages, [7] batches. */
 KzgRet kzg_multi_last_timings(const KzgSettings *s, float out_ms[8]);
 
 /* ---- multi-GPU, one process per GPU (torch.distributed / any transport): the batch sharded by blob in contiguous index ranges ----
@@ -183,7 +207,7 @@ KzgRet kzg_shard_phase2_wait(uint8_t *partial_out, const KzgSettings *s);
 KzgRet kzg_shard_finish_launch(const uint8_t *partials, size_t world, size_t n_batches, const KzgSettings *s);
 KzgRet kzg_shard_finish_wait(bool *ok /* n_batches */, const KzgSettings *s);
 /* n_batches independent verify_blob_kzg_proof_batch calls (src/kzg_proof.rs:472-525) of n blobs each in one
- * launch group, device-resident inputs.  ok_out[b] is the result of batch b; err_out[b] (optional) = 1 where the
+ * launch group, device-resident inputs (on a multi-device handle: on whichever device of the list holds them).  ok_out[b] is the result of batch b; err_out[b] (optional) = 1 where the
  * reference would return Err (then ok_out[b] = false); without err_out any invalid input fails the whole call. */
 KzgRet kzg_verify_blob_kzg_proof_batches_device(bool *ok_out, uint8_t *err_out, const void *d_blobs,
                                                 const void *d_commitments, const void *d_proofs, size_t n,
@@ -191,9 +215,11 @@ KzgRet kzg_verify_blob_kzg_proof_batches_device(bool *ok_out, uint8_t *err_out, 
 
 /* MANY launch groups through one call, kept in flight inside the library (csrc/capi_pipeline.hpp): n_groups groups of
  * batches_per_group independent batches of n blobs each, group g at d_blobs[g] / d_commitments[g] / d_proofs[g] (device
- * memory, the group's batches contiguous; pointers may repeat); `in_flight` groups overlap on private per-group handles of
- * the same device (0 = the default, 3).  ok_out / err_out (optional): [n_groups][batches_per_group], as in the one-group form.
- * This is the entry point behind the benchmark's headline: 256 batches of 1 024 blobs per group, 3 groups in flight. */
+ * memory, the group's batches contiguous; pointers may repeat); `in_flight` groups overlap on private per-group lanes of
+ * the device (0 = the default, 3).  On a handle over several devices every group runs on the device that owns its memory,
+ * `in_flight` groups per device, all devices at once.  ok_out / err_out (optional): [n_groups][batches_per_group], as in the
+ * one-group form.  This is the entry point behind the benchmark's headline: 256 batches of 1 024 blobs per group, 3 groups
+ * in flight. */
 KzgRet kzg_verify_blob_kzg_proof_batch_groups_device(bool *ok_out, uint8_t *err_out, const void *const *d_blobs,
                                                      const void *const *d_commitments, const void *const *d_proofs, size_t n,
                                                      size_t batches_per_group, size_t n_groups, size_t in_flight,

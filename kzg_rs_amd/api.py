@@ -18,6 +18,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KZG_LIB_OVERRIDE") or os.path.join(HERE, "libkzg_rs_amd.so")
+# the A/B build (python -m kzg_rs_amd.build): the product plus the alternative kernel forms kept for measurement and for the
+# differential fuzz; a process selects it with KZG_LIB_OVERRIDE=LIB_AB_PATH and a form with KZG_OPTIONS (options_string)
+LIB_AB_PATH = os.path.join(HERE, "libkzg_rs_amd_ab.so")
 TRUSTED_SETUP_PATH = os.path.join(HERE, "data", "trusted_setup.txt")
 
 BYTES_PER_FIELD_ELEMENT = 32
@@ -44,6 +47,33 @@ def BadArgs(msg):
 
 def InvalidBytesLength(msg):
     return KzgError("InvalidBytesLength", msg)
+
+
+def options_string(**kw):
+    """The value of KZG_OPTIONS for the given switches (csrc/capi_host_util.hpp): options_string(single_stream=1,
+    challenge_kernel="lane") -> "single_stream=1;challenge_kernel=lane"."""
+    return ";".join("%s=%s" % (k, v) for k, v in kw.items())
+
+
+class options:
+    """with api.options(multi_min_blobs=2): ... - KZG_OPTIONS of THIS process for the duration of the block (added to what
+    is already set).  The library re-reads the string whenever it has changed; switches that are read when a handle is made
+    (single_stream, multi_*) apply to handles made inside the block, switches latched on first use only if this is it."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.prev = os.environ.get("KZG_OPTIONS")
+        os.environ["KZG_OPTIONS"] = ";".join(x for x in (self.prev, options_string(**self.kw)) if x)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is None:
+            os.environ.pop("KZG_OPTIONS", None)
+        else:
+            os.environ["KZG_OPTIONS"] = self.prev
+        return False
 
 
 _KIND = {KZG_BADARGS: "BadArgs", KZG_ERROR: "InternalError", KZG_MALLOC: "InternalError",
@@ -73,6 +103,7 @@ def lib():
         L.kzg_settings_from_tau_g2_devices.argtypes = [pp, u8, C.POINTER(C.c_int), sz]
         L.kzg_settings_devices.argtypes = [vp, C.POINTER(sz), C.POINTER(C.c_int), sz, C.POINTER(C.c_int)]
         L.kzg_verify_blob_kzg_proof_batch_sharded.argtypes = [bp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), sz, vp]
+        L.kzg_verify_blob_kzg_proof_batch_sharded_stream.argtypes = [bp, u8, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), sz, sz, sz, vp]
         L.kzg_multi_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
         L.kzg_settings_free.argtypes = [vp]
         L.kzg_settings_free.restype = None
@@ -368,6 +399,26 @@ def verify_blob_kzg_proof_batch_sharded(shards, kzg_settings):
     ok = C.c_bool(False)
     _chk(lib().kzg_verify_blob_kzg_proof_batch_sharded(C.byref(ok), b, c, p, nl, k, kzg_settings._h))
     return bool(ok.value)
+
+
+def verify_blob_kzg_proof_batch_sharded_stream(batches, kzg_settings, in_flight=0):
+    """A STREAM of sharded batches, `in_flight` of them at once inside the library (0: its default): batches = [shards, ...],
+    shards as in verify_blob_kzg_proof_batch_sharded.  Returns True / False per batch, or None where the reference would
+    return Err."""
+    nb = len(batches)
+    if nb == 0:
+        return []
+    k = len(batches[0])
+    if any(len(b) != k for b in batches):
+        raise BadArgs("every batch needs one shard per device of the handle")
+    vp = C.c_void_p
+    flat = [s for b in batches for s in b]
+    b, c, p = (vp * (nb * k))(*[s[0] for s in flat]), (vp * (nb * k))(*[s[1] for s in flat]), (vp * (nb * k))(*[s[2] for s in flat])
+    nl = (C.c_size_t * (nb * k))(*[s[3] for s in flat])
+    ok = (C.c_bool * nb)()
+    err = C.create_string_buffer(nb)
+    _chk(lib().kzg_verify_blob_kzg_proof_batch_sharded_stream(ok, err, b, c, p, nl, k, nb, in_flight, kzg_settings._h))
+    return [None if err.raw[j] else bool(ok[j]) for j in range(nb)]
 
 
 def verify_blob_kzg_proof_batches_device(d_blobs, d_commitments, d_proofs, n, n_batches, kzg_settings):

@@ -10,14 +10,70 @@ static KzgRet fail(KzgRet rc, const std::string& msg) {
     return rc;
 }
 extern "C" const char* kzg_last_error(void) { return g_err.c_str(); }
-#include "host_only.hpp"
 
-// ROCm gives a process 4 hardware queues by default and multiplexes its streams onto them; the pipeline of launch groups
-// (capi_pipeline.hpp) keeps ~4 handles x (2 plain + 2 CU-masked + 1 copy) streams busy.  Measured through bench.py
-// (GPU_MAX_HW_QUEUES = 2 / 4 / 8 / 16): 4.34 / 4.68 / 4.92 / 4.85 M blobs/s.  The runtime reads the variable when it
-// initialises (its first API call), so the library asks for 8 when it is loaded - unless the caller has chosen a value, and
-// without effect if the process has already used HIP.
-__attribute__((constructor)) static void kzg_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0); }
+// ---------------------------------------------------------------- options
+// ONE environment variable, KZG_OPTIONS = "key=value;key=value;..." (';' or blanks between entries), carries every tuning
+// and test switch of the library; a switch is named by its key in the comment beside the code that reads it, and
+// INTEGRATION.md lists them.  The string is parsed when it is first needed and again whenever its value has changed
+// (tests change it between handles); most switches are latched by their reader on first use.  Switches that select a kernel
+// variant compiled only into the A/B build (KZG_AB_VARIANTS=1: fp29=0, evaluate_kernel=32, proofs_chunks=16) are ignored by
+// the product build - ab_variants_built() tells which one is loaded.
+// The device list of an UNCHANGED caller is the one deployment knob with a variable of its own: KZG_DEVICES.
+//
+// The library does not touch the process environment (rounds 1-3 set GPU_MAX_HW_QUEUES from a load-time constructor): the
+// pipeline of launch groups wants 8 hardware queues (measured through bench.py with GPU_MAX_HW_QUEUES = 2 / 4 / 8 / 16:
+// 4.34 / 4.68 / 4.92 / 4.85 M blobs/s; ROCm's default is 4), which the HOST sets in its environment before the HIP runtime
+// initialises; hw_queues_note() is what a constructor leaves in kzg_last_error() when it sees fewer.
+#ifndef KZG_AB_VARIANTS
+#define KZG_AB_VARIANTS 0
+#endif
+#include <map>
+static const char* opt_str(const char* key) {  // nullptr when unset; the pointer stays valid until the process ends
+    static std::mutex mu;
+    static std::string parsed_from;
+    static std::map<std::string, std::string> kv;
+    static std::vector<std::string*> keep;  // values handed out earlier stay alive across a re-parse
+    std::lock_guard<std::mutex> lk(mu);
+    const char* e = getenv("KZG_OPTIONS");
+    const std::string cur = e ? e : "";
+    if (cur != parsed_from) {
+        parsed_from = cur;
+        kv.clear();
+        size_t i = 0;
+        while (i < cur.size()) {
+            size_t j = cur.find_first_of("; \t\n", i);
+            if (j == std::string::npos) j = cur.size();
+            const std::string item = cur.substr(i, j - i);
+            const size_t eq = item.find('=');
+            if (!item.empty()) kv[eq == std::string::npos ? item : item.substr(0, eq)] = eq == std::string::npos ? "1" : item.substr(eq + 1);
+            i = j + 1;
+        }
+    }
+    auto it = kv.find(key);
+    if (it == kv.end()) return nullptr;
+    keep.push_back(new std::string(it->second));
+    return keep.back()->c_str();
+}
+static bool opt_flag(const char* key, bool dflt) {
+    const char* v = opt_str(key);
+    return v ? !(v[0] == '0' || v[0] == 'n' || v[0] == 'f') : dflt;
+}
+static long opt_int(const char* key, long dflt) {
+    const char* v = opt_str(key);
+    return v && *v ? atol(v) : dflt;
+}
+static bool opt_is(const char* key, const char* value) {
+    const char* v = opt_str(key);
+    return v && strcmp(v, value) == 0;
+}
+#define KZG_HOST_THREADS_OPTION opt_int("host_threads", 16)
+#include "host_only.hpp"
+static const char* hw_queues_note() {
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    if (q && atoi(q) >= 8) return nullptr;
+    return "note: GPU_MAX_HW_QUEUES is unset or below 8 - set it to 8 in the environment before the HIP runtime starts; with "
+           "ROCm's default of 4 hardware queues the launch-group pipeline runs ~5 % below its rate";
+}
 
 #define HIPCHK(expr)                                                                                       \
     do {                                                                                                   \
@@ -52,22 +108,20 @@ struct DevTmp {
     T* as() const { return static_cast<T*>(p); }
 };
 
-// Point arithmetic of the decode and MSM kernels: the radix-2^29 field (fp29.hpp) unless KZG_FP29=0 selects the 12x32
-// field (A/B measurement, cross-check).  Decides the table format (G1Jac29Mem / G1Jac) for the whole process.
+// Point arithmetic of the decode and MSM kernels: the radix-2^29 field (fp29.hpp) unless the A/B build's option fp29=0 selects the 12x32
+// field (measurement, cross-check).  Decides the table format (G1Jac29Mem / G1Jac) for the whole process.
 static bool fp29_enabled() {
-    static const bool v = [] {
-        const char* e = getenv("KZG_FP29");
-        return !(e && e[0] == '0');
-    }();
+#if KZG_AB_VARIANTS
+    static const bool v = opt_flag("fp29", true);
     return v;
+#else
+    return true;
+#endif
 }
 // Throughput layout of the verification MSM (MSM_CHUNKS tables) with AFFINE entries and mixed additions (msm.hpp
-// k_mult_to_affine29); KZG_MSM_AFFINE=0 keeps Jacobian entries (A/B measurement).  Radix-2^29 field only.
+// k_mult_to_affine29); option msm_affine=0 keeps Jacobian entries (A/B measurement).  Radix-2^29 field only.
 static bool msm_affine_enabled() {
-    static const bool v = [] {
-        const char* e = getenv("KZG_MSM_AFFINE");
-        return fp29_enabled() && !(e && e[0] == '0');
-    }();
+    static const bool v = fp29_enabled() && opt_flag("msm_affine", true);
     return v;
 }
 constexpr size_t MULT_ENTRY_BYTES = sizeof(G1Jac29Mem) > sizeof(G1Jac) ? sizeof(G1Jac29Mem) : sizeof(G1Jac);

@@ -177,8 +177,11 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     d.chunks_per_block = 1;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     if ((rc = msm_save_reserve(s, 8, MSM_CHUNKS, S)) != KZG_OK) return rc;
-    if (fp29_enabled()) msm_window_launch<Curve29, false>(d, 8, MSM_CHUNKS, S, w.d_msm_save, w.cap_msm_save, s->s1);
-    else msm_window_launch<Curve32, false>(d, 8, MSM_CHUNKS, S, w.d_msm_save, w.cap_msm_save, s->s1);
+#if KZG_AB_VARIANTS
+    if (!fp29_enabled()) msm_window_launch<Curve32, false>(d, 8, MSM_CHUNKS, S, w.d_msm_save, w.cap_msm_save, s->s1);
+    else
+#endif
+        msm_window_launch<Curve29, false>(d, 8, MSM_CHUNKS, S, w.d_msm_save, w.cap_msm_save, s->s1);
     if (S > 1) hipLaunchKernelGGL(k_msm_fold_slices, dim3(MSM_CHUNKS * 8), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, 8);
     hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, w.d_window, w.d_ab, MSM_CHUNKS, 8);
     HIPCHK(hipEventRecord(s->ev[3], s->s1));

@@ -63,8 +63,11 @@ static KzgRet setup_msm(const KzgSettings* s, ProverBufs& b, size_t m) {
     const unsigned slots = MSM_CHUNKS / d.chunks_per_block;
     KzgRet rc_save = msm_save_reserve(s, 8, slots, (unsigned)m);
     if (rc_save != KZG_OK) return rc_save;
-    if (fp29_enabled()) msm_window_launch<Curve29, false>(d, 8, slots, (unsigned)m, s->ws.d_msm_save, s->ws.cap_msm_save, s->s1);
-    else msm_window_launch<Curve32, false>(d, 8, slots, (unsigned)m, s->ws.d_msm_save, s->ws.cap_msm_save, s->s1);
+#if KZG_AB_VARIANTS
+    if (!fp29_enabled()) msm_window_launch<Curve32, false>(d, 8, slots, (unsigned)m, s->ws.d_msm_save, s->ws.cap_msm_save, s->s1);
+    else
+#endif
+        msm_window_launch<Curve29, false>(d, 8, slots, (unsigned)m, s->ws.d_msm_save, s->ws.cap_msm_save, s->s1);
     hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)m), dim3(64), 0, s->s1, b.d_win, b.d_res, (int)slots, 8);
     hipLaunchKernelGGL(k_jac_compress_n, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s->s1, b.d_res, b.d_out, (int)m);
     HIPCHK(hipGetLastError());

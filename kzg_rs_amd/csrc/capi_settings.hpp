@@ -29,6 +29,7 @@ struct Workspace {
     uint32_t *d_status = nullptr, *d_pflag = nullptr, *d_term_point = nullptr, *d_term_scalar = nullptr, *d_sorted = nullptr;
     G1Aff* d_points = nullptr;
     G1Jac *d_window = nullptr, *d_window_sl = nullptr, *d_ab = nullptr, *d_parts = nullptr;
+    G1Jac* d_send = nullptr;  // a shard's contribution to the RCCL all-gather of partial sums: up to MAX_WORLD pieces x (A, B) (capi_multi.hpp)
     uint32_t* d_msm_save = nullptr;  // the window kernel's bucket sums between its row and column trees (msm.hpp MsmDesc::save)
     size_t cap_msm_save = 0;         // bytes
     void* d_mult = nullptr;  // MSM tables: G1Jac29Mem / G1Aff29Mem / G1Jac entries (fp29_enabled(), msm_affine_enabled())
@@ -73,7 +74,7 @@ struct KzgSettings {
     // or - for a small launch (a single batch) - at a pair confined to disjoint halves of the CUs: the 16 two-wave
     // workgroups of the challenge chain and the 32 decode waves otherwise land on the same first CUs of every XCD and,
     // run to run, share SIMDs (the chain then takes 4.9 ms instead of 3.5 ms).  Measured: one 1 024-blob batch 9.1 ms on
-    // the split pair, 10.1-11.5 ms on the plain pair; KZG_CU_MASK=0 disables the split pair.
+    // the split pair, 10.1-11.5 ms on the plain pair; option cu_mask=0 disables the split pair.
     mutable hipStream_t s1 = nullptr, s2 = nullptr, s_sha = nullptr;  // main | point decode | challenge chain (select_streams)
     hipStream_t s_plain[2] = {nullptr, nullptr};
     mutable hipStream_t s_half[2] = {nullptr, nullptr};
@@ -97,8 +98,10 @@ struct KzgSettings {
     struct MultiState* multi = nullptr;
     // further private handles on THIS device (capi_pipeline.hpp): one per launch group kept in flight beyond the first
     mutable std::vector<KzgSettings*> lanes;
-    uint8_t tau_g2_bytes[96] = {};  // g2_points[1] as given: what a lane is built from
-    mutable float multi_ms[8] = {};  // host wall-clock of the last sharded call: [0] whole call [1] copy + phase 1 [2] r hash [3] phase 2 [4] exchange [5] fold + pairing
+    bool borrowed = false;          // a lane: the tables and programs above belong to the handle it was made from (settings_lane)
+    uint8_t tau_g2_bytes[96] = {};  // g2_points[1] as given
+    mutable float multi_ms[8] = {};  // host wall-clock stages of the last sharded call (kzg_multi_last_timings)
+    mutable uint8_t multi_last_r[32] = {};  // the batch challenge of the last sharded call, little-endian (test hook kzg_debug_multi_last_r)
 };
 static void multi_free(KzgSettings* s);
 
@@ -158,12 +161,9 @@ static KzgRet run_program2(const DevProgram2& dp, const Fp* d_in, const uint32_t
          : dp.p.lanes == 192 ? launch_program2<192>(dp, d_in, d_set29, d_out, instances, st)
                              : launch_program2<256>(dp, d_in, d_set29, d_out, instances, st);
 }
-// which form runs a launch of `instances` checks: KZG_PAIRING=1 | 2 forces the one-wave / the latency program (A/B, cross-check)
+// which form runs a launch of `instances` checks: option pairing=1 | 2 forces the one-wave / the latency program (A/B, cross-check)
 static bool pairing_latency_form(size_t instances) {
-    static const int forced = [] {
-        const char* e = getenv("KZG_PAIRING");
-        return e ? atoi(e) : 0;
-    }();
+    static const int forced = (int)opt_int("pairing", 0);
     return forced == 2 || (forced != 1 && instances <= LATENCY_PAIRING_MAX);
 }
 static KzgRet run_verify(const KzgSettings* s, const Fp* d_in, Fp* d_out, int instances, hipStream_t st);
@@ -206,20 +206,49 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
     *out = s;
     return KZG_OK;
 }
-static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
-    memcpy(s->tau_g2_bytes, tau_g2, 96);
+// what every handle owns, a lane included: its streams and events (the workspace grows on first use)
+static KzgRet settings_streams(KzgSettings* s, bool single_stream) {
     HIPCHK(hipGetDevice(&s->device));  // the calling thread's current device (multi_build sets it per shard)
     HIPCHK(hipStreamCreateWithFlags(&s->s_plain[0], hipStreamNonBlocking));
     s->s1 = s->s_sha = s->s_plain[0];
     HIPCHK(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->device));
-    // KZG_SINGLE_STREAM=1 (profiling aid): run the point-decode chain on the same stream as the challenge chain, so
+    // option single_stream=1 (profiling aid): run the point-decode chain on the same stream as the challenge chain, so
     // per-dispatch PMC counters are not polluted by a concurrent kernel
-    if (getenv("KZG_SINGLE_STREAM") && getenv("KZG_SINGLE_STREAM")[0] == '1') s->s2 = s->s1;
+    if (single_stream) s->s2 = s->s1;
     else {
         HIPCHK(hipStreamCreateWithFlags(&s->s_plain[1], hipStreamNonBlocking));
         s->s2 = s->s_plain[1];
     }
     for (auto& e : s->ev) HIPCHK(hipEventCreate(&e));
+    return KZG_OK;
+}
+// A LANE of a handle (capi_pipeline.hpp, capi_multi.hpp): a private handle on the same device - its own streams, events,
+// workspace and timings - that READS the parent's tables and pairing programs (they are immutable after construction): making
+// one costs two streams and a dozen events instead of the table kernels, three program uploads and a PREP pairing run.  The
+// caller has set the parent's device.  Freed with the parent (kzg_settings_free), never handed out.
+static KzgRet settings_lane(KzgSettings** out, const KzgSettings* parent) {
+    KzgSettings* l = new KzgSettings();
+    l->borrowed = true;
+    l->d_M = parent->d_M; l->d_DM = parent->d_DM; l->d_M29 = parent->d_M29; l->d_DM29 = parent->d_DM29;
+    l->d_eval_a = parent->d_eval_a; l->d_eval_b = parent->d_eval_b; l->d_eval_c = parent->d_eval_c;
+    l->d_tau4 = parent->d_tau4; l->d_prep = parent->d_prep; l->d_prep29 = parent->d_prep29;
+    l->d_gen_mult = parent->d_gen_mult; l->d_gen_mult_aff = parent->d_gen_mult_aff;
+    l->prep = parent->prep; l->verify = parent->verify; l->verify2 = parent->verify2;
+    memcpy(l->tau_g2_bytes, parent->tau_g2_bytes, 96);
+    KzgRet rc = settings_streams(l, /*single_stream=*/!parent->s_plain[1]);
+    if (rc != KZG_OK) {
+        const std::string msg = g_err;
+        kzg_settings_free(l);
+        g_err = msg;
+        return rc;
+    }
+    *out = l;
+    return KZG_OK;
+}
+static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
+    memcpy(s->tau_g2_bytes, tau_g2, 96);
+    KzgRet rc_streams = settings_streams(s, opt_flag("single_stream", false));
+    if (rc_streams != KZG_OK) return rc_streams;
     HIPCHK(hipMalloc(&s->d_M, sizeof(Fr) * FE_PER_BLOB));
     HIPCHK(hipMalloc(&s->d_DM, sizeof(Fr) * FE_PER_BLOB));
     HIPCHK(hipMalloc(&s->d_M29, sizeof(Fr29Mem) * FE_PER_BLOB));
@@ -309,12 +338,14 @@ static KzgRet settings_load_points(KzgSettings* s, const std::vector<uint8_t>& g
     HIPCHK(hipMalloc(&s->d_g1_mult, MULT_ENTRY_BYTES * MSM_CHUNKS * (size_t)N));
     HIPCHK(hipMemcpyAsync(d_bytes, g1b.data(), g1b.size(), hipMemcpyHostToDevice, s->s1));
     hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, s->d_g1, s->d_g1_flag, N, 0);
-    if (fp29_enabled())
-        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3((unsigned)((N + 63) / 64)), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s1, d_bytes, d_bytes, N, d_tmp,
-                           d_flag2, s->d_g1_mult, (G1Jac29Mem*)nullptr, N, N);
-    else
+#if KZG_AB_VARIANTS
+    if (!fp29_enabled())
         hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, d_bytes, d_bytes, N, d_tmp,
                            d_flag2, (G1Jac*)s->d_g1_mult, N, N);
+    else
+#endif
+        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3((unsigned)((N + 63) / 64)), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s1, d_bytes, d_bytes, N, d_tmp,
+                           d_flag2, s->d_g1_mult, (G1Jac29Mem*)nullptr, N, N);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> f1((size_t)N), f2((size_t)N);
     HIPCHK(hipMemcpyAsync(f1.data(), s->d_g1_flag, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
@@ -421,35 +452,43 @@ static KzgRet load_trusted_setup_on(KzgSettings** out, const char* txt, size_t l
     return KZG_OK;
 }
 
+// a constructor that succeeded under fewer than 8 hardware queues says so where kzg_last_error() finds it (the return stays KZG_OK)
+static KzgRet constructed(KzgRet rc) {
+    if (rc == KZG_OK) {
+        const char* note = hw_queues_note();
+        g_err = note ? note : "";
+    }
+    return rc;
+}
 extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char* txt, size_t len) {
     if (!out || !txt) return fail(KZG_BADARGS, "null argument");
     std::vector<int> devs;
     KzgRet rc = device_list(devs, nullptr, 0, /*from_env=*/true);
-    return rc != KZG_OK ? rc : load_trusted_setup_on(out, txt, len, devs);
+    return rc != KZG_OK ? rc : constructed(load_trusted_setup_on(out, txt, len, devs));
 }
 extern "C" KzgRet kzg_settings_load_trusted_setup_devices(KzgSettings** out, const char* txt, size_t len, const int* devices, size_t n_devices) {
     if (!out || !txt) return fail(KZG_BADARGS, "null argument");
     std::vector<int> devs;
     KzgRet rc = device_list(devs, devices, n_devices, false);
-    return rc != KZG_OK ? rc : load_trusted_setup_on(out, txt, len, devs);
+    return rc != KZG_OK ? rc : constructed(load_trusted_setup_on(out, txt, len, devs));
 }
 
 extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_g2[96]) {
     if (!out || !tau_g2) return fail(KZG_BADARGS, "null argument");
     std::vector<int> devs;
     KzgRet rc = device_list(devs, nullptr, 0, /*from_env=*/true);
-    return rc != KZG_OK ? rc : settings_on_devices(out, tau_g2, devs);
+    return rc != KZG_OK ? rc : constructed(settings_on_devices(out, tau_g2, devs));
 }
 extern "C" KzgRet kzg_settings_from_tau_g2_devices(KzgSettings** out, const uint8_t tau_g2[96], const int* devices, size_t n_devices) {
     if (!out || !tau_g2) return fail(KZG_BADARGS, "null argument");
     std::vector<int> devs;
     KzgRet rc = device_list(devs, devices, n_devices, false);
-    return rc != KZG_OK ? rc : settings_on_devices(out, tau_g2, devs);
+    return rc != KZG_OK ? rc : constructed(settings_on_devices(out, tau_g2, devs));
 }
 
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
-                    w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_mult, w.d_jtmp, w.d_ktime, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
+                    w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_send, w.d_mult, w.d_jtmp, w.d_ktime, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
                     w.d_records, w.d_hstage[0], w.d_hstage[1], w.d_msm_save, w.d_sha_mid};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -466,9 +505,12 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     s->lanes.clear();
     (void)hipSetDevice(s->device);
     ws_free(s->ws);
-    void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_eval_scratch, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob, s->verify2.blob, s->d_prep29};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+    if (s->d_eval_scratch) (void)hipFree(s->d_eval_scratch);
+    if (!s->borrowed) {  // (a lane reads its parent's tables)
+        void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob, s->verify2.blob, s->d_prep29};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
     for (auto& e : s->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : s->ev_copy)

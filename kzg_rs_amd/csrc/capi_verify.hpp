@@ -1,17 +1,16 @@
 // capi_verify.hpp - the verification path: kernel selection, workspace, MSM tail, the three phases as launch + wait, and the entry points.
 // Part of the single translation unit kzg_capi.hip; not a stand-alone header.
 
-// The evaluation kernel over T blobs on stream s1 (radix-2^29 form; KZG_EVALUATE_KERNEL=32 selects the 8x32 form,
-// kept for A/B measurement and as a cross-check).
+// The evaluation kernel over T blobs on stream s1 (radix-2^29 form; option evaluate_kernel=32 of the A/B build selects the 8x32
+// form, kept for measurement and as a cross-check).
 static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr* d_z, Fr* d_y, uint32_t* d_status, size_t T) {
-    static const bool use32 = [] {
-        const char* e = getenv("KZG_EVALUATE_KERNEL");
-        return e && strcmp(e, "32") == 0;
-    }();
+#if KZG_AB_VARIANTS
+    static const bool use32 = opt_is("evaluate_kernel", "32");
     if (use32) {
         hipLaunchKernelGGL(k_blob_evaluate32, dim3((unsigned)T), dim3(64), 0, s->s1, (const uint8_t*)d_blobs, d_z, s->d_M, s->d_DM, d_y, d_status);
         return KZG_OK;
     }
+#endif
     if (T > s->eval_scratch_cap) {  // 576 bytes per blob between the three kernels (fr_kernels.hpp); callers hold the handle's lock
         if (s->d_eval_scratch) HIPCHK(hipFree(s->d_eval_scratch));  // waits for the kernels that may still read it
         s->d_eval_scratch = nullptr;
@@ -40,14 +39,11 @@ static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const F
 // The challenge kernel over T blobs on stream s1: a producer / consumer form (the serial chain split over wavefronts, lowest
 // latency) while every workgroup can have a CU to itself, the one-lane-per-blob form (highest throughput) beyond that.
 // Small launches take the form with two lanes per blob on the consumer side (k_blob_challenge_split2), mid-size ones the
-// one-lane consumer (k_blob_challenge_split); KZG_CHALLENGE_KERNEL = lane | split | split2 forces a form (A/B
+// one-lane consumer (k_blob_challenge_split); option challenge_kernel = lane | split | split2 forces a form (A/B
 // measurement, cross-check in the tests).
 static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const void* d_commitments, Fr* d_z, size_t T, hipStream_t st = nullptr) {
     if (!st) st = s->s1;
-    static const int forced = [] {
-        const char* e = getenv("KZG_CHALLENGE_KERNEL");
-        return !e ? 0 : strcmp(e, "lane") == 0 ? 1 : strcmp(e, "split") == 0 ? 2 : strcmp(e, "split2") == 0 ? 3 : 0;
-    }();
+    static const int forced = opt_is("challenge_kernel", "lane") ? 1 : opt_is("challenge_kernel", "split") ? 2 : opt_is("challenge_kernel", "split2") ? 3 : 0;
     const uint8_t *bl = (const uint8_t*)d_blobs, *cm = (const uint8_t*)d_commitments;
     // measured on MI355X (tools/prof/challenge_forms_rate.py, ms for 1 024 / 16 384 / 32 768 / 49 152 blobs): lane 5.2 / 6.5 / 6.9 / 12.0,
     // split 3.5 / 5.0 / 5.4 / 8.8, split2 2.9 / 4.4 / 7.2 / 13.3 - three waves per 64 blobs stop paying once the CUs hold more
@@ -111,6 +107,7 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, int stage) {
         HIPCHK(hipMalloc(&w.d_ktime, 16));
         if (msm_affine_enabled()) HIPCHK(hipMalloc(&w.d_jtmp, sizeof(G1Jac29Mem) * np));
         HIPCHK(hipMalloc(&w.d_parts, sizeof(G1Jac) * 2 * capB * MAX_WORLD));
+        HIPCHK(hipMalloc(&w.d_send, sizeof(G1Jac) * 2 * MAX_WORLD));
         HIPCHK(hipMalloc(&w.d_slp_in, sizeof(Fp) * 6 * capB));
         HIPCHK(hipMalloc(&w.d_slp_out, sizeof(Fp) * 6 * capB));
         HIPCHK(hipMalloc(&w.d_bytes, 96 * np));
@@ -145,11 +142,10 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, int stage) {
 }
 
 // (window, chunk) blocks of the MSM: separate while the launch has few batches (latency), merged per window once the
-// batch dimension alone fills the chip (msm.hpp MsmDesc::chunks_per_block); KZG_MSM_CPB = 1 | 2 | 4 overrides.
+// batch dimension alone fills the chip (msm.hpp MsmDesc::chunks_per_block); option msm_cpb = 1 | 2 | 4 overrides.
 static int msm_chunks_per_block(size_t B) {
     static const int forced = [] {
-        const char* e = getenv("KZG_MSM_CPB");
-        int v = e ? atoi(e) : 0;
+        const int v = (int)opt_int("msm_cpb", 0);
         return (v == 1 || v == 2 || v == 4) ? v : 0;
     }();
     if (forced) return forced;
@@ -194,11 +190,8 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     d.stride = 2 * T + 1;
     d.chunks = w.chunks;
     d.chunks_per_block = w.chunks == MSM_CHUNKS ? msm_chunks_per_block(B) : 1;
-    static const int msm_flags = [] {  // KZG_MSM_ROTATE=0 / KZG_MSM_XCD=0: A/B measurement of the two placements (msm.hpp MSM_FLAG_*)
-        const char *r = getenv("KZG_MSM_ROTATE"), *x = getenv("KZG_MSM_XCD");
-        // measured (profiles/r3_ab_msm.txt): XCD placement +2 % throughput; the rotation LOSES 6 % of the kernel - off unless asked for
-        return ((r && r[0] == '1') ? MSM_FLAG_ROTATE : 0) | ((x && x[0] == '0') ? 0 : MSM_FLAG_XCD);
-    }();
+    // option msm_xcd=0: A/B measurement of the XCD placement (msm.hpp MSM_FLAG_XCD; profiles/r3_ab_msm.txt: +2 % throughput)
+    static const int msm_flags = opt_flag("msm_xcd", true) ? MSM_FLAG_XCD : 0;
     d.flags = msm_flags;
     const unsigned slots = d.chunks / d.chunks_per_block, W = MSM_WINDOWS / d.chunks;
     // one large batch: slice the terms of an output over several workgroups until the launch has ~1000 of them
@@ -207,15 +200,18 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     while (S < MSM_MAX_SLICES && W * slots * 2 * B * S < 768 && n / (2 * S) >= 1024 && 2 * S * B <= 128) S *= 2;
     // a small launch (the latency layout: one batch, 64 blocks) is bound by its fullest bucket - ~18 of 2 049 terms, 15 us
     // a Jacobian addition at lone-wave speed: four slices quarter that chain for one more short fold
-    static const unsigned latency_slices = [] {  // KZG_MSM_LATENCY_SLICES = 1 | 2 | 4 | 8 (A/B measurement)
-        const char* e = getenv("KZG_MSM_LATENCY_SLICES");
-        const unsigned v = e ? (unsigned)atoi(e) : 0;
+    static const unsigned latency_slices = [] {  // option msm_latency_slices = 1 | 2 | 4 | 8 (A/B measurement)
+        const unsigned v = (unsigned)opt_int("msm_latency_slices", 0);
         return v == 1 || v == 2 || v == 4 || v == 8 ? v : 4u;
     }();
     if (d.chunks != MSM_CHUNKS && S == 1 && n >= 256 && B <= 4) S = latency_slices;
     // ... and until a block's sorted term list fits in LDS (msm.hpp LDSSORT): the global list costs a line of HBM write
     // traffic per 4-byte entry once the launch outgrows the L2
+#if KZG_AB_VARIANTS
     const size_t lds_cap = fp29_enabled() ? msm_lds_sort_capacity<Curve29>() : msm_lds_sort_capacity<Curve32>();
+#else
+    const size_t lds_cap = msm_lds_sort_capacity<Curve29>();
+#endif
     auto slice_terms = [&](unsigned S_) { return ((size_t)mt + S_ - 1) / S_ * (size_t)d.chunks_per_block; };
     while (S < MSM_MAX_SLICES && slice_terms(S) > lds_cap && n / (2 * S) >= 1024 && 2 * S * B <= 128) S *= 2;  // (d_window_sl holds S B <= 128 slice sets)
     const bool lds_sort = slice_terms(S) + 1 <= lds_cap;  // (+1: slice boundaries round either way)
@@ -231,20 +227,23 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
         if (lds_sort) msm_window_launch<Curve29Aff, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
         else msm_window_launch<Curve29Aff, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
     } else if (fp29_enabled()) {
-        // the latency layout's few workgroups run their reduction trees with four lanes per addition (KZG_MSM_TREE_QUADS=0: A/B)
-        static const bool tree_quads = !(getenv("KZG_MSM_TREE_QUADS") && getenv("KZG_MSM_TREE_QUADS")[0] == '0');
+        // the latency layout's few workgroups run their reduction trees with four lanes per addition (option msm_tree_quads=0: A/B)
+        static const bool tree_quads = opt_flag("msm_tree_quads", true);
         if (tree_quads && d.chunks != MSM_CHUNKS && B <= 4) {
             if (lds_sort) msm_window_launch<Curve29Quads, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
             else msm_window_launch<Curve29Quads, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
         } else if (lds_sort) msm_window_launch<Curve29, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
         else msm_window_launch<Curve29, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
-    } else {
+    }
+#if KZG_AB_VARIANTS
+    else {
         if (lds_sort) msm_window_launch<Curve32, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
         else msm_window_launch<Curve32, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
     }
+#endif
     // the latency layout (one window per chunk) of a few batches: every output is the plain sum of its slots x slices window
-    // sums - one workgroup per output, four lanes per addition (KZG_MSM_SUM_QUADS=0: the fold + combine kernels, A/B)
-    static const bool sum_quads = !(getenv("KZG_MSM_SUM_QUADS") && getenv("KZG_MSM_SUM_QUADS")[0] == '0');
+    // sums - one workgroup per output, four lanes per addition (option msm_sum_quads=0: the fold + combine kernels, A/B)
+    static const bool sum_quads = opt_flag("msm_sum_quads", true);
     if (sum_quads && W == 1 && fp29_enabled() && slots * S >= 2 && slots * S <= (unsigned)SUMQ_MAX_POINTS && 2 * B < 64) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_sum_quads), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SUMQ_LDS_BYTES));
         hipLaunchKernelGGL(k_msm_sum_quads, dim3((unsigned)(2 * B)), dim3(256), SUMQ_LDS_BYTES, s->s1, d.window_sums, w.d_ab, (int)(slots * S));
@@ -269,8 +268,12 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
     Workspace& w = s->ws;
     const int np = (int)(2 * T + 1);
     unsigned blocks = (unsigned)((2 * T + 63) / 64);
-    static const bool no_latency_layout = getenv("KZG_MSM_LATENCY_LAYOUT") && getenv("KZG_MSM_LATENCY_LAYOUT")[0] == '0';
-    static const bool proofs_16 = getenv("KZG_PROOFS_CHUNKS") && atoi(getenv("KZG_PROOFS_CHUNKS")) == 16;  // (A/B measurement)
+    static const bool no_latency_layout = !opt_flag("msm_latency_layout", true);
+#if KZG_AB_VARIANTS
+    static const bool proofs_16 = opt_int("proofs_chunks", 0) == 16;  // (A/B measurement: round 1's sixteen 16-bit chunks for the proof-tuple entries)
+#else
+    constexpr bool proofs_16 = false;
+#endif
     w.chunks = (T <= LATENCY_MAX_BLOBS && !no_latency_layout) ? ((behind_sha || !proofs_16) ? MSM_CHUNKS_LATENCY : MSM_CHUNKS_PROOFS) : MSM_CHUNKS;
     const uint8_t *c = (const uint8_t*)d_commitments, *p = (const uint8_t*)d_proofs;
     const int n2 = (int)(2 * T);
@@ -291,27 +294,34 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
         // (the generator's rows first: behind the decode kernel they would sit on the critical path of a proof-tuple call)
         hipLaunchKernelGGL(k_set_generator_multiples<G1Jac29Mem>, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, mult,
                            (const G1Jac29Mem*)s->d_gen_mult + gen_off, n2, np, w.chunks);
-        // the latency layouts: eight lanes per point, one wavefront of 8 points per CU (KZG_DECODE_QUADS=0: one lane, A/B)
-        static const bool dec_quads = !(getenv("KZG_DECODE_QUADS") && getenv("KZG_DECODE_QUADS")[0] == '0');
+        // the latency layouts: eight lanes per point, one wavefront of 8 points per CU (option decode_quads=0: one lane, A/B)
+        static const bool dec_quads = opt_flag("decode_quads", true);
         // (while every workgroup can have a CU to itself, and not beside the challenge chain: there the decode hides behind the
         // chain anyway and has only half the CUs)
         if (dec_quads && w.chunks != MSM_CHUNKS && !behind_sha && (2 * T + DECQ_POINTS_PER_BLOCK - 1) / DECQ_POINTS_PER_BLOCK <= (size_t)s->n_cus) {
             blocks = (unsigned)((2 * T + DECQ_POINTS_PER_BLOCK - 1) / DECQ_POINTS_PER_BLOCK);
-            if (w.chunks == MSM_CHUNKS_LATENCY) {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_decode_multiples29_quads<MSM_CHUNKS_LATENCY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECQ_LDS_BYTES));
-                hipLaunchKernelGGL(k_g1_decode_multiples29_quads<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), DECQ_LDS_BYTES, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
-            } else {
+#if KZG_AB_VARIANTS
+            if (w.chunks != MSM_CHUNKS_LATENCY) {
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_decode_multiples29_quads<MSM_CHUNKS_PROOFS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECQ_LDS_BYTES));
                 hipLaunchKernelGGL(k_g1_decode_multiples29_quads<MSM_CHUNKS_PROOFS>, dim3(blocks), dim3(64), DECQ_LDS_BYTES, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
+            } else
+#endif
+            {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_decode_multiples29_quads<MSM_CHUNKS_LATENCY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECQ_LDS_BYTES));
+                hipLaunchKernelGGL(k_g1_decode_multiples29_quads<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), DECQ_LDS_BYTES, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
             }
         } else if (w.chunks == MSM_CHUNKS_LATENCY)
             hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS_LATENCY, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
+#if KZG_AB_VARIANTS
         else if (w.chunks == MSM_CHUNKS_PROOFS)
             hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS_PROOFS, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
+#endif
         else
             hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3(blocks), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, n2, np);
         HIPCHK(hipEventRecord(s->ev[10], s->s2));
-    } else {
+    }
+#if KZG_AB_VARIANTS
+    else {
         G1Jac* mult = (G1Jac*)w.d_mult;
         if (w.chunks == MSM_CHUNKS_LATENCY)
             hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), 0, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
@@ -323,6 +333,7 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
         hipLaunchKernelGGL(k_set_generator_multiples<G1Jac>, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, mult,
                            (const G1Jac*)s->d_gen_mult + gen_off, n2, np, w.chunks);
     }
+#endif
     HIPCHK(hipGetLastError());
     return KZG_OK;
 }
@@ -342,9 +353,8 @@ static void select_streams(const KzgSettings* s, size_t T) {
     const bool small = T <= LATENCY_MAX_BLOBS;
     if (small && !s->s_half_tried) {
         s->s_half_tried = true;
-        const char* e = getenv("KZG_CU_MASK");
         hipDeviceProp_t prop;
-        if (!(e && e[0] == '0') && hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount >= 64) {
+        if (opt_flag("cu_mask", true) && hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount >= 64) {
             const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
             std::vector<uint32_t> lo(words, 0), hi(words, 0);
             for (int i = 0; i < ncu; i++) ((i < ncu / 2) ? lo : hi)[i / 32] |= 1u << (i % 32);
@@ -375,15 +385,14 @@ struct HostBatch {
 // consumes a blob front to back, so the chain's segment j (k_blob_challenge_split2_t<true>) runs while slice j + 1 is on the
 // link and the call costs ~ copy + chain / S.  Measured on MI355X (profiles/r3_hostslicebench.txt): hipMemcpy2DAsync from
 // pageable memory returns at once and 8 slices of a 128 MiB batch land 0.31 ms apart, 2.44 ms in all against 2.38 ms for
-// one copy.  A slice costs a dispatch and an event wait (~20 us): small batches take fewer.  KZG_HOST_SLICES = 1 | 2 | 4 |
+// one copy.  A slice costs a dispatch and an event wait (~20 us): small batches take fewer.  option host_slices = 1 | 2 | 4 |
 // 8 | 16 forces S (1: one copy, the round-2 behaviour).
 static unsigned host_slices(size_t n) {
     static const unsigned forced = [] {
-        const char* e = getenv("KZG_HOST_SLICES");
-        const unsigned v = e ? (unsigned)atoi(e) : 0;
+        const unsigned v = (unsigned)opt_int("host_slices", 0);
         return v == 1 || v == 2 || v == 4 || v == 8 || v == 16 ? v : 0u;
     }();
-    static const bool lane_forced = getenv("KZG_CHALLENGE_KERNEL") && strcmp(getenv("KZG_CHALLENGE_KERNEL"), "split2") != 0;
+    static const bool lane_forced = opt_str("challenge_kernel") && !opt_is("challenge_kernel", "split2");
     if (n > SLICED_MAX_BLOBS || lane_forced) return 1;
     if (forced) return forced;
     return n >= 512 ? 8 : n >= 128 ? 4 : 1;
@@ -722,9 +731,20 @@ extern "C" KzgRet kzg_shard_finish(bool* ok, const uint8_t* partials, size_t wor
 
 // B independent batches of n blobs each in ONE launch group: blobs / commitments / proofs are contiguous device
 // arrays of B*n entries, batch b = entries [b n, (b+1) n); ok_out[b] and (optional) err_out[b] per batch.
+static KzgRet batches_device_locked(bool* ok_out, uint8_t* err_out, const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n,
+                                    size_t n_batches, const KzgSettings* s);
+static KzgRet multi_batches_device_locked(bool* ok_out, uint8_t* err_out, const void* d_blobs, const void* d_commitments, const void* d_proofs,
+                                          size_t n, size_t n_batches, const KzgSettings* s);
 extern "C" KzgRet kzg_verify_blob_kzg_proof_batches_device(bool* ok_out, uint8_t* err_out, const void* d_blobs, const void* d_commitments,
                                                            const void* d_proofs, size_t n, size_t n_batches, const KzgSettings* s) {
     KZG_ENTER(s && ok_out && d_blobs && d_commitments && d_proofs && n && n_batches);
+    // a handle over several devices: the launch group runs on the device that owns its memory (capi_multi.hpp)
+    if (s->multi) return multi_batches_device_locked(ok_out, err_out, d_blobs, d_commitments, d_proofs, n, n_batches, s);
+    return batches_device_locked(ok_out, err_out, d_blobs, d_commitments, d_proofs, n, n_batches, s);
+}
+// the calling thread has set s's device and owns s
+static KzgRet batches_device_locked(bool* ok_out, uint8_t* err_out, const void* d_blobs, const void* d_commitments, const void* d_proofs, size_t n,
+                                    size_t n_batches, const KzgSettings* s) {
     KzgRet rc = ws_reserve(s, n * n_batches, n_batches, STAGE_NONE);
     if (rc != KZG_OK) return rc;
     if ((rc = phase1_launch_locked(d_blobs, d_commitments, d_proofs, n, n_batches, s)) != KZG_OK) return rc;
@@ -793,7 +813,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
 // the GPU: the rate is the link's (~56 GB/s measured on MI355X = ~0.43 M blobs/s), not copy + compute.  A pageable
 // hipMemcpyAsync holds the calling thread until the data has left (measured: 2.4 ms per 128 MiB either way), so each chunk's
 // copy is issued in two halves around the host-side steps of the chunk in flight (flags, transcript hashes, launches).
-// KZG_HOST_CHUNK = batches per chunk (default: half the stream, at most 32).
+// option host_chunk = batches per chunk (default: half the stream, at most 32).
 static KzgRet multi_host_stream_locked(bool* ok_out, uint8_t* err_out, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs,
                                        size_t n, size_t n_batches, const KzgSettings* s);
 static KzgRet host_stream_locked(bool* ok_out, uint8_t* err_out, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n,
@@ -810,8 +830,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batches(bool* ok_out, uint8_t* err_o
 static KzgRet host_stream_locked(bool* ok_out, uint8_t* err_out, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n,
                                  size_t n_batches, const KzgSettings* s) {
     static const size_t chunk_forced = [] {
-        const char* e = getenv("KZG_HOST_CHUNK");
-        long v = e ? atol(e) : 0;
+        const long v = opt_int("host_chunk", 0);
         return (size_t)(v < 0 ? 0 : v > 4096 ? 4096 : v);
     }();
     // chunk: whole batches.  Large chunks on purpose: the driver pins and unpins the pageable source around every copy
@@ -891,13 +910,12 @@ static KzgRet host_stream_locked(bool* ok_out, uint8_t* err_out, const uint8_t* 
     }
     HIPCHK(hipStreamSynchronize(s->s_copy));
     // The staging sets are grow-only inside a call but not kept beyond it when they are large (2 x up to 16 GiB would starve
-    // later workspaces on this device): above KZG_HSTAGE_KEEP_MIB per set (default 4608 MiB - the default chunk of 32
+    // later workspaces on this device): above option hstage_keep_mib per set (default 4608 MiB - the default chunk of 32
     // batches of 1 024 blobs is 4.1 GiB) they are released here and allocated again by the next stream call, which costs
     // tens of ms per GiB (measured: a stream of 64 host batches fell from 0.37 M to 0.12 M blobs/s when every call
     // reallocated its 2 x 4.1 GiB); below it they stay with the handle until kzg_settings_free: at most 9 GiB retained.
     static const size_t keep_bytes = [] {
-        const char* e = getenv("KZG_HSTAGE_KEEP_MIB");
-        long v = e ? atol(e) : 4608;
+        const long v = opt_int("hstage_keep_mib", 4608);
         return (size_t)(v < 0 ? 0 : v) << 20;
     }();
     if (w.cap_hstage * ((size_t)BLOB_BYTES + 96) > keep_bytes) {

@@ -93,25 +93,55 @@ static bool have_ni() {
 static bool have_ni() { return false; }
 static void blocks_ni(uint32_t*, const uint8_t*, size_t) {}
 #endif
-static void digest(uint8_t out[32], const uint8_t* data, size_t len) {
+// The hash as a STREAM: update() takes the message in pieces of any length as they become available (the transcript of a
+// sharded batch is hashed while the shards still produce records, capi_multi.hpp), finish() pads and writes the digest.
+struct Stream {
     uint32_t st[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
-    size_t full = len / 64;
-    if (have_ni()) blocks_ni(st, data, full);
-    else
-        for (size_t i = 0; i < full; i++) block(st, data + 64 * i);
-    uint8_t tail[128] = {0};
-    size_t rem = len - 64 * full;
-    memcpy(tail, data + 64 * full, rem);
-    tail[rem] = 0x80;
-    size_t tl = rem + 9 <= 64 ? 64 : 128;
-    uint64_t bits = (uint64_t)len * 8;
-    for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
-    block(st, tail);
-    if (tl == 128) block(st, tail + 64);
-    for (int i = 0; i < 8; i++) {
-        out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16);
-        out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i];
+    uint8_t buf[64] = {0};  // the bytes of an incomplete block
+    size_t fill = 0;
+    uint64_t total = 0;
+    void blocks(const uint8_t* p, size_t nb) {
+        if (!nb) return;
+        if (have_ni()) blocks_ni(st, p, nb);
+        else
+            for (size_t i = 0; i < nb; i++) block(st, p + 64 * i);
     }
+    void update(const uint8_t* data, size_t len) {
+        total += len;
+        if (fill) {
+            const size_t take = std::min(len, (size_t)64 - fill);
+            memcpy(buf + fill, data, take);
+            fill += take;
+            data += take;
+            len -= take;
+            if (fill < 64) return;
+            blocks(buf, 1);
+            fill = 0;
+        }
+        const size_t full = len / 64;
+        blocks(data, full);
+        fill = len - 64 * full;
+        if (fill) memcpy(buf, data + 64 * full, fill);
+    }
+    void finish(uint8_t out[32]) {
+        uint8_t tail[128] = {0};
+        memcpy(tail, buf, fill);
+        tail[fill] = 0x80;
+        const size_t tl = fill + 9 <= 64 ? 64 : 128;
+        const uint64_t bits = total * 8;
+        for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+        block(st, tail);
+        if (tl == 128) block(st, tail + 64);
+        for (int i = 0; i < 8; i++) {
+            out[4 * i] = (uint8_t)(st[i] >> 24); out[4 * i + 1] = (uint8_t)(st[i] >> 16);
+            out[4 * i + 2] = (uint8_t)(st[i] >> 8); out[4 * i + 3] = (uint8_t)st[i];
+        }
+    }
+};
+static void digest(uint8_t out[32], const uint8_t* data, size_t len) {
+    Stream s;
+    s.update(data, len);
+    s.finish(out);
 }
 }  // namespace hostsha
 
@@ -200,38 +230,48 @@ static bool trusted_setup_text(const char* txt, size_t len, std::vector<uint8_t>
 // compute_r_powers' hash (src/kzg_proof.rs:291-348) for B batches: r_b = SHA-256(domain || degree || n_total || records of batch b) mod r,
 // written as 32 little-endian bytes (= Scalar::to_bytes(), the device limb layout) to r_out + 32 b.  Pure host code (SHA-NI):
 // one serial chain of 160 n_total + 32 bytes per batch - hopeless on a GPU lane, ~2 GB/s on a CPU core - and the batches are
-// independent, so they are spread over a few host threads (KZG_HOST_THREADS, default 16).  Record layouts:
+// independent, so they are spread over a few host threads (option host_threads, default 16).  Record layouts:
 //   world == 0 : [B][n_total]       every batch's records in global blob order
 //   world  > 0 : [world][B][n]      as an all-gather / all-to-all of equal shards leaves them (n_total = world n)
 // Returns false when a transcript buffer could not be allocated (nothing is thrown, in a worker thread or out of it).
+// One batch transcript as a stream: the 32-byte header of :298-311 at construction, then the 160-byte records in global blob
+// order, in pieces of any number of records, as they arrive; r() closes the hash: digest mod r as 32 little-endian bytes.
+struct BatchTranscript {
+    hostsha::Stream sha;
+    explicit BatchTranscript(size_t n_total) {
+        uint8_t h[32];
+        memcpy(h, "RCKZGBATCH___V1_", 16);
+        memset(h + 16, 0, 16);
+        h[22] = (uint8_t)(KZG_HOST_FE_PER_BLOB >> 8);
+        h[23] = (uint8_t)(KZG_HOST_FE_PER_BLOB & 0xff);
+        for (int k = 0; k < 8; k++) h[24 + k] = (uint8_t)((uint64_t)n_total >> (56 - 8 * k));
+        sha.update(h, 32);
+    }
+    void records(const uint8_t* rec, size_t count) { sha.update(rec, 160 * count); }
+    void r(uint8_t r_le[32]) {
+        uint8_t dg[32];
+        sha.finish(dg);
+        while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r: at most two subtractions (2^256 < 3r)
+        reverse32(r_le, dg);
+    }
+};
 static bool host_batch_challenges(uint8_t* r_out, const uint8_t* all_records, size_t B, size_t n, size_t n_total, size_t world) {
     std::atomic<bool> failed{false};
-    auto digest_range = [&](size_t b0, size_t b1) {
-        std::vector<uint8_t> t;
-        try {
-            t.resize(32 + 160 * n_total);
-        } catch (...) {
-            failed = true;
-            return;
-        }
-        memcpy(t.data(), "RCKZGBATCH___V1_", 16);
-        memset(t.data() + 16, 0, 16);
-        t[22] = (uint8_t)(KZG_HOST_FE_PER_BLOB >> 8);
-        t[23] = (uint8_t)(KZG_HOST_FE_PER_BLOB & 0xff);
-        for (int k = 0; k < 8; k++) t[24 + k] = (uint8_t)((uint64_t)n_total >> (56 - 8 * k));
+    auto digest_range = [&](size_t b0, size_t b1) {  // (the records are hashed where they lie: no transcript copy)
         for (size_t b = b0; b < b1; b++) {
-            if (world == 0) memcpy(t.data() + 32, all_records + 160 * n_total * b, 160 * n_total);
+            BatchTranscript t(n_total);
+            if (world == 0) t.records(all_records + 160 * n_total * b, n_total);
             else
-                for (size_t k = 0; k < world; k++) memcpy(t.data() + 32 + 160 * n * k, all_records + 160 * n * (k * B + b), 160 * n);
-            uint8_t dg[32];
-            hostsha::digest(dg, t.data(), t.size());
-            while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r: at most two subtractions (2^256 < 3r)
-            reverse32(r_out + 32 * b, dg);
+                for (size_t k = 0; k < world; k++) t.records(all_records + 160 * n * (k * B + b), n);
+            t.r(r_out + 32 * b);
         }
     };
-    static const size_t host_threads = [] {
-        const char* e = getenv("KZG_HOST_THREADS");
-        long v = e ? atol(e) : 16;
+    static const size_t host_threads = [] {  // option host_threads (capi_host_util.hpp; 16 in the stand-alone sanitizer build)
+#ifdef KZG_HOST_THREADS_OPTION
+        long v = KZG_HOST_THREADS_OPTION;
+#else
+        long v = 16;
+#endif
         return (size_t)(v < 1 ? 1 : v > 64 ? 64 : v);
     }();
     const size_t nthr = std::min(host_threads, std::min(B, (B * 160 * n_total) / (512 * 1024) + 1));

@@ -1272,8 +1272,7 @@ inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, 
     d.save = save;
     if (CV::QUADS)  // static + dynamic LDS pass 64 KB (set per call: the attribute belongs to the current device's copy of the kernel)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_window<CV, LDSSORT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_QUADS_LDS_BYTES);
-    static const bool bfirst_on = !(getenv("KZG_MSM_BFIRST") && getenv("KZG_MSM_BFIRST")[0] == '0');
-    if (bfirst_on && msm_two_pass<CV>() && per == gz && d.slices == 1 && (gz & 1) == 0 && d.nterms[1] > d.nterms[0]) d.flags |= MSM_FLAG_BFIRST;
+    if (msm_two_pass<CV>() && per == gz && d.slices == 1 && (gz & 1) == 0 && d.nterms[1] > d.nterms[0]) d.flags |= MSM_FLAG_BFIRST;
     for (unsigned z = 0; z < gz; z += per) {
         d.z0 = (int)z;
         const unsigned nz = std::min(per, gz - z);

@@ -20,7 +20,7 @@ pub mod trusted_setup;
 pub use consts::*;
 pub use dtypes::*;
 pub use kzg_proof::KzgProof;
-pub use pairings::pairings_verify;
+pub use pairings::{pairings_verify, try_pairings_verify};
 pub use trusted_setup::*;
 
 pub use enums::KzgError;

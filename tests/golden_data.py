@@ -43,3 +43,19 @@ def valid_blob_tuples():
             seen.add(c["blob"])
             out.append((blob(c["blob"]), bytes.fromhex(c["commitment"]), bytes.fromhex(c["proof"])))
     return out
+
+
+def off_subgroup_g1():
+    """48 compressed bytes of a point ON the curve y^2 = x^3 + 4 but (with overwhelming probability - callers confirm with
+    the oracle) OUTSIDE the r-torsion: G1Affine::from_compressed rejects it in its subgroup check (src/kzg_proof.rs:17-25)."""
+    P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    x = 5
+    while True:
+        y2 = (x * x * x + 4) % P
+        y = pow(y2, (P + 1) // 4, P)
+        if y * y % P == y2:
+            break
+        x += 1
+    enc = bytearray(x.to_bytes(48, "big"))
+    enc[0] |= 0x80 | (0x20 if y > P - y else 0)
+    return bytes(enc)

@@ -77,6 +77,20 @@ int main(int argc, char** argv) {
     sha_portable(d2, buf.data(), buf.size());
     CHECK(memcmp(d, d2, 32) == 0);
     printf("sha_ni %d\n", (int)hostsha::have_ni());
+    // the streaming form: the same message in pieces of random length (0 included) gives the one-shot digest
+    for (int it = 0; it < 200; it++) {
+        const size_t len = it < 100 ? rng() % 700 : rng() % buf.size();
+        sha_portable(d2, buf.data(), len);
+        hostsha::Stream st;
+        size_t pos = 0;
+        while (pos < len) {
+            const size_t take = std::min(len - pos, (size_t)(rng() % (it % 3 == 0 ? 5 : it % 3 == 1 ? 130 : 100000)));
+            st.update(buf.data() + pos, take);
+            pos += take;
+        }
+        st.finish(d);
+        CHECK(memcmp(d, d2, 32) == 0);
+    }
     // ---- 2. parser
     std::vector<uint8_t> g1b, g2b;
     uint8_t first[2][48];
@@ -146,6 +160,17 @@ int main(int argc, char** argv) {
         uint8_t be[32];
         reverse32(be, r1.data() + 32 * b);
         CHECK(!be_geq_r(be));
+    }
+    {   // the transcript as a stream of record pieces (capi_multi.hpp feeds it chunk by chunk)
+        BatchTranscript t(n_total);
+        for (size_t i = 0; i < n_total;) {
+            const size_t take = std::min(n_total - i, (size_t)(1 + rng() % 5));
+            t.records(flat.data() + 160 * i, take);
+            i += take;
+        }
+        uint8_t rr[32];
+        t.r(rr);
+        CHECK(memcmp(rr, r1.data(), 32) == 0);
     }
     printf("records %s\n", hex(flat.data(), 160 * n_total).c_str());  // batch 0's transcript records
     printf("r0 %s\n", hex(r1.data(), 32).c_str());                     // little-endian

@@ -329,7 +329,7 @@ def test_challenge_kernel_forms(form):
         "blobs = [rng.randbytes(131072) for _ in range(130)]\n"
         "cs = [rng.randbytes(48) for _ in range(130)]\n"
         "print(' '.join(z.hex() for z in api.compute_challenges(blobs, cs, st)))\n" % O.ROOT)
-    env = dict(os.environ, KZG_CHALLENGE_KERNEL=form)
+    env = dict(os.environ, KZG_OPTIONS="challenge_kernel=" + form)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     got = out.stdout.strip().split("\n")[-1].split()
@@ -339,22 +339,24 @@ def test_challenge_kernel_forms(form):
     assert got == [O.compute_challenge(b, c).hex() for b, c in zip(blobs, cs)]
 
 
-@pytest.mark.parametrize("env", [
-    {"KZG_MSM_LATENCY_LAYOUT": "0"},                         # small batches through the throughput layout: affine tables, mixed additions
-    {"KZG_MSM_LATENCY_LAYOUT": "0", "KZG_MSM_AFFINE": "0"},  # ... with Jacobian tables in the radix-2^29 field
-    {"KZG_FP29": "0"},                                       # point kernels in the 12x32 field
-    {"KZG_EVALUATE_KERNEL": "32"},                           # evaluation in the 8x32 field
-], ids=["affine-tables", "jacobian29-tables", "fp-12x32", "fr-8x32"])
-def test_kernel_variants_differential_fuzz(env):
-    """The alternative forms of the point and evaluation kernels (each selected for a whole process by an environment
-    variable) through 12 s of tools/fuzz_campaign.py: mutated c-kzg vectors with duplicates, points at infinity, points
+@pytest.mark.parametrize("opts", [
+    "msm_latency_layout=0",               # small batches through the throughput layout: affine tables, mixed additions
+    "msm_latency_layout=0;msm_affine=0",  # ... with Jacobian tables in the radix-2^29 field
+    "fp29=0",                             # point kernels in the 12x32 field            (A/B build only)
+    "evaluate_kernel=32",                 # evaluation in the 8x32 field                (A/B build only)
+    "proofs_chunks=16",                   # sixteen 16-bit chunks for the proof tuples  (A/B build only)
+], ids=["affine-tables", "jacobian29-tables", "fp-12x32", "fr-8x32", "proofs-16"])
+def test_kernel_variants_differential_fuzz(opts):
+    """The alternative forms of the point and evaluation kernels (each selected for a whole process through KZG_OPTIONS, in
+    the A/B build of the library - libkzg_rs_amd_ab.so, the product plus the variants; the shipped library holds only the
+    default forms) through 12 s of tools/fuzz_campaign.py: mutated c-kzg vectors with duplicates, points at infinity, points
     off the curve or outside G1 and non-canonical scalars, three entry points, every outcome equal to the oracle's.
     The default process takes the latency layout for batches this small, so this is also what runs the throughput
     layout's mixed-addition special cases (P + P, P - P, first addition into an empty bucket) against the oracle."""
     import subprocess
     import sys
     out = subprocess.run([sys.executable, os.path.join(O.ROOT, "tools", "fuzz_campaign.py"), "12", "20261002"],
-                         env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+                         env=dict(os.environ, KZG_OPTIONS=opts, KZG_LIB_OVERRIDE=api.LIB_AB_PATH), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
     assert "no mismatch" in out.stdout
 
@@ -542,7 +544,7 @@ def test_pairings_verify_general_g2_arguments(settings, osettings):
 
 @pytest.mark.parametrize("form", ["1", "2"])
 def test_pairing_forms_in_child_process(form):
-    """Both pairing programs on the GPU, each forced for a whole process (KZG_PAIRING=1: the one-wave throughput program
+    """Both pairing programs on the GPU, each forced for a whole process (KZG_OPTIONS pairing=1: the one-wave throughput program
     of slp.hpp; 2: the three-wave latency program of slp2.hpp - radix-2^29 lazy arithmetic, schoolbook towers): the same
     pairing checks (both outcomes, identity inputs) and a launch group of batches, against the oracle.  The default
     process picks by launch size, so without this test each form would see only one side of the threshold."""
@@ -580,7 +582,7 @@ def test_pairing_forms_in_child_process(form):
         "got = api.verify_blob_kzg_proof_batches_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, B, st2)\n"
         "res.append(got == [b not in (3, 17, 39) for b in range(B)])\n"
         "print('RESULT', all(res), len(res))\n" % (O.ROOT, os.path.join(O.ROOT, "tests")))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_PAIRING=form), capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_OPTIONS="pairing=" + form), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "RESULT True 16" in out.stdout, out.stdout[-2000:]
 
@@ -863,7 +865,7 @@ def test_finish_without_matching_group_is_rejected(settings):
 def test_host_fed_stream_of_batches():
     """kzg_verify_blob_kzg_proof_batches: batches in HOST memory, copied in chunks on a copy stream while the previous chunk is
     verified.  Same results as the oracle batch by batch - a wrong proof, an invalid blob and an invalid commitment among
-    valid batches - in chunks of 3 + 2 (5 batches of 6) and 20 + 20 (40 batches of 1), and with KZG_HOST_CHUNK-independent layout; then a second call with a larger chunk on the same handle
+    valid batches - in chunks of 3 + 2 (5 batches of 6) and 20 + 20 (40 batches of 1), and with a chunk-independent layout; then a second call with a larger chunk on the same handle
     (staging sets regrown)."""
     from kzg_rs_amd import synth
     n, B = 6, 5
@@ -964,7 +966,7 @@ def test_sliced_host_handover_gives_the_same_challenges():
 
 @pytest.mark.parametrize("slices", ["1", "2", "16"])
 def test_host_slices_forced_in_child_process(slices):
-    """KZG_HOST_SLICES = 1 (one copy, the round-2 behaviour), 2 and 16: the host entry point on a 200-blob batch (valid,
+    """KZG_OPTIONS host_slices = 1 (one copy, the round-2 behaviour), 2 and 16: the host entry point on a 200-blob batch (valid,
     a corrupted proof, a non-canonical element in the last field element of a blob) and the challenges of 130 blobs against
     the oracle - every slicing must give the same results as the default (4 and 8, covered by the tests above)."""
     import subprocess
@@ -991,7 +993,7 @@ def test_host_slices_forced_in_child_process(slices):
         "z = api.compute_challenges(bl, cs[:130], st)\n"
         "assert all(z[i] == O.compute_challenge(bl[i], cs[i]) for i in (0, 1, 63, 64, 65, 129))\n"
         "print('slices-ok')\n" % (ROOT, HERE))
-    e = dict(os.environ, KZG_HOST_SLICES=slices)
+    e = dict(os.environ, KZG_OPTIONS="host_slices=" + slices)
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "slices-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of process-wide switches through bench.py: prints throughput and the stand-alone kernel times for each setting.
-#   tools/prof/ab_env.sh "KZG_MSM_ROTATE=0 KZG_MSM_XCD=0" "KZG_MSM_ROTATE=1 KZG_MSM_XCD=0" ...
+#   tools/prof/ab_env.sh "KZG_OPTIONS=msm_xcd=0" "KZG_OPTIONS=msm_xcd=1" ...
 # ("-" = the defaults).  Every setting runs twice, alternating, so that clock state of the box shows up as spread.
 for rep in 1 2; do
   for setting in "$@"; do

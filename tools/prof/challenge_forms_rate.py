@@ -1,5 +1,5 @@
 """Challenge kernel forms by launch size: time of the challenge kernel (kzg_last_timings[5]) for one batch of n device-resident
-blobs, each form forced in a child process (KZG_CHALLENGE_KERNEL).   python tools/prof/challenge_forms_rate.py [n ...]"""
+blobs, each form forced in a child process (KZG_OPTIONS challenge_kernel=...).   python tools/prof/challenge_forms_rate.py [n ...]"""
 import os
 import subprocess
 import sys
@@ -26,5 +26,5 @@ print("challenge %%.3f ms  whole call %%.3f ms" %% (t[5], t[0]))
 """ % ROOT
 for n in [int(x) for x in sys.argv[1:]] or [1024, 8192, 16384, 24576, 32768, 49152]:
     for form in ("lane", "split", "split2"):
-        out = subprocess.run([sys.executable, "-c", CODE, str(n)], env=dict(os.environ, KZG_CHALLENGE_KERNEL=form), capture_output=True, text=True)
+        out = subprocess.run([sys.executable, "-c", CODE, str(n)], env=dict(os.environ, KZG_OPTIONS="challenge_kernel=" + form), capture_output=True, text=True)
         print("n=%6d %-6s %s" % (n, form, out.stdout.strip().splitlines()[-1] if out.returncode == 0 and out.stdout.strip() else out.stderr[-300:]))

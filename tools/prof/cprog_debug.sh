@@ -14,8 +14,8 @@ echo "== plain (system libamdhip64)"; /tmp/cabi_vectors kzg_rs_amd/data/trusted_
 ldd /tmp/cabi_vectors | grep -i hip
 echo "== HIP_HOST_COHERENT=1"; HIP_HOST_COHERENT=1 /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3
 echo "== torch's runtime"; LD_LIBRARY_PATH=$TORCHLIB /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3
-echo "== KZG_CU_MASK=0"; KZG_CU_MASK=0 /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3
-echo "== KZG_SINGLE_STREAM=1"; KZG_SINGLE_STREAM=1 /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3
-echo "== KZG_PAIRING=1"; KZG_PAIRING=1 /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3
-echo "== KZG_DECODE_QUADS=0"; KZG_DECODE_QUADS=0 /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3
-echo "== KZG_MSM_LATENCY_LAYOUT=0"; KZG_MSM_LATENCY_LAYOUT=0 /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3
+echo "== KZG_OPTIONS=cu_mask=0"; KZG_OPTIONS=cu_mask=0 /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3
+echo "== KZG_OPTIONS=single_stream=1"; KZG_OPTIONS=single_stream=1 /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3
+echo "== KZG_OPTIONS=pairing=1"; KZG_OPTIONS=pairing=1 /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3
+echo "== KZG_OPTIONS=decode_quads=0"; KZG_OPTIONS=decode_quads=0 /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3
+echo "== KZG_OPTIONS=msm_latency_layout=0"; KZG_OPTIONS=msm_latency_layout=0 /tmp/cabi_vectors kzg_rs_amd/data/trusted_setup.txt /tmp/vectors.bin 2>&1 | tail -3

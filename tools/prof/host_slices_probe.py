@@ -25,5 +25,5 @@ print("wall median %%.3f ms min %%.3f | device %%.3f phase1 %%.3f challenge(+cop
 """
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 for s in ("1", "2", "4", "8", "16"):
-    r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, n)], env=dict(os.environ, KZG_HOST_SLICES=s), capture_output=True, text=True)
-    print("KZG_HOST_SLICES=%-2s %s" % (s, (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1]))
+    r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, n)], env=dict(os.environ, KZG_OPTIONS="host_slices=" + s), capture_output=True, text=True)
+    print("host_slices=%-2s %s" % (s, (r.stdout.strip().splitlines() or [r.stderr[-300:]])[-1]))

@@ -1,5 +1,5 @@
 """Rate of the host-fed stream entry point (kzg_verify_blob_kzg_proof_batches) for a few chunk sizes:
-    KZG_HOST_CHUNK is read once per process, so each setting runs in a child process.
+    the option host_chunk is read once per process, so each setting runs in a child process.
     python tools/prof/host_stream_rate.py [n_batches]"""
 import os
 import subprocess
@@ -24,6 +24,6 @@ for rep in range(3):
     print("pass %%d: %%.1f ms, %%.0f blobs/s, %%.1f GB/s" %% (rep, dt * 1e3, n * NB / dt, n * NB * 131168 / dt / 1e9))
 """ % (ROOT, NB)
 for chunk in (2, 4, 8, 16, 32):
-    out = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, KZG_HOST_CHUNK=str(chunk)), capture_output=True, text=True)
-    print("KZG_HOST_CHUNK=%d" % chunk)
+    out = subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, KZG_OPTIONS="host_chunk=%d" % chunk), capture_output=True, text=True)
+    print("host_chunk=%d" % chunk)
     print(out.stdout.strip() if out.returncode == 0 else out.stderr[-800:])

@@ -6,7 +6,7 @@ tag=$1
 export TMPDIR=/tmp
 out=/tmp/sg_$tag
 rm -rf $out
-KZG_SINGLE_STREAM=1 rocprofv3 --kernel-trace --stats -d $out -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-latency --no-self-check --group 256 --inflight 1 --steps 3 --warmup 1 > /tmp/sg_$tag.log 2>&1
+KZG_OPTIONS=single_stream=1 rocprofv3 --kernel-trace --stats -d $out -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-latency --no-self-check --group 256 --inflight 1 --steps 3 --warmup 1 > /tmp/sg_$tag.log 2>&1
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 python3 - "$f" > gpurun_out/${tag}_single_group_stats.txt <<'PY'
 import csv, sys

@@ -1,5 +1,5 @@
 """Latency of ONE pairing check (kzg_pairing_check: decode two points + the VERIFY program), per library build:
-    python tools/prof/pairing_latency.py [lib.so ...]     (default: the in-tree library; KZG_PAIRING=1|2 forces a form)
+    python tools/prof/pairing_latency.py [lib.so ...]     (default: the in-tree library; KZG_OPTIONS pairing=1|2 forces a form)
 Prints the program's own interval (HIP events around it) as the median of 30 calls."""
 import os
 import subprocess
@@ -21,7 +21,7 @@ print('pairing_ms median %%.4f min %%.4f' %% (statistics.median(ts[10:]), min(ts
 libs = sys.argv[1:] or [None]
 for lib in libs:
     for form in ("1", "2"):
-        env = dict(os.environ, KZG_PAIRING=form)
+        env = dict(os.environ, KZG_OPTIONS="pairing=" + form)
         if lib:
             env["KZG_LIB_OVERRIDE"] = os.path.abspath(lib)
         out = subprocess.run([sys.executable, "-c", CODE], env=env, capture_output=True, text=True)

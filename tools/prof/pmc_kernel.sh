@@ -6,7 +6,7 @@ pat=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out/pmc_one
 rm -rf $out; mkdir -p $out
-KZG_SINGLE_STREAM=1 timeout 300 rocprofv3 --pmc "$@" --kernel-trace -d $out -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-latency --no-self-check --group 256 --inflight 1 --steps 1 --warmup 0 > $out.log 2>&1
+KZG_OPTIONS=single_stream=1 timeout 300 rocprofv3 --pmc "$@" --kernel-trace -d $out -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-latency --no-self-check --group 256 --inflight 1 --steps 1 --warmup 0 > $out.log 2>&1
 python3 - "$pat" $out/run_counter_collection.csv <<'PY'
 import csv, sys, collections
 pat, path = sys.argv[1], sys.argv[2]

@@ -10,7 +10,7 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCL
     i=$((i+1))
     out=gpurun_out/${tag}_pmc_$i
     rm -rf $out; mkdir -p $out
-    KZG_SINGLE_STREAM=1 KZG_PMC_CALIBRATE=1 rocprofv3 --pmc $ctrs --kernel-trace -d $out -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-latency --no-self-check --group $group --inflight 1 --steps 1 --warmup 0 > $out.log 2>&1
+    KZG_OPTIONS=single_stream=1 KZG_PMC_CALIBRATE=1 rocprofv3 --pmc $ctrs --kernel-trace -d $out -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-latency --no-self-check --group $group --inflight 1 --steps 1 --warmup 0 > $out.log 2>&1
 done
 python3 tools/prof/pmc_to_json.py gpurun_out/${tag}_pmc $group > gpurun_out/${tag}_pmc.json
 rm -rf gpurun_out/${tag}_pmc_1 gpurun_out/${tag}_pmc_2 gpurun_out/${tag}_pmc_3

@@ -48,7 +48,7 @@ for name, o in kern.items():
     if "FETCH_SIZE" in o and "WRITE_SIZE" in o:
         o["hbm_bytes_corrected"] = round(2 * o["FETCH_SIZE"] * 1024 + o["WRITE_SIZE"] * 1024)
 print(json.dumps({
-    "method": "rocprofv3 --pmc, one counter set per run, KZG_SINGLE_STREAM=1, bench.py --group %d --inflight 1 --steps 1 --warmup 0: one "
+    "method": "rocprofv3 --pmc, one counter set per run, KZG_OPTIONS=single_stream=1, bench.py --group %d --inflight 1 --steps 1 --warmup 0: one "
               "launch group of %d batches x 1024 blobs; values are per launch of the kernel (its largest dispatch). FETCH_SIZE / "
               "WRITE_SIZE in KB as reported; hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
               "MI355X_MICROARCH.md HBM section); calibration = the same counters on a dispatch that reads 128 MiB and writes 128 MiB." % (group, group),
