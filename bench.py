@@ -23,11 +23,14 @@ Rank 0 prints ONE JSON line.
 `python3 bench.py --gpus N` from a bare command (no WORLD_SIZE in the environment) starts the N ranks itself, as child
 processes, BEFORE anything in this process has touched the GPU, and exits with their worst return code.
 
-Also in the line: `self_check` (one control group of the full shape with a corrupted proof in one batch and a non-canonical
-field element in another - the benchmarked kernels must say false / Err for exactly those), `roofline.standalone_ms`
-(the dominant kernel alone on the chip: one launch group on a single-stream handle, nothing else in flight), `path`
-(whole-path algorithmic bandwidth and the HBM traffic ratio), `verify_kzg_proof_ms`, and at N > 1 `multi_gpu.single_process`
-(ONE process driving all N GPUs through a multi-device settings handle and the unchanged entry point, in-process RCCL).
+Also in the line: `self_check` (the negative control THROUGH THE BENCHMARKED ENTRY POINT: five launch groups of the full
+shape through kzg_verify_blob_kzg_proof_batch_groups_device with the benchmark's groups in flight, a wrong proof, a field
+element equal to r and a commitment outside G1 poisoned into batches of DIFFERENT groups and lanes - the call must say
+false / Err / Err for exactly those), `roofline.standalone_ms` (the dominant kernel alone on the chip: one launch group on a
+single-stream handle, nothing else in flight), `path` (whole-path algorithmic bandwidth and the HBM traffic ratio),
+`verify_kzg_proof_ms`, and at N > 1 `multi_gpu.single_process` (ONE process driving all N GPUs through a multi-device
+settings handle: launch groups routed to the devices that own them, one sharded batch at a time, and a stream of sharded
+batches in flight).
 """
 import argparse
 import json
@@ -79,12 +82,37 @@ def cpu_baseline(blobs, cs, ps, tau_g2, max_blobs):
     ok3 = O.verify_kzg_proof_batch(cs[:m], [zs[32 * i: 32 * i + 32] for i in range(m)], [ys[32 * i: 32 * i + 32] for i in range(m)], ps[:m], ost)
     dtail = time.perf_counter() - t
     assert ok and ok2 and ok3, "oracle rejects the synthetic batch"
+    # The honest whole-host figure: the reference has no threads (src/kzg_proof.rs:251-277, :399-444 are plain loops), so an
+    # operator fills a host with INDEPENDENT verifications - min(cores, 64) threads, each one single-threaded
+    # verify_blob_kzg_proof_batch of its own 64-blob batch (the oracle is C behind ctypes: the calls run outside the GIL).
+    import threading
+    nthr, mb = min(ncores, 64), min(64, m)
+    oks = [None] * nthr
+    rounds = 2
+
+    def worker(i):
+        lo = (i * mb) % max(m - mb + 1, 1)
+        for _ in range(rounds):
+            oks[i] = O.verify_blob_kzg_proof_batch(bl[lo:lo + mb], cs[lo:lo + mb], ps[lo:lo + mb], ost, nthreads=1)
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(nthr)]
+    t = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    dt_ind = time.perf_counter() - t
+    assert all(oks), "oracle rejects a synthetic sub-batch"
     return {
+        "all_cores_independent": {"value": round(nthr * mb * rounds / dt_ind, 2), "unit": "blobs/s", "cores": nthr, "host_cores": ncores,
+                                  "sample": "%d threads (min(host cores, 64)), each %d single-threaded verify_blob_kzg_proof_batch calls of its own "
+                                            "%d-blob batch: %.2f s - the process-level parallelism an operator of the single-threaded reference would use"
+                                            % (nthr, rounds, mb, dt_ind)},
         "value": round(m / dt1, 2), "unit": "blobs/s", "cores": 1, "kind": "port",
         "sample": "%d of the same synthetic blobs, one verify_blob_kzg_proof_batch call, 1 thread (the reference is single-threaded): "
                   "%.2f s, of which per-blob phase (challenge + evaluation, src/kzg_proof.rs:251-277) %.2f s and random linear combination + "
-                  "pairing (:399-444) %.2f s.  All %d host cores: %.1f blobs/s - only the per-blob loop is threaded there, the %.2f s of the "
-                  "second phase stay serial (its Amdahl limit: %.0f blobs/s), so this is NOT a whole-host figure to set the GPU against"
+                  "pairing (:399-444) %.2f s.  (ONE call with its per-blob loop threaded over all %d host cores: %.1f blobs/s - the %.2f s of the "
+                  "second phase stay serial, Amdahl limit %.0f blobs/s; the whole-host figure is all_cores_independent)"
                   % (m, dt1, max(dt1 - dtail, 0.0), dtail, ncores, m / dtn, dtail, m / dtail),
         "phases_s": {"per_blob": round(max(dt1 - dtail, 0.0), 3), "rlc_and_pairing": round(dtail, 3), "all_cores_call": round(dtn, 3)},
     }
@@ -122,8 +150,14 @@ def spawn_ranks(n):
 
 def single_process_leg(spec, n, steps, warmup):
     """`--single-process-devices 0,1,...`: ONE process, ONE settings handle over the listed devices (include/kzg_rs_amd.h:
-    kzg_settings_from_tau_g2_devices), one batch of n blobs PER DEVICE already resident there, verified through
-    kzg_verify_blob_kzg_proof_batch_sharded - BASELINE configs[4] behind the reference's call shape (one call, one bool).
+    kzg_settings_from_tau_g2_devices) - what a caller of the reference's one-process signature has on a multi-GPU node.
+    n blobs resident PER DEVICE.  Three legs, each checked with a negative control:
+      sharded_batch   one verify_blob_kzg_proof_batch of n x D blobs at a time (BASELINE configs[4] behind the reference's call
+                      shape: one call, one bool) through kzg_verify_blob_kzg_proof_batch_sharded, with its host stage split
+      sharded_stream  the same batches through kzg_verify_blob_kzg_proof_batch_sharded_stream, 4 in flight: the transcript
+                      hash of one batch beside the device phases of the others
+      groups          independent 1 024-blob batches, launch groups of 32 routed to the device that owns them
+                      (kzg_verify_blob_kzg_proof_batch_groups_device, 3 groups in flight per device, no exchange)
     Prints one JSON object."""
     import ctypes as C
 
@@ -132,6 +166,7 @@ def single_process_leg(spec, n, steps, warmup):
     from kzg_rs_amd import api, synth
 
     devs = [int(x) for x in spec.split(",")]
+    D = len(devs)
     torch.cuda.set_device(devs[0])
     blobs, cs, ps, st0 = synth.make_valid_batch(n, seed=77, chunk=1024)
     st = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1], devices=devs)
@@ -146,9 +181,11 @@ def single_process_leg(spec, n, steps, warmup):
              torch.frombuffer(bad, dtype=torch.uint8).to(dev))
         keep.append(t)
         shards.append((t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), n))
-        shards_bad.append((t[0].data_ptr(), t[1].data_ptr(), (t[3] if k == len(devs) - 1 else t[2]).data_ptr(), n))
+        shards_bad.append((t[0].data_ptr(), t[1].data_ptr(), (t[3] if k == D - 1 else t[2]).data_ptr(), n))
     for d in devs:
         torch.cuda.synchronize(d)
+    stage_names = ("call", "copy_and_phase1", "transcript_hash_after_last_piece", "phase2_launch", "exchange", "fold_and_pairing", "transcript_hash_busy", "pieces")
+    # ---- one sharded batch at a time
     for _ in range(max(warmup, 1)):
         assert api.verify_blob_kzg_proof_batch_sharded(shards, st) is True
     t0 = time.perf_counter()
@@ -157,25 +194,77 @@ def single_process_leg(spec, n, steps, warmup):
     dt = (time.perf_counter() - t0) / steps
     stages = st.multi_last_timings()
     neg = api.verify_blob_kzg_proof_batch_sharded(shards_bad, st)
-    # the same batch from HOST memory through the unchanged kzg_verify_blob_kzg_proof_batch (every slice over its own PCIe link)
+    # ---- a stream of sharded batches, several in flight
+    NB, F = max(8, 2 * steps), 4
+    stream_in = [shards] * (NB - 1) + [shards_bad]
+    want = [True] * (NB - 1) + [False]
+    assert api.verify_blob_kzg_proof_batch_sharded_stream(stream_in[-F - 1:], st, in_flight=F) == want[-F - 1:]   # lanes and workspaces
+    t0 = time.perf_counter()
+    got = api.verify_blob_kzg_proof_batch_sharded_stream(stream_in, st, in_flight=F)
+    dts = time.perf_counter() - t0
+    sstages = st.multi_last_timings()
+    stream = {"batches": NB, "in_flight": F, "ms_per_batch": round(dts / NB * 1e3, 4), "value": round(n * D * NB / dts, 2), "unit": "blobs/s",
+              "results_as_expected": got == want,
+              "stage_ms_avg_per_batch": {k: round(v, 4) for k, v in zip(stage_names[1:7], sstages[1:7])}}
+    # ---- independent batches: launch groups routed to the devices that own them
+    groups_leg = None
+    nb = 1024
+    if n >= nb:
+        B = min(n // nb, 32)
+        KG = max(6, steps)  # groups per device (the pointers repeat)
+        glist, gwant = [], []
+        for g in range(KG):
+            for k in range(D):
+                last = g == KG - 1 and k == D - 1
+                off = (n // nb - B) * nb  # the group that ends with the shard's last batch (where the bad proof sits)
+                t = keep[k]
+                glist.append((t[0].data_ptr() + off * BYTES_PER_BLOB, t[1].data_ptr() + 48 * off, (t[3] if last else t[2]).data_ptr() + 48 * off))
+                gwant.append([True] * (B - 1) + [not last])
+        assert api.verify_blob_kzg_proof_batch_groups_device(glist[-3 * D:], nb, B, st, in_flight=3) == gwant[-3 * D:]
+        t0 = time.perf_counter()
+        gres = api.verify_blob_kzg_proof_batch_groups_device(glist, nb, B, st, in_flight=3)
+        dtg = time.perf_counter() - t0
+        groups_leg = {"groups": len(glist), "groups_per_device": KG, "batches_per_group": B, "blobs_per_batch": nb, "in_flight_per_device": 3,
+                      "value": round(len(glist) * B * nb / dtg, 2), "unit": "blobs/s", "ms": round(dtg * 1e3, 3), "results_as_expected": gres == gwant,
+                      "what": "independent %d-blob batches in launch groups of %d, every group on the device that holds it, one pipeline and host "
+                              "thread per device, no exchange" % (nb, B)}
+    # the same batch from HOST memory through the unchanged kzg_verify_blob_kzg_proof_batch (interleaved chunks, each over its device's PCIe link)
     host = None
-    if n * len(devs) <= 8192:
-        hb = np_tile(blobs, len(devs))
+    if n * D <= 8192:
+        hb = np_tile(blobs, D)
         okh = C.c_bool(False)
         for _ in range(2):
-            api._chk(api.lib().kzg_verify_blob_kzg_proof_batch(C.byref(okh), hb.ctypes.data_as(C.c_char_p), hc * len(devs), hp * len(devs), n * len(devs), st._h))
+            api._chk(api.lib().kzg_verify_blob_kzg_proof_batch(C.byref(okh), hb.ctypes.data_as(C.c_char_p), hc * D, hp * D, n * D, st._h))
         t0 = time.perf_counter()
         for _ in range(steps):
-            api._chk(api.lib().kzg_verify_blob_kzg_proof_batch(C.byref(okh), hb.ctypes.data_as(C.c_char_p), hc * len(devs), hp * len(devs), n * len(devs), st._h))
-        host = {"ms_per_call": round((time.perf_counter() - t0) / steps * 1e3, 4), "ok": bool(okh.value)}
+            api._chk(api.lib().kzg_verify_blob_kzg_proof_batch(C.byref(okh), hb.ctypes.data_as(C.c_char_p), hc * D, hp * D, n * D, st._h))
+        hst = st.multi_last_timings()
+        host = {"ms_per_call": round((time.perf_counter() - t0) / steps * 1e3, 4), "ok": bool(okh.value),
+                "stage_ms": {k: round(v, 4) for k, v in zip(stage_names, hst)}}
     devices, exchange = st.devices()
-    print(json.dumps({"devices": devices, "exchange": exchange, "batch": n * len(devs), "blobs_per_device": n, "steps": steps,
-                      "ms_per_call": round(dt * 1e3, 4), "value": round(n * len(devs) / dt, 2), "unit": "blobs/s", "ok": bool(ok),
-                      "corrupted_proof_on_last_device": neg,
-                      "stage_ms": {k: round(v, 4) for k, v in zip(("call", "copy_and_phase1", "transcript_hash", "phase2_launch", "exchange", "fold_and_pairing"), stages)},
-                      "host_vec_blob": host,
-                      "what": "one process, one multi-device KzgSettings handle, ONE verify_blob_kzg_proof_batch of %d blobs sharded by blob "
-                              "(%d resident per device), partial sums exchanged by %s" % (n * len(devs), n, exchange)}))
+    print(json.dumps({"devices": devices, "exchange": exchange, "batch": n * D, "blobs_per_device": n, "steps": steps,
+                      "sharded_batch": {"ms_per_call": round(dt * 1e3, 4), "value": round(n * D / dt, 2), "unit": "blobs/s", "ok": bool(ok),
+                                        "corrupted_proof_on_last_device": neg,
+                                        "stage_ms": {k: round(v, 4) for k, v in zip(stage_names, stages)}},
+                      "sharded_stream": stream, "groups": groups_leg, "host_vec_blob": host,
+                      "what": "one process, one multi-device KzgSettings handle over %d device(s); sharded batches of %d blobs (%d resident per device), "
+                              "partial sums exchanged by %s" % (D, n * D, n, exchange)}))
+
+
+def off_subgroup_g1():
+    """48 compressed bytes of a point ON y^2 = x^3 + 4 but outside the r-torsion (the first x >= 5 with a square right-hand
+    side; a random curve point lies in G1 with probability ~2^-126): from_compressed's subgroup check rejects it."""
+    P = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+    x = 5
+    while True:
+        y2 = (x * x * x + 4) % P
+        y = pow(y2, (P + 1) // 4, P)
+        if y * y % P == y2:
+            break
+        x += 1
+    enc = bytearray(x.to_bytes(48, "big"))
+    enc[0] |= 0x80 | (0x20 if y > P - y else 0)
+    return bytes(enc)
 
 
 def np_tile(blobs, k):
@@ -423,27 +512,57 @@ def main():
                       "k_slp_run(pairing)": st_tm[3], "whole_group": st_tm[0]}
         if not all(r is True for r in solo_res):
             raise SystemExit("verification of a valid synthetic batch returned false (stand-alone group)")
-        # ---- self check at the benchmarked shape: the same full group with two poisoned batches.  Batch `bf` gets a valid G1
-        # point that is not its blob's proof (-> false), batch `be` a field element >= r (-> Err); everything else stays true.
-        bf, be = (G // 3, (2 * G) // 3) if G >= 3 else (0, G - 1)
-        i_f, i_e = bf * n + n // 2, be * n + n - 1
-        keep_p = v[2][i_f].clone()
-        keep_e = v[0][i_e, 64:96].clone()
-        v[2][i_f] = v[2][(i_f + 1) % (n * G)]
-        v[0][i_e, 64:96] = torch.tensor(list((0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001).to_bytes(32, "big")), dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-        res = api.verify_blob_kzg_proof_batches_device(v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), n, G, solo)
-        v[2][i_f] = keep_p
-        v[0][i_e, 64:96] = keep_e
-        torch.cuda.synchronize()
-        false_b = [b for b, r in enumerate(res) if r is False]
-        err_b = [b for b, r in enumerate(res) if r is None]
-        want_f, want_e = ([bf], [be]) if bf != be else ([], [be])
         solo_sums, solo_cnt = solo.timing_totals()
-        self_check = {"batches": G, "blobs": n * G, "poisoned": {"wrong_proof_in_batch": bf, "non_canonical_element_in_batch": be},
-                      "false_batches": false_b, "err_batches": err_b, "true_batches": sum(1 for r in res if r is True),
-                      "passed": false_b == want_f and err_b == want_e and sum(1 for r in res if r is True) == G - len(set(want_f + want_e))}
         solo.close()
+        # ---- self check THROUGH THE BENCHMARKED ENTRY POINT at the benchmarked shape (src/kzg_proof.rs:436-444 -> Ok(false);
+        # src/dtypes.rs:48-57, src/kzg_proof.rs:17-25 -> Err): n_handles + 1 full launch groups through ONE
+        # kzg_verify_blob_kzg_proof_batch_groups_device call with the benchmark's groups in flight, so every lane of the
+        # pipeline carries a group and lane 0 carries two.  Poisoned in DIFFERENT groups (= different lanes): group 0 a valid
+        # G1 point that is not its blob's proof (-> false), group 1 a field element equal to r (-> Err), group 2 a
+        # commitment on the curve but outside G1 (-> Err); the last group repeats group 0's memory (-> false again).
+        NG = n_handles + 1
+        order = [i % n_handles for i in range(NG)]
+        bf, be, bc = G // 3, (2 * G) // 3, G - 1
+        poison = {}
+        if n_handles >= 3 and G >= 3:
+            poison = {0: ("wrong_proof", bf, None), 1: ("element_equals_r", be, None), 2: ("commitment_outside_g1", bc, None)}
+        else:  # (a reduced --inflight / --group: everything in the one variant there is)
+            poison = {0: ("wrong_proof", 0, None)}
+        saved = []
+        r_be = torch.tensor(list((0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001).to_bytes(32, "big")), dtype=torch.uint8, device=dev)
+        off_g1 = torch.tensor(list(off_subgroup_g1()), dtype=torch.uint8, device=dev)
+        for vi, (kind, b, _) in poison.items():
+            vv = variants[vi]
+            if kind == "wrong_proof":
+                i = b * n + n // 2
+                saved.append((vv[2], i, vv[2][i].clone()))
+                vv[2][i] = vv[2][(i + 1) % (n * G)]
+            elif kind == "element_equals_r":
+                i = b * n + n - 1
+                saved.append((vv[0], (i, slice(64, 96)), vv[0][i, 64:96].clone()))
+                vv[0][i, 64:96] = r_be
+            else:
+                i = b * n + 1
+                saved.append((vv[1], i, vv[1][i].clone()))
+                vv[1][i] = off_g1
+        torch.cuda.synchronize()
+        res = api.verify_blob_kzg_proof_batch_groups_device([tuple(t.data_ptr() for t in variants[vi]) for vi in order], n, G, settings, in_flight=F)
+        for t, i, old in saved:
+            t[i] = old
+        torch.cuda.synchronize()
+        want = [[True] * G for _ in range(NG)]
+        for g, vi in enumerate(order):
+            if vi in poison:
+                want[g][poison[vi][1]] = False if poison[vi][0] == "wrong_proof" else None
+        false_b = [[g, b] for g in range(NG) for b in range(G) if res[g][b] is False]
+        err_b = [[g, b] for g in range(NG) for b in range(G) if res[g][b] is None]
+        self_check = {"entry_point": "kzg_verify_blob_kzg_proof_batch_groups_device", "groups": NG, "groups_in_flight": F, "batches_per_group": G,
+                      "blobs": n * G * NG,
+                      "poisoned": [{"group": g, "lane": g % (n_handles), "batch": poison[vi][1], "how": poison[vi][0]} for g, vi in enumerate(order) if vi in poison],
+                      "false_batches": false_b, "err_batches": err_b, "true_batches": sum(1 for row in res for r in row if r is True),
+                      "passed": res == want}
+        # the clean groups again: nothing of the poisoned call may linger on the lanes
+        run_groups(n_handles)
         if world == 1:
             # one proof at a time (src/kzg_proof.rs:353-397, the revm precompile's call): median of 32 calls
             pc, pz, py, pp, _ = synth.make_valid_proofs(1, seed=5, settings=settings)
@@ -504,9 +623,13 @@ def main():
         per_blob = insts / pmc["blobs_per_launch"]  # wave-instructions per blob, all kernels of the path
         simds, clock = 1024, 2.4e9
         valu = {"wave_insts_per_blob": round(per_blob), "insts_per_cycle_per_simd": round(per_blob * (n * G * K / elapsed) / (simds * clock), 4),
+                "cycles_per_inst": round((simds * clock) / (per_blob * (n * G * K / elapsed)), 3),
+                "ceiling_insts_per_cycle_per_simd": {"multiply_add_kernels (evaluate, decode, MSM window, MSM reduce)": 0.238, "sha256 (k_blob_challenge)": 0.256},
                 "note": "VALU wave-instructions issued per SIMD cycle at the measured throughput (SQ_INSTS_VALU of every kernel of the path, profiles/"
-                        + pmc_file + "); gfx950 issues the path's instruction mix at 2.4-4.3 cycles per wave-instruction "
-                        "(profiles/r1_issuebench_valu_issue_cost.txt, the builder's own microbenchmark), i.e. 0.23-0.42 is the ceiling"}
+                        + pmc_file + ").  Ceilings per kernel class, from the builder's microbenchmarks: the multiply-add kernels are v_mad_u64_u32 / "
+                        "carry-chain code at 4.2 cycles per wave-instruction on a saturated SIMD = 0.238 (profiles/r1_issuebench_valu_issue_cost.txt; "
+                        "with the 2-4 wavefronts per SIMD their register budgets allow: 5.5 / 5.15 / 4.9 cycles, profiles/r3_depbench_mad_issue_vs_occupancy.txt); "
+                        "the SHA-256 kernel mixes 4.2-cycle rotates with 2.4-cycle logic at 3.9 cycles = 0.256 (profiles/r1_shabench_sha256_compress.txt)"}
         path_bytes = sum(prof[k].get("hbm_bytes_corrected", 0) for k in path if k in prof)
         path_ratio = round(path_bytes / (PATH_ALG_BYTES * pmc["blobs_per_launch"]), 3)
     except Exception:
@@ -593,16 +716,30 @@ def main():
 
 
 def run_single_process_child(devices, n, timeout=420):
+    """The one-process leg in child processes (a failure or a hang there costs that leg, not the line): once with the default
+    exchange (partial sums through pinned host memory) and once with the in-process RCCL all-gather (KZG_OPTIONS
+    multi_exchange=rccl) - on a list of distinct devices that is the north star's collective over xGMI."""
     import subprocess
-    try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-process-devices", devices, "--blobs", str(n)],
-                           capture_output=True, text=True, timeout=timeout)
-        for line in reversed(r.stdout.strip().splitlines()):
-            if line.startswith("{"):
-                return json.loads(line)
-        return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-600:])}
-    except Exception as e:  # timeout included
-        return {"error": repr(e)[:600]}
+    out = {}
+    for name, opts in (("host_exchange", None), ("rccl_exchange", "multi_exchange=rccl")):
+        env = dict(os.environ)
+        if opts:
+            if len(set(devices.split(","))) != len(devices.split(",")):
+                out[name] = {"skipped": "the device list names a device twice: ncclCommInitAll needs distinct devices"}
+                continue
+            env["KZG_OPTIONS"] = ";".join(x for x in (env.get("KZG_OPTIONS"), opts) if x)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-process-devices", devices, "--blobs", str(n)],
+                               capture_output=True, text=True, timeout=timeout, env=env)
+            for line in reversed(r.stdout.strip().splitlines()):
+                if line.startswith("{"):
+                    out[name] = json.loads(line)
+                    break
+            else:
+                out[name] = {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-600:])}
+        except Exception as e:  # timeout included
+            out[name] = {"error": repr(e)[:600]}
+    return out
 
 
 if __name__ == "__main__":

@@ -143,3 +143,16 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_groups_device(bool* ok_out, ui
 } catch (const std::bad_alloc&) {
     return fail(KZG_MALLOC, "host buffers of the pipeline");  // (nothing is thrown across the C ABI)
 }
+
+// test hook: the transcript records (160 B each: C || z LE || y LE || pi) of the last launch group that ran on lane `lane` of
+// the handle (0 = the handle itself), entries [first, first + count) of the group's blobs in order - what lets a test compare
+// the (z, y) the in-library pipeline computed with the oracle's (tests/test_gpu_baseline_sizes.py)
+extern "C" KzgRet kzg_debug_lane_records(uint8_t* out, size_t lane, size_t first, size_t count, const KzgSettings* s) {
+    if (!s || !out) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (lane > s->lanes.size()) return fail(KZG_BADARGS, "no such lane");
+    const KzgSettings* l = lane_of(s, lane);
+    if (!l->ws.h_buf || first + count > l->ws.cap_n) return fail(KZG_BADARGS, "records out of range");
+    memcpy(out, l->ws.h_buf + 160 * first, 160 * count);
+    return KZG_OK;
+}

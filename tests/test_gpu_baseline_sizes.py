@@ -9,6 +9,7 @@ import random
 import numpy as np
 import pytest
 
+import golden_data as G
 import oracle_lib as O
 from kzg_rs_amd import api
 from kzg_rs_amd.api import KzgSettings
@@ -377,3 +378,69 @@ def test_launch_group_of_65536_blobs_with_poisoned_batches():
     hb.finish_launch(None, 1)
     got = hb.finish_wait()
     assert [None if e else r for r, e in zip(got, hb.bad)] == want
+
+
+def test_three_launch_groups_in_flight_with_poisoned_batches_through_the_pipeline_entry():
+    """The entry point behind the headline at (a quarter of) its shape: kzg_verify_blob_kzg_proof_batch_groups_device with
+    3 launch groups of 64 batches x 1 024 blobs (3 x 8 GiB) and in_flight = 3 - the in-library pipeline with every lane
+    carrying a group, the throughput-form challenge kernel, merged-chunk MSM blocks and the one-wave pairing program.
+    Every batch is a different permutation of 1 024 valid tuples; poisoned in DIFFERENT groups (= lanes):
+        group 0, batch 11: a valid G1 point that is not its blob's proof   -> false   (src/kzg_proof.rs:436-444)
+        group 1, batch 29: a field element equal to r                      -> Err     (src/dtypes.rs:48-57)
+        group 2, batch 47: a commitment on the curve but outside G1        -> Err     (src/kzg_proof.rs:17-25)
+        group 2, batch 63: a wrong proof in the very last batch            -> false
+    all other 188 batches -> true; then the same three groups as SEVEN (pointers repeat: lanes are reused while groups are in
+    flight) with in_flight 2 and 4.  8 (z, y) records read back from the lanes - first / last blob of a group, a neighbour
+    of each poisoned blob - equal the oracle's compute_challenge / evaluate_polynomial_in_evaluation_form."""
+    import ctypes as C
+    import torch
+    from kzg_rs_amd import synth
+    n, B, K = 1024, 64, 3
+    blobs, cs, ps, st = synth.make_valid_batch(n, seed=2024, chunk=1024)
+    ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])
+    off = G.off_subgroup_g1()
+    with pytest.raises(O.OracleError):
+        O.g1_decompress(off)
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    base_b = torch.from_numpy(blobs).cuda()
+    base_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).cuda().view(n, 48)
+    base_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).cuda().view(n, 48)
+    orders, groups = [], []
+    for g in range(K):
+        order = torch.cat([torch.randperm(n, generator=gen) for _ in range(B)])
+        idx = order.cuda()
+        groups.append([base_b[idx].contiguous(), base_c[idx].contiguous(), base_p[idx].contiguous()])
+        orders.append(order)
+    r_t = torch.tensor(list(R.to_bytes(32, "big")), dtype=torch.uint8, device="cuda")
+    groups[0][2][11 * n + 500] = groups[0][2][11 * n + 501].clone()
+    groups[1][0][29 * n + 1023, 4064:4096] = r_t
+    groups[2][1][47 * n] = torch.tensor(list(off), dtype=torch.uint8, device="cuda")
+    groups[2][2][63 * n + 1023] = groups[2][2][63 * n + 1022].clone()
+    torch.cuda.synchronize()
+    want = [[True] * B for _ in range(K)]
+    want[0][11], want[1][29], want[2][47], want[2][63] = False, None, None, False
+    ptrs = [tuple(t.data_ptr() for t in g) for g in groups]
+    assert api.verify_blob_kzg_proof_batch_groups_device(ptrs, n, B, st, in_flight=3) == want
+    # (z, y) as the pipeline's lanes computed them: group g ran on lane g
+    L = api.lib()
+    L.kzg_debug_lane_records.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    sample = [(0, 0), (0, 11 * n + 499), (0, 11 * n + 500), (1, 29 * n + 1022), (1, n * B - 1), (2, 47 * n + 1), (2, 63 * n + 1023), (2, 40000)]
+    for g, i in sample:
+        rec = C.create_string_buffer(160)
+        api._chk(L.kzg_debug_lane_records(rec, g, i, 1, st._h))
+        j = int(orders[g][i])
+        cbytes = bytes(groups[g][1][i].cpu().numpy().tobytes())
+        pbytes = bytes(groups[g][2][i].cpu().numpy().tobytes())
+        z = O.compute_challenge(blobs[j].tobytes(), cbytes)
+        y = O.evaluate_polynomial_in_evaluation_form(blobs[j].tobytes(), z, ost)
+        assert rec.raw == cbytes + z[::-1] + y[::-1] + pbytes, (g, i)
+    # the oracle on two of the poisoned batches (1 024 blobs each, 8 threads)
+    for g, b in ((0, 11), (2, 63)):
+        o = orders[g][b * n:(b + 1) * n].tolist()
+        hc = groups[g][1][b * n:(b + 1) * n].cpu().numpy()
+        hp = groups[g][2][b * n:(b + 1) * n].cpu().numpy()
+        assert O.verify_blob_kzg_proof_batch([blobs[j].tobytes() for j in o], [hc[k].tobytes() for k in range(n)], [hp[k].tobytes() for k in range(n)], ost, nthreads=8) is False
+    # lanes reused while groups are in flight, other pipeline depths
+    seven = [0, 1, 2, 2, 0, 1, 0]
+    for in_flight in (2, 4):
+        assert api.verify_blob_kzg_proof_batch_groups_device([ptrs[g] for g in seven], n, B, st, in_flight=in_flight) == [want[g] for g in seven]

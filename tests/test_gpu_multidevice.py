@@ -285,7 +285,7 @@ def test_interleaved_chunks_and_the_streamed_transcript_hash(env):
     want_r_bad = _expected_r(O, ost, bl, cs, bad)
     L = api.lib()
     ok = C.c_bool(False)
-    for chunk, chunks_per_dev, pieces in ((5, 8, 24), (7, 8, 17), (1, 64, 63), (40, 8, 3), (118, 8, 1)):
+    for chunk, chunks_per_dev, pieces in ((5, 8, 24), (7, 8, 17), (1, 64, 59), (40, 8, 3), (118, 8, 1)):
         with api.options(multi_min_blobs=2, multi_min_chunk=chunk, multi_chunks=chunks_per_dev):
             st3 = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1], devices=[0, 0, 0])
         api._chk(L.kzg_verify_blob_kzg_proof_batch(C.byref(ok), blobs.ctypes.data_as(C.c_char_p), hc, hp, n, st3._h))

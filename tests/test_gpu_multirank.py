@@ -178,8 +178,12 @@ def test_bench_script_bare_command_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["multi_gpu"]["ranks"] == 2
     assert d["self_check"]["passed"] is True
-    sp = d["multi_gpu"]["single_process"]
-    assert sp.get("ok") is True and sp["corrupted_proof_on_last_device"] is False and sp["batch"] == 512 and sp["devices"] == [0, 0], sp
+    sp = d["multi_gpu"]["single_process"]["host_exchange"]
+    assert sp["batch"] == 512 and sp["devices"] == [0, 0] and sp["exchange"] == "host", sp
+    assert sp["sharded_batch"]["ok"] is True and sp["sharded_batch"]["corrupted_proof_on_last_device"] is False, sp
+    assert sp["sharded_stream"]["results_as_expected"] is True and sp["sharded_stream"]["in_flight"] == 4, sp
+    assert sp["host_vec_blob"]["ok"] is True
+    assert "skipped" in d["multi_gpu"]["single_process"]["rccl_exchange"]  # (the shared-GPU rig names device 0 twice)
 
 
 def _nccl_worker(port, q):
