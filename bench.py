@@ -52,10 +52,10 @@ ALG_BYTES = {
     "k_msm": 3 * 128,                               # three (point, scalar) terms per blob, 96 + 32 B each
     "k_slp_run(pairing)": 0,
 }
-PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge", "k_blob_evaluate": "kzg::k_blob_evaluate",
+PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge", "k_blob_evaluate": "kzg::k_blob_evaluate_t<true>",
             "k_g1_decode_multiples": "kzg::k_g1_decode_multiples29<4, true>", "k_msm": "kzg::k_msm_window<kzg::Curve29Aff, true>",
             "k_slp_run(pairing)": "kzg::k_slp_run<false>"}
-PMC_FILES = ("r3_pmc.json", "r2_pmc.json")  # newest first; the first that exists is used (kernel names must match PMC_NAME)
+PMC_FILES = ("r4_pmc.json", "r3_pmc.json")  # newest first; the first that exists is used (kernel names must match PMC_NAME)
 PATH_ALG_BYTES = BYTES_PER_BLOB + 48 + 48 + 64   # full verify, per blob: blob + commitment + proof read, z and y written
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
 
@@ -283,7 +283,7 @@ def main():
     ap.add_argument("--config5", action="store_true", help="same as --workload config5")
     ap.add_argument("--blobs", type=int, default=None, help="blobs per GPU per batch (overrides the workload's)")
     ap.add_argument("--group", type=int, default=None, help="independent batches per launch group = per step (overrides the workload's)")
-    ap.add_argument("--inflight", type=int, default=3, help="launch groups kept in flight by the fixed-order software pipeline")
+    ap.add_argument("--inflight", type=int, default=4, help="launch groups kept in flight by the fixed-order software pipeline")
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single_batch / end_to_end legs (profiling runs)")

@@ -431,8 +431,8 @@ def verify_blob_kzg_proof_batches_device(d_blobs, d_commitments, d_proofs, n, n_
     return [None if err.raw[b] else bool(ok[b]) for b in range(n_batches)]
 
 
-def verify_blob_kzg_proof_batch_groups_device(groups, n, batches_per_group, kzg_settings, in_flight=3):
-    """Many launch groups through ONE C call, `in_flight` of them overlapping inside the library: groups = [(d_blobs,
+def verify_blob_kzg_proof_batch_groups_device(groups, n, batches_per_group, kzg_settings, in_flight=0):
+    """Many launch groups through ONE C call, `in_flight` of them (0: the library's default, 4) overlapping inside the library: groups = [(d_blobs,
     d_commitments, d_proofs), ...] device pointers of groups of `batches_per_group` batches of n blobs.  Returns one list per
     group with True / False per batch, or None where the reference would return Err."""
     k, B, vp = len(groups), batches_per_group, C.c_void_p

@@ -42,7 +42,7 @@ static KzgRet evaluate_device_locked(void* d_y, const void* d_blobs, const void*
     Workspace& w = s->ws;
     HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * n, s->s1));
     HIPCHK(hipEventRecord(s->ev[7], s->s1));
-    KzgRet rc = launch_evaluate(s, d_blobs, (const Fr*)d_z, (Fr*)d_y, w.d_status, n);
+    KzgRet rc = launch_evaluate(s, d_blobs, (const Fr*)d_z, (Fr*)d_y, w.d_status, n, /*alone=*/true);
     if (rc != KZG_OK) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[8], s->s1));

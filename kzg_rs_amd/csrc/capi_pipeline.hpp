@@ -23,7 +23,7 @@ static KzgRet groups_pipeline_locked(bool* ok_out, uint8_t* err, const void* con
                                      const void* const* d_proofs, const size_t* idx, size_t K, size_t n, size_t B, size_t in_flight,
                                      const KzgSettings* c) {
     if (K == 0) return KZG_OK;
-    const size_t F = std::max<size_t>(1, std::min<size_t>(in_flight ? in_flight : 3, 8));
+    const size_t F = std::max<size_t>(1, std::min<size_t>(in_flight ? in_flight : 4, 8));
     const size_t d1 = F - 1, d3 = F > 1 ? 1 : 0, S = d1 + d3 + 1;  // S handles: the handle itself + S - 1 lanes
     KzgRet rc = pipeline_lanes(c, S - 1);
     if (rc != KZG_OK) return rc;

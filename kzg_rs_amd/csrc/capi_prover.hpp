@@ -129,7 +129,7 @@ static KzgRet compute_proofs(uint8_t* proofs48, uint8_t* ys32, const uint8_t* bl
             hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s->s1, b.d_cm, b.d_cm, (int)m, b.d_cpts, b.d_cflag, (int)m, 1);
             if ((rc = launch_challenge(s, b.d_blobs, b.d_cm, b.d_z, m)) != KZG_OK) return rc;
         }
-        if ((rc = launch_evaluate(s, b.d_blobs, b.d_z, b.d_y, b.d_status, m)) != KZG_OK) return rc;
+        if ((rc = launch_evaluate(s, b.d_blobs, b.d_z, b.d_y, b.d_status, m, /*alone=*/true)) != KZG_OK) return rc;
         hipLaunchKernelGGL(k_blob_quotient, dim3((unsigned)m), dim3(64), 0, s->s1, b.d_blobs, b.d_z, b.d_y, s->d_M, b.d_sc, b.d_status);
         HIPCHK(hipGetLastError());
         if ((rc = setup_msm(s, b, m)) != KZG_OK) return rc;

@@ -3,7 +3,8 @@
 
 // The evaluation kernel over T blobs on stream s1 (radix-2^29 form; option evaluate_kernel=32 of the A/B build selects the 8x32
 // form, kept for measurement and as a cross-check).
-static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr* d_z, Fr* d_y, uint32_t* d_status, size_t T) {
+// alone: the evaluation is the whole call (kzg_evaluate_polynomials*, BASELINE configs[2]) - nothing else wants the CUs.
+static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr* d_z, Fr* d_y, uint32_t* d_status, size_t T, bool alone = false) {
 #if KZG_AB_VARIANTS
     static const bool use32 = opt_is("evaluate_kernel", "32");
     if (use32) {
@@ -24,14 +25,38 @@ static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const F
     // A launch that leaves CUs free asks for enough (unused) dynamic LDS that no CU takes a second workgroup: the dispatcher
     // otherwise pairs workgroups on half the CUs, two wavefronts per SIMD, and the single batch waits twice as long.
     const unsigned eval_blocks = (unsigned)((T + EVAL_BLOBS_PER_BLOCK - 1) / EVAL_BLOBS_PER_BLOCK);
-    size_t spread_lds = 0;
+    // A LARGE launch inside a verification asks for 16 KB of (unused) dynamic LDS per workgroup: 38.9 + 16 KB caps a CU at two
+    // workgroups = two wavefronts per SIMD, although the kernel's 166 VGPRs would allow three.  Alone on the chip three are
+    // faster (14.5 against 15.3 ms per 262 144 blobs), but beside the other launch groups' kernels three workgroups hold
+    // 117 KB of a CU's 160 KB of LDS and the MSM window blocks (36-46 KB each) queue behind them: 4.74-4.82 M blobs/s with
+    // three, 4.91-4.97 M with two (profiles/r4_ab_evaluate.txt).  Option eval_lds_pad=<bytes> overrides (measurement).
+    static const long pad_opt = opt_int("eval_lds_pad", -1);
+    const size_t lds_pad = pad_opt >= 0 ? (size_t)std::min(120L * 1024, pad_opt) : alone ? 0 : 16384;
+    size_t spread_lds = lds_pad;
+    if (lds_pad) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad) != hipSuccess) {
+            (void)hipGetLastError();
+            spread_lds = 0;
+        }
+    }
     if (eval_blocks <= (unsigned)s->n_cus) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate), hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_SPREAD_LDS) == hipSuccess)
+        bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_SPREAD_LDS) == hipSuccess;
+#if KZG_AB_VARIANTS
+        attr_ok = attr_ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_SPREAD_LDS) == hipSuccess;
+#endif
+        if (attr_ok)
             spread_lds = EVAL_SPREAD_LDS;
         else (void)hipGetLastError();  // the launch below goes without the spreading request; nothing sticky is left for the callers' checks
     }
-    hipLaunchKernelGGL(k_blob_evaluate, dim3(eval_blocks), dim3(64 * EVAL_BLOBS_PER_BLOCK), spread_lds, s->s1,
-                       (const uint8_t*)d_blobs, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, s->d_eval_scratch, d_status, (int)T);
+#if KZG_AB_VARIANTS
+    static const bool eval_r3 = opt_is("evaluate_kernel", "r3");  // round 3's kernel: 192 VGPRs, two wavefronts per SIMD (A/B measurement)
+    if (eval_r3)
+        hipLaunchKernelGGL(k_blob_evaluate_t<false>, dim3(eval_blocks), dim3(64 * EVAL_BLOBS_PER_BLOCK), spread_lds, s->s1,
+                           (const uint8_t*)d_blobs, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, s->d_eval_scratch, d_status, (int)T);
+    else
+#endif
+        hipLaunchKernelGGL(k_blob_evaluate_t<true>, dim3(eval_blocks), dim3(64 * EVAL_BLOBS_PER_BLOCK), spread_lds, s->s1,
+                           (const uint8_t*)d_blobs, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, s->d_eval_scratch, d_status, (int)T);
     hipLaunchKernelGGL(k_eval_finish, dim3(per_lane), dim3(64), 0, s->s1, s->d_eval_scratch, d_y, (int)T);
     return KZG_OK;
 }

@@ -32,6 +32,9 @@
 
 namespace kzg {
 
+#ifndef KZG_AB_VARIANTS
+#define KZG_AB_VARIANTS 0
+#endif
 constexpr int FE_PER_BLOB = 4096;
 constexpr int BLOB_BYTES = 131072;
 
@@ -427,6 +430,8 @@ __device__ __forceinline__ Fr fr_shfl_xor(const Fr& a, int mask) {
     return r;
 }
 
+#if KZG_AB_VARIANTS  // (the 8x32 form of the evaluation: A/B build only, option evaluate_kernel=32)
+
 // z_in: plain little-endian limbs (any value < 2^256; reduced mod r here, like scalar_from_bytes_unchecked)
 // y_out: plain little-endian canonical limbs.  status[b] |= 1 when a blob element is >= r
 // (src/kzg_proof.rs:36-41 -> KzgError::BadArgs).
@@ -507,6 +512,8 @@ __global__ __launch_bounds__(64, 4) void k_blob_evaluate32(const uint8_t* __rest
     }
 }
 
+#endif  // KZG_AB_VARIANTS
+
 // ---------------------------------------------------------------- evaluation in radix 2^29 (fr29.hpp)
 // The same tree as k_blob_evaluate32 with every field element in 9 x 29-bit limbs: products accumulate a whole
 // column in one 64-bit register without carry instructions, additions are limb-wise and nothing is reduced inside
@@ -581,6 +588,23 @@ __device__ __forceinline__ Fr29 eval_table_load(const EvalTables& t, int slot, i
     return r;
 }
 
+// The same entry through buffer descriptors (wave-uniform 128-bit resources in SGPRs): the per-lane part of the address is ONE
+// 32-bit register that never changes (lane * 16, lane * 4), the slot travels in the scalar offset - no 64-bit address
+// pairs in VGPRs and no vector address arithmetic in the loop.
+struct EvalRsrc {
+    __amdgpu_buffer_rsrc_t a, b, c;
+};
+__device__ __forceinline__ Fr29 eval_table_load(const EvalRsrc& t, int slot, uint32_t lane16, uint32_t lane4) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(t.a, lane16, slot * 1024, 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(t.b, lane16, slot * 1024, 0);
+    Fr29 r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = __builtin_amdgcn_raw_buffer_load_b32(t.c, lane4, slot * 256, 0);
+    return r;
+}
+
 // Evaluation = k_eval_powers -> k_blob_evaluate -> k_eval_finish.  The serial parts of a blob's evaluation (13 squarings
 // of z before the tree, 4 products after it) would run on one lane of the blob's wavefront at the price of 64: they are
 // taken out into one-lane-per-blob kernels, with 576 bytes of scratch per blob in between:
@@ -623,7 +647,11 @@ __global__ __launch_bounds__(64) void k_eval_finish(const uint32_t* __restrict__
 // wait counters turn the prefetches into stalls - three waves per SIMD were 2 % slower than two with working prefetches.
 constexpr int EVAL_BLOBS_PER_BLOCK = 4;
 constexpr int EVAL_SPREAD_LDS = 96 * 1024;  // dynamic LDS nobody touches: with it a CU holds ONE workgroup (launch_evaluate)
-__global__ __launch_bounds__(256, 2) void k_blob_evaluate(const uint8_t* __restrict__ blobs, const EvalTables tab,
+// SPLIT = true (round 4, the product's form): three wavefronts per SIMD - 166 VGPRs, no scratch - by (i) buffer descriptors
+// instead of 64-bit address pairs, (ii) a line that is live once instead of twice (see the loop).  SPLIT = false is round 3's
+// kernel (192 VGPRs, two wavefronts per SIMD), kept in the A/B build (option evaluate_kernel=r3) for measurement.
+template <bool SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 3 : 2) void k_blob_evaluate_t(const uint8_t* __restrict__ blobs, const EvalTables tab,
                                                        uint32_t* __restrict__ scratch, uint32_t* __restrict__ status, int T) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int blob_idx = blockIdx.x * EVAL_BLOBS_PER_BLOCK + wave;
@@ -635,7 +663,10 @@ __global__ __launch_bounds__(256, 2) void k_blob_evaluate(const uint8_t* __restr
     uint4 (*stack_a)[64] = stack_as[wave], (*stack_b)[64] = stack_bs[wave];
     uint32_t (*stack_c)[64] = stack_cs[wave];
     if (!active) return;  // no workgroup barrier below: a wavefront only ever touches its own part of the LDS
-    uint32_t* const my = scratch + (size_t)blob_idx * EVAL_SCRATCH_WORDS;
+    // (the wavefront's blob index is uniform, but derived from threadIdx: readfirstlane makes that provable - the blob's
+    // addresses then live in scalar registers, and a buffer operation is not wrapped in a waterfall loop)
+    const int blob_u = SPLIT ? __builtin_amdgcn_readfirstlane(blob_idx) : blob_idx;
+    uint32_t* const my = scratch + (size_t)blob_u * EVAL_SCRATCH_WORDS;
     for (int i = lane; i < 14 * 9; i += 64) reinterpret_cast<uint32_t*>(Z)[i] = my[i];
     const uint4* src = reinterpret_cast<const uint4*>(blobs + (size_t)blob_idx * BLOB_BYTES) + (size_t)lane * 128;
     const Fr29 zd = Z[13];
@@ -649,6 +680,82 @@ __global__ __launch_bounds__(256, 2) void k_blob_evaluate(const uint8_t* __restr
     // the root entry of the next merge are requested one product ahead of their use (three waves per SIMD do not hide an
     // L2 / HBM round trip by themselves).
     uint4 cur[8];
+    if constexpr (SPLIT) {
+    const __amdgpu_buffer_rsrc_t rs_blob = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(blobs) + (size_t)blob_u * BLOB_BYTES, 0, BLOB_BYTES, 0x00020000);
+    EvalRsrc rs;
+    rs.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(tab.a), 0, EVAL_SLOTS * 64 * 16, 0x00020000);
+    rs.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(tab.b), 0, EVAL_SLOTS * 64 * 16, 0x00020000);
+    rs.c = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(tab.c), 0, EVAL_SLOTS * 64 * 4, 0x00020000);
+    const uint32_t lane2k = (uint32_t)lane * 2048u, lane16 = (uint32_t)lane * 16u, lane4 = (uint32_t)lane * 4u;
+    auto blob_load = [&](int byte_off) {  // 16 bytes of this lane's 2 KiB of the blob; byte_off is uniform (scalar offset + immediate)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_blob, lane2k, byte_off, 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
+#pragma unroll
+    for (int i = 0; i < 8; i++) cur[i] = blob_load(16 * i);
+    Fr29 leaf0 = eval_table_load(rs, 0, lane16, lane4), leaf1 = eval_table_load(rs, 1, lane16, lane4);
+    // Register diet for three wavefronts per SIMD (168 VGPRs): a pair's two elements are CONVERTED (byte swap, canonical check,
+    // radix 2^29, sum and difference: 18 registers) before anything else of the iteration, which frees the 16 registers of
+    // its half line - and the next line's half is requested into exactly those.  The line registers are then live once
+    // (32) instead of twice (64), and the table entries are requested one product ahead of their use instead of a whole
+    // iteration ahead.  Memory operations keep their order (sched_barrier 0x7: only ALU instructions may cross).
+    struct PairOps {
+        Fr29 s, u;
+    };
+    auto convert = [&](const uint4& a_hi, const uint4& a_lo, const uint4& b_hi, const uint4& b_lo) {
+        Fr wa = fr_from_be_words(a_hi, a_lo), wb = fr_from_be_words(b_hi, b_lo);
+        if (__any((wa.l[7] >= consts::FR_MOD[7]) | (wb.l[7] >= consts::FR_MOD[7]))) bad |= FrF::geq_mod(wa) | FrF::geq_mod(wb);
+        const Fr29 pa = fr29_from_words(wa.l), pb = fr29_from_words(wb.l);
+        PairOps o;
+        o.s = fr29_add(pa, pb);
+        o.u = fr29_sub_biased4(pa, pb);
+        psum = fr29_add(psum, o.s);
+        return o;
+    };
+    for (int j = 0; j < 16; j++) {  // pairs q = 2j, 2j + 1
+        const int jn = j < 15 ? j + 1 : 15;
+        const PairOps p0 = convert(cur[0], cur[1], cur[2], cur[3]);
+        __builtin_amdgcn_sched_barrier(0x7);
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[i] = blob_load(128 * jn + 16 * i);
+        __builtin_amdgcn_sched_barrier(0x7);
+        const Fr29 n0 = fr29_mul2(p0.s, zd, p0.u, leaf0);  // z s + roots[2k] u, k = 32 lane + q: ONE reduction (fr29.hpp)
+        const PairOps p1 = convert(cur[4], cur[5], cur[6], cur[7]);
+        __builtin_amdgcn_sched_barrier(0x7);
+#pragma unroll
+        for (int i = 4; i < 8; i++) cur[i] = blob_load(128 * jn + 16 * i);
+        Fr29 root = eval_table_load(rs, 32 + j, lane16, lane4);  // the level-1 merge of the two pairs
+        __builtin_amdgcn_sched_barrier(0x7);
+        const Fr29 n1 = fr29_mul2(p1.s, zd, p1.u, leaf1);
+        psum = fr29_normalize(psum);  // limbs: 2^29 + 2 * 2^30 < 2^32 between normalisations
+        __builtin_amdgcn_sched_barrier(0x7);
+        leaf0 = eval_table_load(rs, 2 * jn, lane16, lane4);
+        leaf1 = eval_table_load(rs, 2 * jn + 1, lane16, lane4);
+        Fr29 root_next = eval_table_load(rs, 48 + (j >> 1), lane16, lane4);  // the level-2 merge that follows when j is odd
+        __builtin_amdgcn_sched_barrier(0x7);
+        n = fr29_mul2(fr29_add(n0, n1), Z[1], fr29_sub_biased4(n0, n1), root);
+        root = root_next;
+        int level = 2;  // level of the merge that may follow: node index at level L is (32 lane + 2j + 1) >> L
+        for (int jj = j; jj & 1; jj >>= 1) {
+            Fr29 na;
+            const uint4 h0 = stack_a[level - 2][lane], h1 = stack_b[level - 2][lane];
+            na.l[0] = h0.x; na.l[1] = h0.y; na.l[2] = h0.z; na.l[3] = h0.w;
+            na.l[4] = h1.x; na.l[5] = h1.y; na.l[6] = h1.z; na.l[7] = h1.w;
+            na.l[8] = stack_c[level - 2][lane];
+            root_next = eval_table_load(rs, 64 - (32 >> level) + (j >> level), lane16, lane4);  // for the merge one level up, if it follows (always a valid slot)
+            const Fr29 sum = fr29_add(na, n), dif = fr29_sub_biased4(na, n);
+            n = fr29_mul2(sum, Z[level], dif, root);
+            root = root_next;
+            level++;
+        }
+        if (j != 15) {  // level <= 5 here
+            stack_a[level - 2][lane] = make_uint4(n.l[0], n.l[1], n.l[2], n.l[3]);
+            stack_b[level - 2][lane] = make_uint4(n.l[4], n.l[5], n.l[6], n.l[7]);
+            stack_c[level - 2][lane] = n.l[8];
+        }
+    }
+    } else {
 #pragma unroll
     for (int i = 0; i < 8; i++) cur[i] = src[i];
     Fr29 leaf0 = eval_table_load(tab, 0, lane), leaf1 = eval_table_load(tab, 1, lane);
@@ -701,6 +808,7 @@ __global__ __launch_bounds__(256, 2) void k_blob_evaluate(const uint8_t* __restr
         leaf0 = leaf0_next;
         leaf1 = leaf1_next;
     }
+    }
     // n = N0_{6,lane}; fold across lanes
     for (int L = 6; L < 12; L++) {
         int sh = L - 6;
@@ -733,7 +841,7 @@ __global__ __launch_bounds__(256, 2) void k_blob_evaluate(const uint8_t* __restr
         my[14 * 9 + lane] = vn;
         my[15 * 9 + lane] = vs;
     }
-    if (lane == 0 && any_bad) atomicOr(&status[blob_idx], 1u);
+    if (lane == 0 && any_bad) atomicOr(&status[blob_u], 1u);
 }
 
 // ---------------------------------------------------------------- quotient polynomial (prover side)
