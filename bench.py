@@ -499,6 +499,7 @@ def main():
     self_check = None
     proof_ms = None
     solo_sums, solo_cnt = [0.0] * 8, 0
+    sc_sums, sc_cnt = [0.0] * 8, 0
     if not args.no_self_check:
         with api.options(single_stream=1):   # read when a handle is made
             solo = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1])
@@ -563,6 +564,10 @@ def main():
                       "passed": res == want}
         # the clean groups again: nothing of the poisoned call may linger on the lanes
         run_groups(n_handles)
+        for h in handles:  # (the control and the clean groups after it are launches of this process too: see launch_ms_all_launches)
+            t, c = h.timing_totals(reset=True)
+            sc_sums = [a + b for a, b in zip(sc_sums, t)]
+            sc_cnt += c
         if world == 1:
             # one proof at a time (src/kzg_proof.rs:353-397, the revm precompile's call): median of 32 calls
             pc, pz, py, pp, _ = synth.make_valid_proofs(1, seed=5, settings=settings)
@@ -669,10 +674,10 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": ALG_BYTES[dom] * units,
                      "launch_ms_incl_warmup": round((sums[5] + warm_sum5) / max(cnt + warm_cnt, 1), 4) if stamped else None,
-                     # every launch of this kernel at this size in the process: warm-up + timed groups in flight, and the stand-alone /
-                     # self-check groups - the population behind the kernel's AverageNs in a rocprofv3 --stats of this command
-                     "launch_ms_all_launches": round((sums[5] + warm_sum5 + solo_sums[5]) / max(cnt + warm_cnt + solo_cnt, 1), 4) if stamped else None,
-                     "launches": cnt + warm_cnt + solo_cnt if stamped else None,
+                     # every launch of this kernel at this size in the process: warm-up + timed groups in flight, the stand-alone groups and
+                     # the groups of the self check - the population behind the kernel's AverageNs in a rocprofv3 --stats of this command
+                     "launch_ms_all_launches": round((sums[5] + warm_sum5 + solo_sums[5] + sc_sums[5]) / max(cnt + warm_cnt + solo_cnt + sc_cnt, 1), 4) if stamped else None,
+                     "launches": cnt + warm_cnt + solo_cnt + sc_cnt if stamped else None,
                      "launch_ms_source": ("live: the kernel's own execution interval, stamped inside the kernel with s_memrealtime (first wavefront in, last "
                                           "wavefront out) and averaged over the %d launch groups of the timed region, %d groups in flight (residency, not cost); "
                                           "launch_ms_incl_warmup averages the %d warm-up groups in as well - the population rocprofv3 --kernel-trace --stats of "
