@@ -156,3 +156,16 @@ extern "C" KzgRet kzg_debug_lane_records(uint8_t* out, size_t lane, size_t first
     memcpy(out, l->ws.h_buf + 160 * first, 160 * count);
     return KZG_OK;
 }
+
+// test hook (no GPU needed): the value KZG_OPTIONS gives `key` right now, as the library's parser reads it; -1 when unset,
+// else the length of the value (copied, truncated, NUL-terminated into out[cap]); *ab_build = 1 in the A/B build
+extern "C" int kzg_debug_option(const char* key, char* out, size_t cap, int* ab_build) {
+    if (ab_build) *ab_build = KZG_AB_VARIANTS;
+    const char* v = key ? opt_str(key) : nullptr;
+    if (!v) return -1;
+    if (out && cap) {
+        strncpy(out, v, cap - 1);
+        out[cap - 1] = 0;
+    }
+    return (int)strlen(v);
+}

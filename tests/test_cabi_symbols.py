@@ -118,3 +118,44 @@ def test_loading_the_library_leaves_the_environment_alone():
             "print(g(b'GPU_MAX_HW_QUEUES'), dict(os.environ) == before)\n" % ([api.LIB_PATH, api.LIB_AB_PATH],))
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "None True"
+
+
+def test_kzg_options_string_is_parsed_as_documented():
+    """KZG_OPTIONS = "key=value;key=value" (';' or blanks between entries; a bare key means 1), read through the library's own
+    parser (csrc/capi_host_util.hpp) - re-read when the string changes, unknown keys harmless; and which of the two libraries
+    is the A/B build."""
+    import ctypes as C
+    from kzg_rs_amd import api, build
+    build.build()
+
+    def get(L, key):
+        buf = C.create_string_buffer(64)
+        n = L.kzg_debug_option(key.encode(), buf, 64, None)
+        return None if n < 0 else buf.value.decode()
+
+    L = C.CDLL(api.LIB_PATH)
+    L.kzg_debug_option.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]
+    keep = os.environ.get("KZG_OPTIONS")
+    try:
+        os.environ["KZG_OPTIONS"] = "challenge_kernel=lane; multi_min_blobs=2\tsingle_stream host_slices=16;;x=a=b"
+        assert get(L, "challenge_kernel") == "lane" and get(L, "multi_min_blobs") == "2" and get(L, "single_stream") == "1"
+        assert get(L, "host_slices") == "16" and get(L, "x") == "a=b" and get(L, "pairing") is None
+        os.environ["KZG_OPTIONS"] = "pairing=2"  # the string has changed: parsed again
+        assert get(L, "pairing") == "2" and get(L, "challenge_kernel") is None
+        with api.options(msm_cpb=4):
+            assert get(L, "msm_cpb") == "4" and get(L, "pairing") == "2"
+        assert get(L, "msm_cpb") is None
+        os.environ.pop("KZG_OPTIONS")
+        assert get(L, "pairing") is None
+    finally:
+        if keep is None:
+            os.environ.pop("KZG_OPTIONS", None)
+        else:
+            os.environ["KZG_OPTIONS"] = keep
+    ab = C.c_int(-1)
+    L.kzg_debug_option(b"x", None, 0, C.byref(ab))
+    assert ab.value == 0
+    LA = C.CDLL(api.LIB_AB_PATH)
+    LA.kzg_debug_option.argtypes = L.kzg_debug_option.argtypes
+    LA.kzg_debug_option(b"x", None, 0, C.byref(ab))
+    assert ab.value == 1

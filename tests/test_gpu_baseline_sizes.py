@@ -444,3 +444,78 @@ def test_three_launch_groups_in_flight_with_poisoned_batches_through_the_pipelin
     seven = [0, 1, 2, 2, 0, 1, 0]
     for in_flight in (2, 4):
         assert api.verify_blob_kzg_proof_batch_groups_device([ptrs[g] for g in seven], n, B, st, in_flight=in_flight) == [want[g] for g in seven]
+
+
+def test_host_batch_of_8192_blobs_dealt_over_two_logical_devices_with_default_chunking():
+    """The reference's call shape on a multi-device handle at a size where the DEFAULT dealing applies (no test options):
+    one host Vec<Blob> of 8 192 blobs (1 GiB) over a handle on [0, 0] -> 16 interleaved chunks of 512 blobs, 8 lanes per
+    logical device, every chunk crossing in slices behind its SHA-256 segments, the transcript hashed by the streaming
+    context as the chunks' records come back: r equal to the oracle's compute_r over all 8 192 records (the oracle computes
+    every z and y itself), valid -> True, one wrong proof in the last chunk -> False with the oracle's r for THAT transcript,
+    one non-canonical element in chunk 9 -> Err."""
+    import ctypes as C
+    from kzg_rs_amd import synth
+    n = 8192
+    blobs, cs, ps, st1 = synth.make_valid_batch(n, seed=8192, chunk=1024)
+    ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])
+    st2 = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1], devices=[0, 0])
+    L = api.lib()
+    L.kzg_debug_multi_last_r.argtypes = [C.c_char_p, C.c_void_p]
+    ok = C.c_bool(False)
+    hc, hp = b"".join(cs), b"".join(ps)
+    api._chk(L.kzg_verify_blob_kzg_proof_batch(C.byref(ok), blobs.ctypes.data_as(C.c_char_p), hc, hp, n, st2._h))
+    assert ok.value is True
+    t = st2.multi_last_timings()
+    assert int(t[7]) == 16, t
+    got_r = C.create_string_buffer(32)
+    api._chk(L.kzg_debug_multi_last_r(got_r, st2._h))
+    zs = [O.compute_challenge(blobs[i].tobytes(), cs[i]) for i in range(n)]
+    ys = [O.evaluate_polynomial_in_evaluation_form(blobs[i].tobytes(), zs[i], ost) for i in range(n)]
+    assert got_r.raw == O.compute_r(hc, b"".join(zs), b"".join(ys), hp, n)
+    bad = list(ps)
+    bad[n - 3] = ps[n - 4]
+    hb = b"".join(bad)
+    api._chk(L.kzg_verify_blob_kzg_proof_batch(C.byref(ok), blobs.ctypes.data_as(C.c_char_p), hc, hb, n, st2._h))
+    assert ok.value is False
+    api._chk(L.kzg_debug_multi_last_r(got_r, st2._h))
+    assert got_r.raw == O.compute_r(hc, b"".join(zs), b"".join(ys), hb, n)
+    bb = blobs.copy()
+    bb[9 * 512 + 77, 32 * 4000: 32 * 4001] = list(R.to_bytes(32, "big"))
+    assert L.kzg_verify_blob_kzg_proof_batch(C.byref(ok), bb.ctypes.data_as(C.c_char_p), hc, hp, n, st2._h) == api.KZG_BADARGS
+    # the single-device handle agrees on the corrupted batch
+    api._chk(L.kzg_verify_blob_kzg_proof_batch(C.byref(ok), blobs.ctypes.data_as(C.c_char_p), hc, hb, n, st1._h))
+    assert ok.value is False
+    st2.close()
+
+
+def test_stream_of_sharded_batches_with_throughput_sized_shards():
+    """kzg_verify_blob_kzg_proof_batch_sharded_stream with shards above the latency layouts' range: 5 batches of 2 x 5 000
+    resident blobs on a handle over [0, 0] (throughput-form MSM tables, affine mixed additions, merged chunks off: one batch per
+    launch), 3 in flight on private lane sets, each with its own 10 000-record transcript: valid / wrong proof in the second
+    shard / valid / non-canonical element in the first shard / valid; the wrong-proof batch also through the oracle."""
+    import torch
+    from kzg_rs_amd import synth
+    n = 5000
+    blobs, cs, ps, st1 = synth.make_valid_batch(2 * n, seed=5000, chunk=1000)
+    ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])
+    st2 = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1], devices=[0, 0])
+    d_b = torch.from_numpy(blobs).cuda()
+    d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).cuda()
+    wrong = list(ps)
+    wrong[n + 4321] = ps[n + 4320]
+    d_p, d_pw = (torch.frombuffer(bytearray(b"".join(x)), dtype=torch.uint8).cuda() for x in (ps, wrong))
+    bb = blobs.copy()
+    bb[1234, 0:32] = list(R.to_bytes(32, "big"))
+    d_bb = torch.from_numpy(bb).cuda()
+    torch.cuda.synchronize()
+
+    def shards(db, dp):
+        return [(db.data_ptr() + 131072 * lo, d_c.data_ptr() + 48 * lo, dp.data_ptr() + 48 * lo, n) for lo in (0, n)]
+
+    batches = [shards(d_b, d_p), shards(d_b, d_pw), shards(d_b, d_p), shards(d_bb, d_p), shards(d_b, d_p)]
+    want = [True, False, True, None, True]
+    for in_flight in (3, 1):
+        assert api.verify_blob_kzg_proof_batch_sharded_stream(batches, st2, in_flight=in_flight) == want
+    assert O.verify_blob_kzg_proof_batch([blobs[i].tobytes() for i in range(2 * n)], cs, wrong, ost, nthreads=8) is False
+    assert api.KzgProof.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_pw.data_ptr(), 2 * n, st1) is False
+    st2.close()

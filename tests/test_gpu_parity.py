@@ -1157,3 +1157,23 @@ def test_launch_groups_pipelined_inside_the_library():
     # the one-group form on the same handle still works after the lanes exist, and the totals include the lanes' groups
     assert api.verify_blob_kzg_proof_batches_device(groups[1][0], groups[1][1], groups[1][2], n, B, st) == want[1]
     assert st.timing_totals()[1] >= 7 * 5
+
+
+def test_constructor_notes_too_few_hardware_queues():
+    """The library does not set GPU_MAX_HW_QUEUES for its host any more (rounds 1-3: a load-time constructor did).  A settings
+    constructor that runs with fewer than 8 hardware queues succeeds and leaves a note where kzg_last_error() finds it; with 8
+    it leaves none; either way the environment is as the host made it."""
+    import subprocess
+    import sys
+    code = ("import os, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "from kzg_rs_amd import api\n"
+            "before = dict(os.environ)\n"
+            "st = api.KzgSettings.load_trusted_setup_file()\n"
+            "print('NOTE[' + api.lib().kzg_last_error().decode() + ']')\n"
+            "assert dict(os.environ) == before\n" % O.ROOT)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "GPU_MAX_HW_QUEUES is unset or below 8" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="8"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "NOTE[]" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
