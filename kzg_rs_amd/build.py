@@ -39,11 +39,15 @@ def build(force=False, verbose=False, variants=(0, 1)):
     slp_dir = os.path.join(HERE, "slp")
     slp_src = [os.path.join(slp_dir, f) for f in ("trace.py", "schedule.py", "gen_pairing.py")]
     slp_src.append(os.path.join(slp_dir, "schedule2.py"))
-    if force or any(_newer(os.path.join(data, "slp_%s.bin" % nm), slp_src) for nm in ("verify", "prep", "verify2")):
+    if force or any(_newer(os.path.join(data, "slp_%s.bin" % nm), slp_src) for nm in ("verify", "prep", "verify2", "scalars", "verify3")):
         subprocess.check_call([sys.executable, "-m", "kzg_rs_amd.slp.gen_pairing"], cwd=ROOT)
+    fb_gen = os.path.join(ROOT, "tools", "gen_fixed_base.py")
+    if force or _newer(os.path.join(data, "fixed_base.bin"), [fb_gen, os.path.join(ROOT, "tools", "bls_params.py")]):
+        subprocess.check_call([sys.executable, fb_gen])
     # 2. the libraries (the two device passes side by side: each is one hipcc process)
     deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(data, "slp_prep.bin"),
                                                                os.path.join(data, "slp_verify.bin"), os.path.join(data, "slp_verify2.bin"),
+                                                               os.path.join(data, "slp_scalars.bin"), os.path.join(data, "slp_verify3.bin"), os.path.join(data, "fixed_base.bin"),
                                                                os.path.join(ROOT, "include", "kzg_rs_amd.h")]
     todo = [v for v in variants if force or _newer(LIB_AB if v else LIB, deps)]
     if len(todo) > 1:

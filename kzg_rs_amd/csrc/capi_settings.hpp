@@ -69,6 +69,8 @@ struct KzgSettings {
     uint8_t g1_first[2][48] = {};     // g1_points[0], [1] of the FILE order, for the monomial-form check (build.rs:107-129)
     DevProgram prep, verify;
     DevProgram2 verify2;            // VERIFY scheduled for one check at a time (kzg_rs_amd/slp/schedule2.py)
+    DevProgram2 scalars, verify3;   // the one-proof path (proof_kernels.hpp): [y]G, the lines of [tau]G2 - [z]G2 | the pairing behind them
+    Fp* d_fixed_base = nullptr;     // fixed-base tables of the two generators (tools/gen_fixed_base.py), 3.4 MB
     uint32_t* d_prep29 = nullptr;   // d_prep in the latency program's format (radix 2^29, 16 words per element)
     // s1 / s2: the two streams the current launch uses (challenge chain | point decode).  They point at the plain pair,
     // or - for a small launch (a single batch) - at a pair confined to disjoint halves of the CUs: the 16 two-wave
@@ -82,6 +84,8 @@ struct KzgSettings {
     int n_cus = 0;
     hipEvent_t ev[12] = {};
     mutable hipStream_t s_copy = nullptr;  // host -> device staging copies of the host-fed stream (made on first use)
+    mutable hipStream_t s_aux = nullptr;   // the one-proof path's third stream: the subgroup test beside the pairing (made on first use)
+    mutable Fp* d_proof = nullptr;         // ... and its device buffers: SCALARS' inputs | VERIFY3's inputs (made on first use)
     mutable hipEvent_t ev_copy[2] = {nullptr, nullptr};
     mutable hipEvent_t ev_slice[17] = {};  // a host Vec<Blob> arriving in slices: [0] commitments + proofs landed, [1 + j] slice j landed
     mutable std::mutex mu;
@@ -133,7 +137,7 @@ static KzgRet upload_program2(DevProgram2& dp, const unsigned char* begin, const
     HIPCHK(hipMalloc(&dp.blob, len));
     HIPCHK(hipMemcpy(dp.blob, begin, len, hipMemcpyHostToDevice));
     Slp2Program& p = dp.p;
-    p.lanes = w[1]; p.n_slots = w[2]; p.n_steps = w[3]; p.n_const = w[4]; p.n_in = w[5]; p.n_set = w[6]; p.n_out = w[7]; p.n_load_steps = w[8];
+    p.lanes = w[1]; p.n_slots = w[2]; p.n_steps = w[3]; p.n_const = w[4]; p.n_in = w[5]; p.n_set = w[6]; p.n_out = w[7]; p.n_load_steps = w[8]; p.out_values = w[9];
     if (p.n_load_steps >= p.n_steps) return fail(KZG_ERROR, "embedded latency program has no compute steps");
     const uint32_t* d = reinterpret_cast<const uint32_t*>(dp.blob);
     size_t off = 16;
@@ -234,6 +238,7 @@ static KzgRet settings_lane(KzgSettings** out, const KzgSettings* parent) {
     l->d_tau4 = parent->d_tau4; l->d_prep = parent->d_prep; l->d_prep29 = parent->d_prep29;
     l->d_gen_mult = parent->d_gen_mult; l->d_gen_mult_aff = parent->d_gen_mult_aff;
     l->prep = parent->prep; l->verify = parent->verify; l->verify2 = parent->verify2;
+    l->scalars = parent->scalars; l->verify3 = parent->verify3; l->d_fixed_base = parent->d_fixed_base;
     memcpy(l->tau_g2_bytes, parent->tau_g2_bytes, 96);
     KzgRet rc = settings_streams(l, /*single_stream=*/!parent->s_plain[1]);
     if (rc != KZG_OK) {
@@ -264,6 +269,11 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
     if ((rc = upload_program(s->prep, kzg_slp_prep_begin, kzg_slp_prep_end)) != KZG_OK) return rc;
     if ((rc = upload_program(s->verify, kzg_slp_verify_begin, kzg_slp_verify_end)) != KZG_OK) return rc;
     if ((rc = upload_program2(s->verify2, kzg_slp_verify2_begin, kzg_slp_verify2_end)) != KZG_OK) return rc;
+    if ((rc = upload_program2(s->scalars, kzg_slp_scalars_begin, kzg_slp_scalars_end)) != KZG_OK) return rc;
+    if ((rc = upload_program2(s->verify3, kzg_slp_verify3_begin, kzg_slp_verify3_end)) != KZG_OK) return rc;
+    if ((size_t)(kzg_fixed_base_end - kzg_fixed_base_begin) != FB_TABLE_BYTES) return fail(KZG_ERROR, "embedded fixed-base table has the wrong size");
+    HIPCHK(hipMalloc(&s->d_fixed_base, FB_TABLE_BYTES));
+    HIPCHK(hipMemcpy(s->d_fixed_base, kzg_fixed_base_begin, FB_TABLE_BYTES, hipMemcpyHostToDevice));
     // decompress [tau]G2 on the device, then prepare the lines of [tau]G2 and of the generator
     DevTmp t_bytes, t_flag, t_q;  // released on every path out of this function
     HIPCHK(hipMalloc(&t_bytes.p, 96));
@@ -318,6 +328,9 @@ static KzgRet settings_build(KzgSettings* s, const uint8_t tau_g2[96]) {
     if (s->verify.p.n_set != 2 * s->prep.p.n_out || s->verify.p.n_in != 6 || s->prep.p.n_in != 4 || s->verify2.p.n_set != s->verify.p.n_set ||
         s->verify2.p.n_in != 6 || s->verify2.p.n_out != s->verify.p.n_out)
         return fail(KZG_ERROR, "embedded SLP programs do not fit together");
+    if (s->scalars.p.n_in != (uint32_t)SCALARS_INPUTS || s->scalars.p.n_set != 0 || !s->scalars.p.out_values || s->scalars.p.n_out + 6 != (uint32_t)VERIFY3_INPUTS ||
+        s->verify3.p.n_in != (uint32_t)VERIFY3_INPUTS || s->verify3.p.n_set != s->verify.p.n_set || s->verify3.p.n_out != (uint32_t)VERIFY3_OUTPUTS || s->verify3.p.out_values)
+        return fail(KZG_ERROR, "embedded one-proof programs do not fit together");
     return KZG_OK;
 }
 
@@ -506,8 +519,9 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     (void)hipSetDevice(s->device);
     ws_free(s->ws);
     if (s->d_eval_scratch) (void)hipFree(s->d_eval_scratch);
+    if (s->d_proof) (void)hipFree(s->d_proof);
     if (!s->borrowed) {  // (a lane reads its parent's tables)
-        void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob, s->verify2.blob, s->d_prep29};
+        void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob, s->verify2.blob, s->d_prep29, s->scalars.blob, s->verify3.blob, s->d_fixed_base};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
@@ -517,7 +531,7 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
         if (e) (void)hipEventDestroy(e);
     for (auto& e : s->ev_slice)
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t st : {s->s_plain[0], s->s_plain[1], s->s_half[0], s->s_half[1], s->s_copy})
+    for (hipStream_t st : {s->s_plain[0], s->s_plain[1], s->s_half[0], s->s_half[1], s->s_copy, s->s_aux})
         if (st) (void)hipStreamDestroy(st);
     delete s;
     if (prev >= 0) (void)hipSetDevice(prev);

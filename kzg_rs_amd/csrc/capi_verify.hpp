@@ -961,11 +961,106 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof(bool* ok, const uint8_t* blob, const
 
 extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitments, const uint8_t* zs, const uint8_t* ys,
                                              const uint8_t* proofs, size_t n, const KzgSettings* s);
+// ONE proof, in the reference's own form (src/kzg_proof.rs:384-396): e(C - [y]G, G2) == e(pi, [tau]G2 - [z]G2).  z and y are
+// known before any point is decoded, so three chains run side by side on three streams (proof_kernels.hpp):
+//   A: k_proof_select -> SCALARS ([y]G, the 68 line triples of Q = [tau]G2 - [z]G2) ......... then VERIFY3 (the pairing)
+//   B: k_proof_decompress: the square roots of C and pi on two lanes of one wavefront -> VERIFY3's point inputs
+//   C: the full decode of both points (subgroup test: 2 x 64 doublings) - only its verdict is awaited, beside the pairing
+// Critical path max(A's SCALARS, B) + VERIFY3 instead of decode -> MSM -> pairing.  *general = true: Q is the identity
+// (z = tau: possible only for who knows the setup's secret) - its lines mean nothing, the caller takes the general path.
+static KzgRet proof_single_locked(bool* ok, bool* general, const uint8_t* commitment, const uint8_t* z_be, const uint8_t* y_be, const uint8_t* proof,
+                                  const KzgSettings* s) {
+    *general = false;
+    KzgRet rc = ws_reserve(s, 1, 1, STAGE_CP);
+    if (rc != KZG_OK) return rc;
+    select_streams(s, 1);
+    Workspace& w = s->ws;
+    if (!s->d_proof) HIPCHK(hipMalloc(&s->d_proof, sizeof(Fp) * (SCALARS_INPUTS + VERIFY3_INPUTS)));
+    const bool one_stream = !s->s_plain[1];  // option single_stream: everything in sequence (profiling)
+    if (!one_stream && !s->s_aux) HIPCHK(hipStreamCreateWithFlags(&s->s_aux, hipStreamNonBlocking));
+    hipStream_t sa = s->s_plain[0], sb = one_stream ? sa : s->s_plain[1], sc = one_stream ? sa : s->s_aux;
+    Fp* const d_scal_in = s->d_proof;
+    Fp* const d_v3in = s->d_proof + SCALARS_INPUTS;
+    // pinned mirror: [z LE | y LE] 64 B, [C | pi] 96 B, status of the decompression 2 words, of the full decode 4 words, VERIFY3's outputs
+    uint8_t* const h = w.h_buf;
+    reverse32(h, z_be);
+    reverse32(h + 32, y_be);
+    memcpy(h + 64, commitment, 48);
+    memcpy(h + 112, proof, 48);
+    uint32_t* const h_pre = reinterpret_cast<uint32_t*>(h + 160);
+    uint32_t* const h_full = reinterpret_cast<uint32_t*>(h + 176);
+    Fp* const h_out = reinterpret_cast<Fp*>(h + 1024);
+    h_pre[0] = h_pre[1] = h_full[0] = h_full[1] = G1_INVALID;
+    HIPCHK(hipEventRecord(s->ev[0], sa));
+    // A: the scalars' chain
+    hipLaunchKernelGGL(k_proof_select, dim3(1), dim3(128), 0, sa, reinterpret_cast<const uint32_t*>(h), s->d_fixed_base, s->d_tau4, d_scal_in);
+    if ((rc = run_program2(s->scalars, d_scal_in, nullptr, d_v3in + 6, 1, sa)) != KZG_OK) return rc;
+    // B: the two square roots
+    hipLaunchKernelGGL(k_proof_decompress, dim3(1), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), sb, h + 64, d_v3in, h_pre);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev[6], sb));
+    // C: the subgroup test (the decode pass of the general path; its tables are not used)
+    {
+        struct RestoreS2 {
+            const KzgSettings* s;
+            hipStream_t keep;
+            ~RestoreS2() { s->s2 = keep; }
+        } restore{s, s->s2};
+        s->s2 = sc;
+        if ((rc = launch_decode(s, h + 64, h + 112, 1, /*behind_sha=*/false)) != KZG_OK) return rc;
+        HIPCHK(hipMemcpyAsync(h_full, w.d_pflag, 8, hipMemcpyDeviceToHost, sc));
+    }
+    // A again: the pairing, once the points are there; its eight outputs go straight into the mirror
+    if (sb != sa) HIPCHK(hipStreamWaitEvent(sa, s->ev[6], 0));
+    HIPCHK(hipEventRecord(s->ev[4], sa));
+    if ((rc = run_program2(s->verify3, d_v3in, s->d_prep29, h_out, 1, sa)) != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[9], sa));
+    HIPCHK(hipStreamSynchronize(sa));
+    if (sc != sa) HIPCHK(hipStreamSynchronize(sc));
+    elapsed(&s->timings[3], s->ev[4], s->ev[9]);
+    elapsed(&s->timings[0], s->ev[0], s->ev[9]);
+    // the reference's order of errors: commitment (:372), then proof (:378); an encoding the decompression accepts can
+    // still fail the subgroup test of the full decode
+    for (int i = 0; i < 2; i++)
+        if (h_pre[i] == G1_INVALID || h_full[i] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    const uint32_t* o = reinterpret_cast<const uint32_t*>(h_out);
+    uint32_t any = 0, zq = 0;
+    for (int i = 0; i < 72; i++) any |= o[i];
+    for (int i = 72; i < 96; i++) zq |= o[i];
+    if (!zq) {
+        *general = true;
+        return KZG_OK;
+    }
+    *ok = any == 0;
+    return KZG_OK;
+}
+
 extern "C" KzgRet kzg_verify_kzg_proof(bool* ok, const uint8_t commitment[48], const uint8_t z[32], const uint8_t y[32],
                                        const uint8_t proof[48], const KzgSettings* s) {
-    // src/kzg_proof.rs:353-397: the same equation as the batch form with the single scalar r^0 = 1:
+    // src/kzg_proof.rs:353-397.  One proof at a time takes the reference's own equation (proof_single_locked); option
+    // proof_path=msm sends it through the batch form with the single scalar r^0 = 1 instead (round 3's path; A/B, cross-check):
     // e(pi, [tau]G2) == e(C - [y]G + [z]pi, G2)  <=>  e(pi, [tau - z]G2) == e(C - [y]G, G2)
+    if (!ok || !s) return fail(KZG_BADARGS, "null argument");
     if (!commitment || !z || !y || !proof) return fail(KZG_BADARGS, "null argument");
+    static const bool msm_path = opt_is("proof_path", "msm");
+    if (!msm_path) {
+        if (be_geq_r(z) || be_geq_r(y)) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");  // (sic) :360-371
+        bool general = false;
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            HIPCHK(hipSetDevice(s->device));
+            const KzgRet rc = proof_single_locked(ok, &general, commitment, z, y, proof, s);
+            if (rc != KZG_OK) {  // nothing of the call stays in flight behind an error
+                const std::string msg = g_err;
+                for (hipStream_t st : {s->s_plain[0], s->s_plain[1], s->s_aux})
+                    if (st) (void)hipStreamSynchronize(st);
+                (void)hipGetLastError();
+                g_err = msg;
+                return rc;
+            }
+        }
+        if (!general) return KZG_OK;
+    }
     return kzg_verify_kzg_proof_batch(ok, commitment, z, y, proof, 1, s);
 }
 

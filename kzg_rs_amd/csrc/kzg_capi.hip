@@ -22,6 +22,7 @@
 #include "msm.hpp"
 #include "slp.hpp"
 #include "slp2.hpp"
+#include "proof_kernels.hpp"
 
 using namespace kzg;
 
@@ -35,10 +36,17 @@ __asm__(".section .rodata\n"
         ".global kzg_slp_verify_end\nkzg_slp_verify_end:\n"
         ".balign 16\n.global kzg_slp_verify2_begin\nkzg_slp_verify2_begin:\n.incbin \"" KZG_DATA_DIR "/slp_verify2.bin\"\n"
         ".global kzg_slp_verify2_end\nkzg_slp_verify2_end:\n"
+        ".balign 16\n.global kzg_slp_scalars_begin\nkzg_slp_scalars_begin:\n.incbin \"" KZG_DATA_DIR "/slp_scalars.bin\"\n"
+        ".global kzg_slp_scalars_end\nkzg_slp_scalars_end:\n"
+        ".balign 16\n.global kzg_slp_verify3_begin\nkzg_slp_verify3_begin:\n.incbin \"" KZG_DATA_DIR "/slp_verify3.bin\"\n"
+        ".global kzg_slp_verify3_end\nkzg_slp_verify3_end:\n"
+        ".balign 16\n.global kzg_fixed_base_begin\nkzg_fixed_base_begin:\n.incbin \"" KZG_DATA_DIR "/fixed_base.bin\"\n"
+        ".global kzg_fixed_base_end\nkzg_fixed_base_end:\n"
         ".text\n");
 #endif
 extern "C" const unsigned char kzg_slp_prep_begin[], kzg_slp_prep_end[], kzg_slp_verify_begin[], kzg_slp_verify_end[], kzg_slp_verify2_begin[],
-    kzg_slp_verify2_end[];
+    kzg_slp_verify2_end[], kzg_slp_scalars_begin[], kzg_slp_scalars_end[], kzg_slp_verify3_begin[], kzg_slp_verify3_end[], kzg_fixed_base_begin[],
+    kzg_fixed_base_end[];
 
 // The library is ONE translation unit (device code and the host ABI share types and inline helpers); its parts, in
 // dependency order:

@@ -34,6 +34,7 @@ struct Slp2Desc {
 };
 struct Slp2Program {
     uint32_t lanes, n_slots, n_steps, n_const, n_in, n_set, n_out, n_load_steps;
+    uint32_t out_values;        // 0: the outputs are written as "is it 0 mod p" flags; 1: as canonical 12x32 Montgomery values
     const uint32_t* consts;     // [n_const][16]
     const uint32_t* out_slots;  // [n_out]
     const Slp2Desc* desc;       // [n_steps][lanes]
@@ -132,7 +133,8 @@ __device__ __forceinline__ void slp2_exec_load(uint32_t* slots, const uint4 d, c
 
 // inputs: [instances][n_in] Fp (12x32 Montgomery, as the MSM leaves them); settings_inputs: [n_set][16] words (radix 2^29,
 // Montgomery 2^406: k_fp_to_fp29mem); outputs: [instances][n_out] Fp, all-zero words where the program's output is
-// 0 mod p and a 1 otherwise (the host only asks "all zero?").
+// 0 mod p and a 1 otherwise (the host only asks "all zero?") - or, for a program with out_values set, the values themselves
+// as canonical 12x32 Montgomery elements: the instance-input format, so that a program feeds the next one (SCALARS -> VERIFY3).
 // Descriptor streaming as in slp.hpp: a group of steps ahead into registers, parked in a per-lane LDS ring at the group
 // boundary, read back one step ahead.  Dynamic LDS = slots | ring.
 // (one workgroup per CU whatever happens - the LDS footprint; a whole SIMD's registers are there for the taking, and the
@@ -180,13 +182,19 @@ __global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(1, 1))) v
         ring[(size_t)4 * LANES + tid] = r4; ring[(size_t)5 * LANES + tid] = r5; ring[(size_t)6 * LANES + tid] = r6; ring[(size_t)7 * LANES + tid] = r7;
     }
 #undef SLP2_DESC_AT
-    if (tid < prog.n_out) {
-        const bool z = slp2_is_zero(slp2_load(slots2, prog.out_slots[tid]));
+    for (uint32_t oi = tid; oi < prog.n_out; oi += LANES) {
+        const Fp29 v = slp2_load(slots2, prog.out_slots[oi]);
         Fp o;
+        if (prog.out_values) {
+            fp29_to_words(o.l, fp29_mul(v, fp29_const(cp29::FP29_TO_STD)));  // x 2^384 mod p as a plain integer, below 2p
+            o = FpF::reduce_once(o);
+        } else {
+            const bool z = slp2_is_zero(v);
 #pragma unroll
-        for (int i = 0; i < 12; i++) o.l[i] = 0u;
-        o.l[0] = z ? 0u : 1u;
-        outputs[(size_t)inst * prog.n_out + tid] = o;
+            for (int i = 0; i < 12; i++) o.l[i] = 0u;
+            o.l[0] = z ? 0u : 1u;
+        }
+        outputs[(size_t)inst * prog.n_out + oi] = o;
     }
 }
 

@@ -17,7 +17,11 @@ the depth:
 
 Binary format (little-endian u32 words):
   [0] magic 0x32504c53 ("SLP2")  [1] lanes  [2] n_slots  [3] n_steps  [4] n_const  [5] n_inputs
-  [6] n_settings_inputs  [7] n_outputs  [8] n_load_steps (the LOAD steps are the first steps of the program)  [9..15] reserved
+  [6] n_settings_inputs  [7] n_outputs  [8] n_load_steps (the LOAD steps are the first steps of the program)
+  [9] output mode: 0 = the kernel writes, per output, "is it 0 mod p" (all-zero words / a 1) - what a check needs;
+                   1 = it writes the VALUES as canonical 12x32 Montgomery elements - the instance-input format, so that one
+                       program's outputs are the next one's inputs (SCALARS -> VERIFY3)
+  [10..15] reserved
   const pool : n_const * 16 words  (14 limbs of 29 bits + 2 zero words: field constants in Montgomery form, radix
                2^406, or raw limb patterns - the subtraction biases)
   out slots  : n_outputs words, zero-padded to a multiple of 4 (the descriptors are read as 16-byte vectors)
@@ -153,7 +157,7 @@ class Plan:
         self.max_bound = max(self.bound.values())
 
 
-def schedule2(g, lanes=256, n_instance_inputs=None, K=4, margin=None, cost_mul=560, cost_lin=170, cost_load=60):
+def schedule2(g, lanes=256, n_instance_inputs=None, K=4, margin=None, cost_mul=560, cost_lin=170, cost_load=60, out_values=False):
     """-> (program bytes, statistics).  margin: an operation is not started while its height (remaining critical path) is
     more than `margin` below the most urgent ready operation - keeps early-computable values (the line evaluations of
     all Miller iterations) from occupying LDS slots for the whole program."""
@@ -261,7 +265,7 @@ def schedule2(g, lanes=256, n_instance_inputs=None, K=4, margin=None, cost_mul=5
     n_set = len(g.inputs) - n_instance_inputs
     n_load_steps = sum(1 for k, _ in steps if k == K_LOAD)
     assert all(k == K_LOAD for k, _ in steps[:n_load_steps]), "the interpreter runs the LOAD steps as a prefix"
-    words = [MAGIC2, lanes, n_slots, len(steps), len(const_index), n_in, n_set, len(g.outputs), n_load_steps] + [0] * 7
+    words = [MAGIC2, lanes, n_slots, len(steps), len(const_index), n_in, n_set, len(g.outputs), n_load_steps, 1 if out_values else 0] + [0] * 6
     for x in const_nodes:
         words += limbs29(g.val[x] * R406 % P) + [0, 0]
     for e in bias_es:

@@ -1177,3 +1177,73 @@ def test_constructor_notes_too_few_hardware_queues():
     assert out.returncode == 0 and "GPU_MAX_HW_QUEUES is unset or below 8" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
     out = subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="8"), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "NOTE[]" in out.stdout, (out.stdout[-500:], out.stderr[-1500:])
+
+
+def test_verify_kzg_proof_both_paths_and_the_z_equals_tau_corner():
+    """One proof at a time runs the reference's own equation (src/kzg_proof.rs:384-396) on three streams: SCALARS + VERIFY3
+    beside the square roots and the subgroup test (csrc/proof_kernels.hpp).  (a) all 122 reference vectors through that
+    path in this process and through round 3's MSM path in a child process (KZG_OPTIONS proof_path=msm): strict null <=> Err
+    both ways.  (b) Under the known-tau test setup: z = tau makes the per-call G2 point the identity - SCALARS reports it and
+    the call takes the general path (the equation then reads C == [y]G, whatever pi is); the answers equal the oracle's.  (c) points at infinity on either side, a commitment outside G1 (Err from the subgroup test that
+    runs beside the pairing), a proof that is not on the curve."""
+    import subprocess
+    import sys
+    from kzg_rs_amd import synth
+    st = api.KzgSettings.load_trusted_setup_file()
+    ost = O.Settings.mainnet()
+
+    def call(c, z, y, p, s):
+        try:
+            return KzgProof.verify_kzg_proof(Bytes48(c), Bytes32(z), Bytes32(y), Bytes48(p), s)
+        except KzgError as e:
+            assert e.kind == "BadArgs"
+            return None
+
+    for c in G.vectors()["verify_kzg_proof"]:
+        args = [bytes.fromhex(c[k][2:] if c[k].startswith("0x") else c[k]) for k in ("commitment", "z", "y", "proof")]
+        if any(len(a) != n for a, n in zip(args, (48, 32, 32, 48))):
+            continue  # (length errors are the mirror's, tested elsewhere)
+        assert call(*args, st) == c["output"], c["name"]
+    code = ("import sys\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import golden_data as G\n"
+            "from kzg_rs_amd import api\n"
+            "from kzg_rs_amd.api import Bytes32, Bytes48, KzgProof\n"
+            "st = api.KzgSettings.load_trusted_setup_file()\n"
+            "bad = 0\n"
+            "for c in G.vectors()['verify_kzg_proof']:\n"
+            "    try:\n"
+            "        got = KzgProof.verify_kzg_proof(Bytes48.from_hex(c['commitment']), Bytes32.from_hex(c['z']), Bytes32.from_hex(c['y']), Bytes48.from_hex(c['proof']), st)\n"
+            "    except api.KzgError:\n"
+            "        got = None\n"
+            "    bad += got != c['output']\n"
+            "print('MSM-PATH mismatches', bad)\n" % (O.ROOT, os.path.join(O.ROOT, "tests")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_OPTIONS="proof_path=msm"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "MSM-PATH mismatches 0" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+    # (b) z = tau under the synthetic setup: e(C - [y]G, G2) == e(pi, O) = 1  <=>  C == [y]G, whatever pi is
+    tau, tau_g2 = synth.synthetic_setup()
+    sst = api.KzgSettings.from_tau_g2(tau_g2)
+    osst = O.Settings.from_tau_g2(tau_g2)
+    zt = tau.to_bytes(32, "big")
+    y = (123456789).to_bytes(32, "big")
+    yG = api.g1_mul_generator([y], sst)[0]
+    other = api.g1_mul_generator([(987).to_bytes(32, "big")], sst)[0]
+    for c_, p_ in ((yG, other), (yG, G1_INF), (other, other), (G1_INF, other)):
+        want = O.verify_kzg_proof(c_, zt, y, p_, osst)
+        assert call(c_, zt, y, p_, sst) is want, (c_[:4], p_[:4])
+    assert call(yG, zt, y, other, sst) is True and call(other, zt, y, other, sst) is False
+    # (c) special points through the one-proof path, against the oracle
+    cs, zs, ys, ps, _ = synth.make_valid_proofs(3, seed=21, settings=sst)
+    off = G.off_subgroup_g1()
+    notcurve = bytes([0x80]) + bytes(46) + b"\x01"
+    cases = [(cs[0], zs[0], ys[0], ps[0]), (cs[0], zs[0], ys[1], ps[0]), (G1_INF, zs[0], bytes(32), G1_INF), (G1_INF, zs[0], ys[0], G1_INF),
+             (off, zs[0], ys[0], ps[0]), (cs[0], zs[0], ys[0], off), (cs[0], zs[0], ys[0], notcurve), (notcurve, zs[0], ys[0], ps[0]),
+             (cs[0], R.to_bytes(32, "big"), ys[0], ps[0]), (cs[0], zs[0], (R + 5).to_bytes(32, "big"), ps[0]),
+             (api.g1_mul_generator([ys[2]], sst)[0], zs[2], ys[2], G1_INF)]
+    for c_, z_, y_, p_ in cases:
+        try:
+            want = O.verify_kzg_proof(c_, z_, y_, p_, osst)
+        except O.OracleError:
+            want = None
+        assert call(c_, z_, y_, p_, sst) is want, (c_[:3].hex(), z_[:3].hex(), p_[:3].hex())
+    assert [call(*cases[i], sst) for i in (0, 1, 2, 3, 4, 10)] == [True, False, True, False, None, True]
