@@ -159,3 +159,24 @@ def test_kzg_options_string_is_parsed_as_documented():
     LA.kzg_debug_option.argtypes = L.kzg_debug_option.argtypes
     LA.kzg_debug_option(b"x", None, 0, C.byref(ab))
     assert ab.value == 1
+
+
+def test_build_checks_the_kernels_the_host_object_launches(tmp_path):
+    """kzg_rs_amd/build.py caches the gfx950 code object across host-only edits; the key is a heuristic, so the link step
+    compares the kernels the host object launches (its __device_stub__ symbols) with the kernels the cached code object
+    defines.  Here: a device pass that instantiates k_t<3> and a host pass that launches k_t<4> - the difference is seen."""
+    import subprocess
+    from kzg_rs_amd import build
+    src = tmp_path / "t.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n"
+                   "template <int N> __global__ void k_t(int* p) { p[0] = N; }\n"
+                   "__global__ void k_u(float* q, int n) { q[0] = n; }\n"
+                   "void f(int* p, float* q) { hipLaunchKernelGGL(k_t<VARIANT>, dim3(1), dim3(1), 0, 0, p); hipLaunchKernelGGL(k_u, dim3(1), dim3(1), 0, 0, q, 1); }\n")
+    dev, host_same, host_other = (str(tmp_path / n) for n in ("t.out", "same.o", "other.o"))
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-DVARIANT=3", "--cuda-device-only", "--no-gpu-bundle-output", "-c", "-o", dev, str(src)])
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-DVARIANT=3", "--cuda-host-only", "-c", "-o", host_same, str(src)])
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-DVARIANT=4", "--cuda-host-only", "-c", "-o", host_other, str(src)])
+    defined = build._kernel_names(dev, stubs=False)
+    assert defined == {"void k_t<3>(int*)", "k_u(float*, int)"}
+    assert build._kernel_names(host_same, stubs=True) - defined == set()
+    assert build._kernel_names(host_other, stubs=True) - defined == {"void k_t<4>(int*)"}

@@ -1,8 +1,8 @@
 """Product library (default kernel forms only) against the A/B build (the same + the alternative forms): what stripping the
 variants from the shipped code object changes.  Each library in a child process:
   - size of the .so and of its gfx950 code object
-  - verify_kzg_proof (one proof at a time): 96 calls, min / median / max, the distinct duration levels of the decode kernel
-    (a lone wavefront's time takes one of 8 values ~90 us apart, by where the dispatcher put it)
+  - verify_kzg_proof (one proof at a time): 96 calls, min / median / max / spread (a lone wavefront's time
+    depends on where the dispatcher put it; both paths: default and KZG_OPTIONS=proof_path=msm, round 3's)
   - one verify_blob_kzg_proof_batch of 1 024 device-resident blobs: 32 calls, min / median / max
     python3 tools/prof/code_object_ab.py            (through gpurun, from the repo root)"""
 import json
@@ -20,10 +20,9 @@ from kzg_rs_amd.api import Bytes32, Bytes48, KzgProof
 cs, zs, ys, ps, st = synth.make_valid_proofs(4, seed=9)
 args = (Bytes48(cs[0]), Bytes32(zs[0]), Bytes32(ys[0]), Bytes48(ps[0]), st)
 for _ in range(8): assert KzgProof.verify_kzg_proof(*args)
-ts, dec = [], []
+ts = []
 for _ in range(96):
     t0 = time.perf_counter(); assert KzgProof.verify_kzg_proof(*args); ts.append((time.perf_counter() - t0) * 1e3)
-    dec.append(round(st.last_timings()[6], 2))
 ts.sort()
 n = 1024
 blobs, c, p, st2 = synth.make_valid_batch(n, seed=3, chunk=1024)
@@ -34,9 +33,7 @@ tb = []
 for _ in range(32):
     t0 = time.perf_counter(); assert KzgProof.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, st2); tb.append((time.perf_counter() - t0) * 1e3)
 tb.sort()
-levels = sorted(set(round(x / 0.045) * 0.045 for x in dec))
-print(json.dumps({"verify_kzg_proof_ms": {"min": round(ts[0], 3), "median": round(ts[48], 3), "max": round(ts[-1], 3)},
-                  "decode_kernel_ms": {"min": min(dec), "max": max(dec), "spread": round(max(dec) - min(dec), 3), "levels_seen": len(levels)},
+print(json.dumps({"verify_kzg_proof_ms": {"min": round(ts[0], 3), "median": round(ts[48], 3), "max": round(ts[-1], 3), "spread": round(ts[-1] - ts[0], 3)},
                   "one_batch_1024_ms": {"min": round(tb[0], 3), "median": round(tb[16], 3), "max": round(tb[-1], 3)}}))
 """ % ROOT
 
@@ -52,8 +49,10 @@ def code_object_bytes(lib):
 
 
 res = {}
-for name, lib in (("product", os.path.join(ROOT, "kzg_rs_amd", "libkzg_rs_amd.so")), ("ab_build", os.path.join(ROOT, "kzg_rs_amd", "libkzg_rs_amd_ab.so"))):
-    env = dict(os.environ, KZG_LIB_OVERRIDE=lib, GPU_MAX_HW_QUEUES="8")
+for name, lib, opts in (("product", os.path.join(ROOT, "kzg_rs_amd", "libkzg_rs_amd.so"), ""), ("ab_build", os.path.join(ROOT, "kzg_rs_amd", "libkzg_rs_amd_ab.so"), ""),
+                        ("product_msm_proof_path", os.path.join(ROOT, "kzg_rs_amd", "libkzg_rs_amd.so"), "proof_path=msm"),
+                        ("ab_build_msm_proof_path", os.path.join(ROOT, "kzg_rs_amd", "libkzg_rs_amd_ab.so"), "proof_path=msm")):
+    env = dict(os.environ, KZG_LIB_OVERRIDE=lib, GPU_MAX_HW_QUEUES="8", KZG_OPTIONS=opts)
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     res[name] = {"so_bytes": os.path.getsize(lib), "code_object_bytes": code_object_bytes(lib)}

@@ -11,7 +11,7 @@ for what in batch proof; do
     rm -rf /tmp/tl_$what
     timeout 300 rocprofv3 --kernel-trace -d /tmp/tl_$what -o run --output-format csv -- python3 tools/prof/call_timeline.py run $what > /dev/null 2>&1
     if [ $what = batch ]; then echo "== one verify_blob_kzg_proof_batch call of 1 024 device-resident blobs" >> $out
-    else echo "" >> $out; echo "== one verify_kzg_proof call (eight lanes per point in the decode kernel; the call takes 2.6 ... 3.0 ms depending on where the lone wavefronts are placed: DESIGN.md section 9)" >> $out; fi
+    else echo "" >> $out; echo "== one verify_kzg_proof call (round 4: three streams - k_proof_select + SCALARS | k_proof_decompress: the two square roots | the full decode for the subgroup verdict - then VERIFY3; DESIGN.md section 3.7)" >> $out; fi
     python3 tools/prof/call_timeline.py show /tmp/tl_$what | cut -c1-160 >> $out
 done
 cat $out
