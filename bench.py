@@ -547,6 +547,8 @@ def main():
                 saved.append((vv[1], i, vv[1][i].clone()))
                 vv[1][i] = off_g1
         torch.cuda.synchronize()
+        for h in handles:  # (the single-batch legs above ran on this handle too: only the control's launches are counted below)
+            h.timing_totals(reset=True)
         res = api.verify_blob_kzg_proof_batch_groups_device([tuple(t.data_ptr() for t in variants[vi]) for vi in order], n, G, settings, in_flight=F)
         for t, i, old in saved:
             t[i] = old
