@@ -169,3 +169,11 @@ extern "C" int kzg_debug_option(const char* key, char* out, size_t cap, int* ab_
     }
     return (int)strlen(v);
 }
+
+// test hook (no GPU needed): compute_challenge (src/kzg_proof.rs:46-72) as the HOST computes it for small host batches
+// (host_only.hpp host_blob_challenge); z as 32 big-endian bytes
+extern "C" void kzg_debug_host_blob_challenge(uint8_t z_be[32], const uint8_t* blob, const uint8_t* commitment48) {
+    uint8_t le[32];
+    host_blob_challenge(le, blob, commitment48);
+    reverse32(z_be, le);
+}

@@ -404,7 +404,19 @@ static void select_streams(const KzgSettings* s, size_t T) {
 // over itself, into the staging buffers it is given as d_blobs / d_commitments / d_proofs.
 struct HostBatch {
     const uint8_t *blobs, *commitments, *proofs;
+    const uint8_t* z_le = nullptr;  // the challenges, computed on the host (host_blob_challenges): n x 32 little-endian bytes ...
+    std::thread* z_thread = nullptr;  // ... by this thread, which phase 1 joins where it needs them (the point decode runs meanwhile)
 };
+// HOST batches of up to this many blobs take their challenges from the host's SHA-NI cores (option host_challenge_max_blobs;
+// 0: never): a blob's SHA-256 chain is 2.8 ms on the GPU however few blobs there are and 65 us on a host core, and the hashing
+// (up to 16 threads, option host_threads) runs beside the point decode.  Measured on MI355X + its 256-core host, one
+// verify_blob_kzg_proof_batch call, host / GPU hashing (tools/prof/small_host_batch_latency.py): n = 1: 1.72 / 4.44 ms (with the
+// one-proof tail), 2: 3.03 / 4.45, 8: 3.01 / 4.42, 64: 3.24 / 4.59, 128: 3.37 / 4.39, 256: 3.70 / 4.48, 512: 4.33 / 4.58.
+// Larger batches, and every device-resident one, hash on the GPU.
+static size_t host_challenge_max_blobs() {
+    static const size_t v = (size_t)std::max(0L, std::min(4096L, opt_int("host_challenge_max_blobs", 256)));
+    return v;
+}
 // In how many slices ACROSS the blobs (slice j = bytes [j W, (j + 1) W) of every blob, W = 128 KiB / S) a host batch of n
 // blobs crosses PCIe.  One copy of the whole array first and the 2.8 ms SHA-256 chains after it cost copy + chain; SHA-256
 // consumes a blob front to back, so the chain's segment j (k_blob_challenge_split2_t<true>) runs while slice j + 1 is on the
@@ -469,7 +481,7 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
     const size_t T = n * B;
     KzgRet rc;
     select_streams(s, T);
-    const unsigned S = host ? host_slices(T) : 1;
+    const unsigned S = host && !host->z_le ? host_slices(T) : 1;
     HIPCHK(hipEventRecord(s->ev[0], s->s1));
     if (host && S == 1) {  // one copy of everything, on the stream the kernels follow on
         HIPCHK(hipMemcpyAsync(const_cast<void*>(d_commitments), host->commitments, 48 * T, hipMemcpyHostToDevice, s->s1));
@@ -484,14 +496,20 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
         HIPCHK(hipStreamWaitEvent(s->s2, s->ev[0], 0));
     }
     HIPCHK(hipEventRecord(s->ev[5], s->s2));
-    if ((rc = launch_decode(s, d_commitments, d_proofs, T)) != KZG_OK) return rc;
+    // (with the challenges from the host there is no SHA-256 chain to hide behind: the eight-lane decode, as for proof tuples)
+    if ((rc = launch_decode(s, d_commitments, d_proofs, T, /*behind_sha=*/!(host && host->z_le))) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[6], s->s2));
     HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * T, s->s1));
     if (s->s_sha != s->s1) {
         HIPCHK(hipEventRecord(s->ev[11], s->s1));
         HIPCHK(hipStreamWaitEvent(s->s_sha, s->ev[11], 0));
     }
-    if (host && S > 1) {
+    if (host && host->z_le) {  // the host hashes the blobs: z crosses as 32 bytes per blob (pinned mirror, bytes [192 T, 224 T))
+        w.ktime_valid = false;
+        if (host->z_thread && host->z_thread->joinable()) host->z_thread->join();
+        memcpy(w.h_buf + 192 * T, host->z_le, 32 * T);
+        HIPCHK(hipMemcpyAsync(w.d_z, w.h_buf + 192 * T, 32 * T, hipMemcpyHostToDevice, s->s_sha));
+    } else if (host && S > 1) {
         if ((rc = sliced_segments(s, *host, const_cast<void*>(d_blobs), d_commitments, w.d_z, T, S, s->s_sha)) != KZG_OK) return rc;
     } else if ((rc = launch_challenge(s, d_blobs, d_commitments, w.d_z, T, s->s_sha)) != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[7], s->s_sha));
@@ -806,8 +824,10 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_device(bool* ok, const void* d
     return batch_device_locked(ok, d_blobs, d_commitments, d_proofs, n, s);
 }
 
+static KzgRet blob_single_locked(bool* ok, bool* general, const uint8_t* blob, const uint8_t* commitment, const uint8_t* proof, const KzgSettings* s);
+static void proof_drain(const KzgSettings* s);
 extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs, const uint8_t* commitments,
-                                                  const uint8_t* proofs, size_t n, const KzgSettings* s) {
+                                                  const uint8_t* proofs, size_t n, const KzgSettings* s) try {
     if (!ok || !s) return fail(KZG_BADARGS, "null argument");
     if (n == 0) {
         *ok = true;
@@ -818,10 +838,40 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
     HIPCHK(hipSetDevice(s->device));
     // several devices: contiguous slices of the Vec<Blob>, each over its own device's PCIe link (capi_multi.hpp)
     if (multi_takes(s, n)) return multi_array_locked(ok, blobs, commitments, proofs, n, true, s);
-    KzgRet rc = ws_reserve(s, n, 1, STAGE_BLOBS);
-    if (rc != KZG_OK) return rc;
+    KzgRet rc;
+    const size_t host_max = host_challenge_max_blobs();
+    static const bool msm_path = opt_is("proof_path", "msm");
+    if (n == 1 && host_max >= 1 && !msm_path) {  // verify_blob_kzg_proof (:446-470, :482-489): host hash, one-proof tail
+        bool general = false;
+        if ((rc = blob_single_locked(ok, &general, blobs, commitments, proofs, s)) != KZG_OK) {
+            proof_drain(s);
+            return rc;
+        }
+        if (!general) return KZG_OK;
+    }
+    if ((rc = ws_reserve(s, n, 1, STAGE_BLOBS)) != KZG_OK) return rc;
     Workspace& w = s->ws;
-    const HostBatch host{blobs, commitments, proofs};  // phase 1 brings the batch over, in slices across the blobs (host_slices)
+    HostBatch host{blobs, commitments, proofs};  // phase 1 brings the batch over, in slices across the blobs (host_slices)
+    std::vector<uint8_t> z_host;
+    std::thread hasher;
+    struct Join {  // (a joinable thread must never be destroyed: whatever path leaves this scope)
+        std::thread& t;
+        ~Join() {
+            if (t.joinable()) t.join();
+        }
+    } join_hasher{hasher};
+    if (n <= host_max) {  // a few blobs: their challenges from the host's SHA-NI cores, beside the point decode on the GPU
+        z_host.resize(32 * n);
+        host.z_le = z_host.data();
+        const size_t threads = (size_t)std::max(1L, std::min(16L, opt_int("host_threads", 16)));
+        auto work = [&, threads] { host_blob_challenges(z_host.data(), blobs, commitments, n, threads); };
+        try {
+            hasher = std::thread(work);
+            host.z_thread = &hasher;
+        } catch (const std::system_error&) {
+            work();
+        }
+    }
     rc = batch_device_locked(ok, w.d_stage_blobs, w.d_stage_cp, w.d_stage_cp + 48 * n, n, s, &host);
     if (rc != KZG_OK && s->s_copy) {  // nothing may still read the caller's memory when the error goes back
         const std::string msg = g_err;
@@ -830,6 +880,8 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
         g_err = msg;
     }
     return rc;
+} catch (const std::bad_alloc&) {
+    return fail(KZG_MALLOC, "host buffers of the call");  // (nothing is thrown across the C ABI)
 }
 
 // A STREAM of host-resident batches: n_batches independent verify_blob_kzg_proof_batch calls (src/kzg_proof.rs:472-525) of n
@@ -968,59 +1020,71 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
 //   C: the full decode of both points (subgroup test: 2 x 64 doublings) - only its verdict is awaited, beside the pairing
 // Critical path max(A's SCALARS, B) + VERIFY3 instead of decode -> MSM -> pairing.  *general = true: Q is the identity
 // (z = tau: possible only for who knows the setup's secret) - its lines mean nothing, the caller takes the general path.
-static KzgRet proof_single_locked(bool* ok, bool* general, const uint8_t* commitment, const uint8_t* z_be, const uint8_t* y_be, const uint8_t* proof,
-                                  const KzgSettings* s) {
-    *general = false;
-    KzgRet rc = ws_reserve(s, 1, 1, STAGE_CP);
+struct ProofStreams {
+    hipStream_t sa, sb, sc;
+};
+// the buffers and streams of the one-proof path, made on first use; the pinned mirror (w.h_buf) holds
+//   [0, 64) z | y little-endian (verify_kzg_proof)   [64, 160) C | pi   [160, 168) status of the decompression
+//   [176, 184) status of the full decode   [1024, 1408) VERIFY3's eight outputs
+static KzgRet proof_reserve(ProofStreams& ps, const KzgSettings* s) {
+    KzgRet rc = ws_reserve(s, 1, 1, STAGE_BLOBS);
     if (rc != KZG_OK) return rc;
     select_streams(s, 1);
-    Workspace& w = s->ws;
     if (!s->d_proof) HIPCHK(hipMalloc(&s->d_proof, sizeof(Fp) * (SCALARS_INPUTS + VERIFY3_INPUTS)));
     const bool one_stream = !s->s_plain[1];  // option single_stream: everything in sequence (profiling)
     if (!one_stream && !s->s_aux) HIPCHK(hipStreamCreateWithFlags(&s->s_aux, hipStreamNonBlocking));
-    hipStream_t sa = s->s_plain[0], sb = one_stream ? sa : s->s_plain[1], sc = one_stream ? sa : s->s_aux;
-    Fp* const d_scal_in = s->d_proof;
-    Fp* const d_v3in = s->d_proof + SCALARS_INPUTS;
-    // pinned mirror: [z LE | y LE] 64 B, [C | pi] 96 B, status of the decompression 2 words, of the full decode 4 words, VERIFY3's outputs
+    ps.sa = s->s_plain[0];
+    ps.sb = one_stream ? ps.sa : s->s_plain[1];
+    ps.sc = one_stream ? ps.sa : s->s_aux;
+    return KZG_OK;
+}
+// B and C: the two square roots -> VERIFY3's point inputs (event ev[6]); the full decode for the subgroup verdict
+static KzgRet proof_points_launch(const ProofStreams& ps, const uint8_t* commitment, const uint8_t* proof, const KzgSettings* s) {
+    Workspace& w = s->ws;
     uint8_t* const h = w.h_buf;
-    reverse32(h, z_be);
-    reverse32(h + 32, y_be);
     memcpy(h + 64, commitment, 48);
     memcpy(h + 112, proof, 48);
     uint32_t* const h_pre = reinterpret_cast<uint32_t*>(h + 160);
     uint32_t* const h_full = reinterpret_cast<uint32_t*>(h + 176);
-    Fp* const h_out = reinterpret_cast<Fp*>(h + 1024);
     h_pre[0] = h_pre[1] = h_full[0] = h_full[1] = G1_INVALID;
-    HIPCHK(hipEventRecord(s->ev[0], sa));
-    // A: the scalars' chain
-    hipLaunchKernelGGL(k_proof_select, dim3(1), dim3(128), 0, sa, reinterpret_cast<const uint32_t*>(h), s->d_fixed_base, s->d_tau4, d_scal_in);
-    if ((rc = run_program2(s->scalars, d_scal_in, nullptr, d_v3in + 6, 1, sa)) != KZG_OK) return rc;
-    // B: the two square roots
-    hipLaunchKernelGGL(k_proof_decompress, dim3(1), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), sb, h + 64, d_v3in, h_pre);
+    Fp* const d_v3in = s->d_proof + SCALARS_INPUTS;
+    hipLaunchKernelGGL(k_proof_decompress, dim3(1), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), ps.sb, h + 64, d_v3in, h_pre);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(s->ev[6], sb));
-    // C: the subgroup test (the decode pass of the general path; its tables are not used)
-    {
-        struct RestoreS2 {
-            const KzgSettings* s;
-            hipStream_t keep;
-            ~RestoreS2() { s->s2 = keep; }
-        } restore{s, s->s2};
-        s->s2 = sc;
-        if ((rc = launch_decode(s, h + 64, h + 112, 1, /*behind_sha=*/false)) != KZG_OK) return rc;
-        HIPCHK(hipMemcpyAsync(h_full, w.d_pflag, 8, hipMemcpyDeviceToHost, sc));
-    }
-    // A again: the pairing, once the points are there; its eight outputs go straight into the mirror
-    if (sb != sa) HIPCHK(hipStreamWaitEvent(sa, s->ev[6], 0));
-    HIPCHK(hipEventRecord(s->ev[4], sa));
-    if ((rc = run_program2(s->verify3, d_v3in, s->d_prep29, h_out, 1, sa)) != KZG_OK) return rc;
-    HIPCHK(hipEventRecord(s->ev[9], sa));
-    HIPCHK(hipStreamSynchronize(sa));
-    if (sc != sa) HIPCHK(hipStreamSynchronize(sc));
+    HIPCHK(hipEventRecord(s->ev[6], ps.sb));
+    struct RestoreS2 {
+        const KzgSettings* s;
+        hipStream_t keep;
+        ~RestoreS2() { s->s2 = keep; }
+    } restore{s, s->s2};
+    s->s2 = ps.sc;
+    KzgRet rc = launch_decode(s, h + 64, h + 112, 1, /*behind_sha=*/false);
+    if (rc != KZG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(h_full, w.d_pflag, 8, hipMemcpyDeviceToHost, ps.sc));
+    return KZG_OK;
+}
+// A: the scalars' chain from z and y (8 little-endian limbs each; pinned host or device memory; ordered behind what stream
+// sa already holds), then the pairing once the points are there; waits, and reads the verdicts
+static KzgRet proof_tail_locked(bool* ok, bool* general, const ProofStreams& ps, const uint32_t* z, const uint32_t* y, const KzgSettings* s) {
+    Workspace& w = s->ws;
+    uint8_t* const h = w.h_buf;
+    Fp* const d_scal_in = s->d_proof;
+    Fp* const d_v3in = s->d_proof + SCALARS_INPUTS;
+    Fp* const h_out = reinterpret_cast<Fp*>(h + 1024);
+    hipLaunchKernelGGL(k_proof_select, dim3(1), dim3(128), 0, ps.sa, z, y, s->d_fixed_base, s->d_tau4, d_scal_in);
+    KzgRet rc = run_program2(s->scalars, d_scal_in, nullptr, d_v3in + 6, 1, ps.sa);
+    if (rc != KZG_OK) return rc;
+    if (ps.sb != ps.sa) HIPCHK(hipStreamWaitEvent(ps.sa, s->ev[6], 0));
+    HIPCHK(hipEventRecord(s->ev[4], ps.sa));
+    if ((rc = run_program2(s->verify3, d_v3in, s->d_prep29, h_out, 1, ps.sa)) != KZG_OK) return rc;  // the eight outputs go straight into the mirror
+    HIPCHK(hipEventRecord(s->ev[9], ps.sa));
+    HIPCHK(hipStreamSynchronize(ps.sa));
+    if (ps.sc != ps.sa) HIPCHK(hipStreamSynchronize(ps.sc));
     elapsed(&s->timings[3], s->ev[4], s->ev[9]);
     elapsed(&s->timings[0], s->ev[0], s->ev[9]);
     // the reference's order of errors: commitment (:372), then proof (:378); an encoding the decompression accepts can
     // still fail the subgroup test of the full decode
+    const uint32_t* h_pre = reinterpret_cast<const uint32_t*>(h + 160);
+    const uint32_t* h_full = reinterpret_cast<const uint32_t*>(h + 176);
     for (int i = 0; i < 2; i++)
         if (h_pre[i] == G1_INVALID || h_full[i] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
     const uint32_t* o = reinterpret_cast<const uint32_t*>(h_out);
@@ -1033,6 +1097,55 @@ static KzgRet proof_single_locked(bool* ok, bool* general, const uint8_t* commit
     }
     *ok = any == 0;
     return KZG_OK;
+}
+static void proof_drain(const KzgSettings* s) {  // nothing of the call stays in flight behind an error (the first message is kept)
+    const std::string msg = g_err;
+    for (hipStream_t st : {s->s_plain[0], s->s_plain[1], s->s_aux})
+        if (st) (void)hipStreamSynchronize(st);
+    (void)hipGetLastError();
+    g_err = msg;
+}
+
+static KzgRet proof_single_locked(bool* ok, bool* general, const uint8_t* commitment, const uint8_t* z_be, const uint8_t* y_be, const uint8_t* proof,
+                                  const KzgSettings* s) {
+    *general = false;
+    ProofStreams ps{};
+    KzgRet rc = proof_reserve(ps, s);
+    if (rc != KZG_OK) return rc;
+    uint8_t* const h = s->ws.h_buf;
+    reverse32(h, z_be);
+    reverse32(h + 32, y_be);
+    HIPCHK(hipEventRecord(s->ev[0], ps.sa));
+    if ((rc = proof_points_launch(ps, commitment, proof, s)) != KZG_OK) return rc;
+    return proof_tail_locked(ok, general, ps, reinterpret_cast<const uint32_t*>(h), reinterpret_cast<const uint32_t*>(h + 32), s);
+}
+
+// ONE blob from host memory (KzgProof::verify_blob_kzg_proof, src/kzg_proof.rs:446-470; the n == 1 branch of the batch form,
+// :482-489): the point chains start at once; the host hashes the blob (65 us) while the blob crosses PCIe; z follows as 32
+// bytes; the evaluation (one wavefront) gives y on the device; then the one-proof tail.  *general as in proof_single_locked.
+static KzgRet blob_single_locked(bool* ok, bool* general, const uint8_t* blob, const uint8_t* commitment, const uint8_t* proof, const KzgSettings* s) {
+    *general = false;
+    ProofStreams ps{};
+    KzgRet rc = proof_reserve(ps, s);
+    if (rc != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    uint8_t* const h = w.h_buf;
+    HIPCHK(hipEventRecord(s->ev[0], ps.sa));
+    if ((rc = proof_points_launch(ps, commitment, proof, s)) != KZG_OK) return rc;
+    HIPCHK(hipMemsetAsync(w.d_status, 0, 4, ps.sa));
+    HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blob, BLOB_BYTES, hipMemcpyHostToDevice, ps.sa));  // (pageable: the call returns when the bytes have left)
+    host_blob_challenge(h + 192, blob, commitment);
+    HIPCHK(hipMemcpyAsync(w.d_z, h + 192, 32, hipMemcpyHostToDevice, ps.sa));
+    if ((rc = launch_evaluate(s, w.d_stage_blobs, w.d_z, w.d_y, w.d_status, 1)) != KZG_OK) return rc;  // (on s->s1 = sa)
+    HIPCHK(hipMemcpyAsync(h + 224, w.d_status, 4, hipMemcpyDeviceToHost, ps.sa));
+    rc = proof_tail_locked(ok, general, ps, reinterpret_cast<const uint32_t*>(w.d_z), reinterpret_cast<const uint32_t*>(w.d_y), s);
+    // the reference parses the commitment (:453), the blob (:454: a non-canonical element is BadArgs), then the proof (:455)
+    const uint32_t* h_pre = reinterpret_cast<const uint32_t*>(h + 160);
+    const uint32_t* h_full = reinterpret_cast<const uint32_t*>(h + 176);
+    if (h_pre[0] == G1_INVALID || h_full[0] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    if (rc == KZG_OK || rc == KZG_BADARGS)
+        if (*reinterpret_cast<const uint32_t*>(h + 224) != 0) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");  // (sic) :38-40
+    return rc;
 }
 
 extern "C" KzgRet kzg_verify_kzg_proof(bool* ok, const uint8_t commitment[48], const uint8_t z[32], const uint8_t y[32],
@@ -1050,12 +1163,8 @@ extern "C" KzgRet kzg_verify_kzg_proof(bool* ok, const uint8_t commitment[48], c
             std::lock_guard<std::mutex> lk(s->mu);
             HIPCHK(hipSetDevice(s->device));
             const KzgRet rc = proof_single_locked(ok, &general, commitment, z, y, proof, s);
-            if (rc != KZG_OK) {  // nothing of the call stays in flight behind an error
-                const std::string msg = g_err;
-                for (hipStream_t st : {s->s_plain[0], s->s_plain[1], s->s_aux})
-                    if (st) (void)hipStreamSynchronize(st);
-                (void)hipGetLastError();
-                g_err = msg;
+            if (rc != KZG_OK) {
+                proof_drain(s);
                 return rc;
             }
         }

@@ -255,6 +255,44 @@ struct BatchTranscript {
         reverse32(r_le, dg);
     }
 };
+// compute_challenge (src/kzg_proof.rs:46-72) on the HOST for blobs that lie in host memory: z = SHA-256("FSBLOBVERIFY_V1_" ||
+// u64_be(0) || u64_be(4096) || blob || commitment) mod r, as 32 little-endian bytes (the device limb layout).  The same
+// argument as for the batch transcript: a 131 KB serial chain is 65 us on a SHA-NI core and 2.8 ms on GPU lanes, and a call
+// with a handful of blobs has no parallelism across blobs to give the GPU (capi_verify.hpp: host batches of up to
+// host_challenge_max_blobs blobs; larger ones, and everything device-resident, hash on the GPU).
+static void host_blob_challenge(uint8_t z_le[32], const uint8_t* blob, const uint8_t* commitment48) {
+    uint8_t h[32];
+    memcpy(h, "FSBLOBVERIFY_V1_", 16);
+    memset(h + 16, 0, 16);
+    h[30] = (uint8_t)(KZG_HOST_FE_PER_BLOB >> 8);
+    h[31] = (uint8_t)(KZG_HOST_FE_PER_BLOB & 0xff);
+    hostsha::Stream sha;
+    sha.update(h, 32);
+    sha.update(blob, (size_t)32 * KZG_HOST_FE_PER_BLOB);
+    sha.update(commitment48, 48);
+    uint8_t dg[32];
+    sha.finish(dg);
+    while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r (:74-91)
+    reverse32(z_le, dg);
+}
+static void host_blob_challenges(uint8_t* z_le, const uint8_t* blobs, const uint8_t* commitments, size_t n, size_t max_threads) {
+    auto range = [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; i++) host_blob_challenge(z_le + 32 * i, blobs + (size_t)32 * KZG_HOST_FE_PER_BLOB * i, commitments + 48 * i);
+    };
+    const size_t nthr = std::max<size_t>(1, std::min(max_threads, n));
+    if (nthr == 1) return range(0, n);
+    std::vector<std::thread> pool;
+    for (size_t k = 1; k < nthr; k++) {
+        try {
+            pool.emplace_back(range, n * k / nthr, n * (k + 1) / nthr);
+        } catch (const std::system_error&) {
+            range(n * k / nthr, n * (k + 1) / nthr);
+        }
+    }
+    range(0, n / nthr);
+    for (auto& th : pool) th.join();
+}
+
 static bool host_batch_challenges(uint8_t* r_out, const uint8_t* all_records, size_t B, size_t n, size_t n_total, size_t world) {
     std::atomic<bool> failed{false};
     auto digest_range = [&](size_t b0, size_t b1) {  // (the records are hashed where they lie: no transcript copy)

@@ -21,14 +21,14 @@ constexpr int SCALARS_INPUTS = FB_WINDOWS * (int)(FB_G2_FP + FB_G1_FP) + 4;  // 
 constexpr int VERIFY3_INPUTS = 9 + 68 * 6 + 2;                                 // pi, C, [y]G, the lines of Q, Z of Q
 constexpr int VERIFY3_OUTPUTS = 8;                                             // the six pairing coefficients, Z.c0 and Z.c1 of Q
 
-// zy: z then y, 8 little-endian 32-bit limbs each (canonical; pinned host memory or device memory)
-__global__ __launch_bounds__(128) void k_proof_select(const uint32_t* __restrict__ zy, const Fp* __restrict__ table, const Fp* __restrict__ tau4,
-                                                      Fp* __restrict__ out) {
+// z, y: 8 little-endian 32-bit limbs each (canonical; pinned host memory or device memory)
+__global__ __launch_bounds__(128) void k_proof_select(const uint32_t* __restrict__ z, const uint32_t* __restrict__ y, const Fp* __restrict__ table,
+                                                      const Fp* __restrict__ tau4, Fp* __restrict__ out) {
     const int t = threadIdx.x;
     if (t < 2 * FB_WINDOWS) {
         const bool g1 = t >= FB_WINDOWS;
         const int w = g1 ? t - FB_WINDOWS : t;
-        const uint32_t digit = (zy[(g1 ? 8 : 0) + (w >> 2)] >> (8 * (w & 3))) & 255u;
+        const uint32_t digit = ((g1 ? y : z)[w >> 2] >> (8 * (w & 3))) & 255u;
         const size_t nfp = g1 ? FB_G1_FP : FB_G2_FP;
         const Fp* src = table + (g1 ? (size_t)FB_WINDOWS * FB_DIGITS * FB_G2_FP : 0) + ((size_t)w * FB_DIGITS + digit) * nfp;
         Fp* dst = out + (g1 ? (size_t)FB_WINDOWS * FB_G2_FP + (size_t)w * FB_G1_FP : (size_t)w * FB_G2_FP);

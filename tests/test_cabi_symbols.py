@@ -180,3 +180,41 @@ def test_build_checks_the_kernels_the_host_object_launches(tmp_path):
     assert defined == {"void k_t<3>(int*)", "k_u(float*, int)"}
     assert build._kernel_names(host_same, stubs=True) - defined == set()
     assert build._kernel_names(host_other, stubs=True) - defined == {"void k_t<4>(int*)"}
+
+
+def test_host_blob_challenge_matches_the_reference_kat_and_the_oracle():
+    """Small host batches take their Fiat-Shamir challenges from the host's SHA-NI cores (csrc/host_only.hpp
+    host_blob_challenge: the same serial-chain argument as for the batch transcript).  Against the reference's own known
+    answer (test_compute_challenge, src/kzg_proof.rs:739-752), the derived (z) table of the valid mainnet blobs, and the oracle
+    on random blobs and commitments (digests above r included)."""
+    import ctypes as C
+    import random
+    import golden_data as G
+    import oracle_lib as O
+    from kzg_rs_amd import api, build
+    build.build()
+    L = C.CDLL(api.LIB_PATH)
+    L.kzg_debug_host_blob_challenge.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.kzg_debug_host_blob_challenge.restype = None
+
+    def z(blob, c):
+        out = C.create_string_buffer(32)
+        L.kzg_debug_host_blob_challenge(out, blob, c)
+        return out.raw
+
+    for blob, c, _ in G.valid_blob_tuples():
+        assert z(blob, c) == O.compute_challenge(blob, c)
+    k = G.kat()["compute_challenge"]  # the reference's own known answer
+    c = G.case("verify_blob_kzg_proof", k["case"])
+    assert z(G.blob(c["blob"]), bytes.fromhex(c["commitment"])).hex() == k["z"]
+    for suffix, (zz, _) in G.kat()["zy_table"].items():
+        c = G.case("verify_blob_kzg_proof", suffix)
+        assert z(G.blob(c["blob"]), bytes.fromhex(c["commitment"])).hex() == zz
+    rng = random.Random(2718)
+    above_r = 0
+    for _ in range(24):
+        blob, c = rng.randbytes(131072), rng.randbytes(48)
+        want = O.compute_challenge(blob, c)
+        assert z(blob, c) == want
+        above_r += int.from_bytes(O.sha256(b"FSBLOBVERIFY_V1_" + bytes(14) + b"\x10\x00" + blob + c), "big") >= 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    assert above_r >= 3  # (a digest is above r with probability 0.55: the reduction was exercised)
