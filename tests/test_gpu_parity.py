@@ -1247,3 +1247,57 @@ def test_verify_kzg_proof_both_paths_and_the_z_equals_tau_corner():
             want = None
         assert call(c_, z_, y_, p_, sst) is want, (c_[:3].hex(), z_[:3].hex(), p_[:3].hex())
     assert [call(*cases[i], sst) for i in (0, 1, 2, 3, 4, 10)] == [True, False, True, False, None, True]
+
+
+def test_small_host_batches_hash_on_the_host_or_on_the_gpu_with_the_same_results():
+    """Host batches of up to 256 blobs take their Fiat-Shamir challenges from the host's SHA-NI cores (beside the point decode;
+    one blob: plus the one-proof tail), larger and device-resident ones from the GPU's SHA-256 kernels.  All 29 + 27 + 24
+    reference vectors for the two blob entry points in this process (host hashing: every batch vector has at most 7 blobs)
+    and again in a child process with KZG_OPTIONS=host_challenge_max_blobs=0 (GPU hashing, round 3's behaviour): strict
+    null <=> Err both ways; and a synthetic 40-blob host batch - valid, a wrong proof, a non-canonical element in the last
+    blob, an off-subgroup proof - against the oracle through both."""
+    import ctypes as C
+    import subprocess
+    import sys
+    from kzg_rs_amd import synth
+    code = ("import sys\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import ctypes as C\n"
+            "import golden_data as G, oracle_lib as O\n"
+            "from kzg_rs_amd import api, synth\n"
+            "st = api.KzgSettings.load_trusted_setup_file()\n"
+            "bad = 0\n"
+            "for c in G.vectors()['verify_blob_kzg_proof']:\n"
+            "    try:\n"
+            "        got = api.KzgProof.verify_blob_kzg_proof(api.Blob.from_slice(G.blob(c['blob'])), api.Bytes48.from_hex(c['commitment']), api.Bytes48.from_hex(c['proof']), st)\n"
+            "    except api.KzgError:\n"
+            "        got = None\n"
+            "    bad += got != c['output']\n"
+            "for c in G.vectors()['verify_blob_kzg_proof_batch']:\n"
+            "    try:\n"
+            "        got = api.KzgProof.verify_blob_kzg_proof_batch([api.Blob.from_slice(G.blob(b)) for b in c['blobs']], [api.Bytes48.from_hex(x) for x in c['commitments']], [api.Bytes48.from_hex(x) for x in c['proofs']], st)\n"
+            "    except api.KzgError:\n"
+            "        got = None\n"
+            "    bad += got != c['output']\n"
+            "n = 40\n"
+            "blobs, cs, ps, sst = synth.make_valid_batch(n, seed=404)\n"
+            "ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])\n"
+            "L = api.lib(); ok = C.c_bool(False)\n"
+            "R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001\n"
+            "def run(b, p):\n"
+            "    rc = L.kzg_verify_blob_kzg_proof_batch(C.byref(ok), b.ctypes.data_as(C.c_char_p), b''.join(cs), b''.join(p), n, sst._h)\n"
+            "    return None if rc else bool(ok.value)\n"
+            "def want(b, p):\n"
+            "    try:\n"
+            "        return O.verify_blob_kzg_proof_batch([b[i].tobytes() for i in range(n)], cs, p, ost)\n"
+            "    except O.OracleError:\n"
+            "        return None\n"
+            "wrong = list(ps); wrong[17] = ps[18]\n"
+            "offp = list(ps); offp[39] = G.off_subgroup_g1()\n"
+            "bb = blobs.copy(); bb[39, 32 * 4095:] = list(R.to_bytes(32, 'big'))\n"
+            "res = [run(blobs, ps), run(blobs, wrong), run(bb, ps), run(blobs, offp)]\n"
+            "bad += res != [want(blobs, ps), want(blobs, wrong), want(bb, ps), want(blobs, offp)] or res != [True, False, None, None]\n"
+            "print('SMALL-HOST mismatches', bad)\n" % (O.ROOT, os.path.join(O.ROOT, "tests")))
+    for opts in ("", "host_challenge_max_blobs=0"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_OPTIONS=opts), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "SMALL-HOST mismatches 0" in out.stdout, (opts, out.stdout[-500:], out.stderr[-2000:])
