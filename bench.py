@@ -498,6 +498,7 @@ def main():
     standalone = None
     self_check = None
     proof_ms = None
+    blob_ms = None
     solo_sums, solo_cnt = [0.0] * 8, 0
     sc_sums, sc_cnt = [0.0] * 8, 0
     if not args.no_self_check:
@@ -581,6 +582,15 @@ def main():
                 ts.append(time.perf_counter() - t0)
             assert okp is True
             proof_ms = round(sorted(ts[4:])[16] * 1e3, 4)
+            # one blob from host memory (src/kzg_proof.rs:446-470): median of 16 calls
+            b0 = api.Blob(blobs[0].tobytes())
+            ts = []
+            for _ in range(20):
+                t0 = time.perf_counter()
+                okb = api.KzgProof.verify_blob_kzg_proof(b0, api.Bytes48(cs[0]), api.Bytes48(ps[0]), settings)
+                ts.append(time.perf_counter() - t0)
+            assert okb is True
+            blob_ms = round(sorted(ts[4:])[8] * 1e3, 4)
     backend_name = dist.get_backend() if dist else None
     if dist:
         # every rank leaves its GPU before rank 0 reports (and, at N > 1, drives all of them from one process)
@@ -700,6 +710,7 @@ def main():
         "single_batch": single,
         "end_to_end": end2end,
         "verify_kzg_proof_ms": proof_ms,
+        "verify_blob_kzg_proof_ms": blob_ms,
     }
     if world > 1:
         g = max(pipe.stats["groups"], 1)  # warm-up groups included; per-step averages of THIS rank's host time
