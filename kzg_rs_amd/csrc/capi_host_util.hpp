@@ -31,8 +31,7 @@ extern "C" const char* kzg_last_error(void) { return g_err.c_str(); }
 static const char* opt_str(const char* key) {  // nullptr when unset; the pointer stays valid until the process ends
     static std::mutex mu;
     static std::string parsed_from;
-    static std::map<std::string, std::string> kv;
-    static std::vector<std::string*> keep;  // values handed out earlier stay alive across a re-parse
+    static std::map<std::string, std::string*> kv;  // (values handed out earlier stay alive across a re-parse: a few bytes per change of the string)
     std::lock_guard<std::mutex> lk(mu);
     const char* e = getenv("KZG_OPTIONS");
     const std::string cur = e ? e : "";
@@ -45,14 +44,12 @@ static const char* opt_str(const char* key) {  // nullptr when unset; the pointe
             if (j == std::string::npos) j = cur.size();
             const std::string item = cur.substr(i, j - i);
             const size_t eq = item.find('=');
-            if (!item.empty()) kv[eq == std::string::npos ? item : item.substr(0, eq)] = eq == std::string::npos ? "1" : item.substr(eq + 1);
+            if (!item.empty()) kv[eq == std::string::npos ? item : item.substr(0, eq)] = new std::string(eq == std::string::npos ? "1" : item.substr(eq + 1));
             i = j + 1;
         }
     }
     auto it = kv.find(key);
-    if (it == kv.end()) return nullptr;
-    keep.push_back(new std::string(it->second));
-    return keep.back()->c_str();
+    return it == kv.end() ? nullptr : it->second->c_str();
 }
 static bool opt_flag(const char* key, bool dflt) {
     const char* v = opt_str(key);
