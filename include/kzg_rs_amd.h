@@ -116,6 +116,14 @@ KzgRet kzg_settings_tau_g2(const KzgSettings *s, uint8_t out[96]);
  * beside the two square roots, the subgroup test beside the pairing (csrc/proof_kernels.hpp): 1.6-1.7 ms on MI355X. */
 KzgRet kzg_verify_kzg_proof(bool *ok, const uint8_t commitment[48], const uint8_t z[32], const uint8_t y[32],
                             const uint8_t proof[48], const KzgSettings *s);
+/* n INDEPENDENT verify_kzg_proof calls (src/kzg_proof.rs:353-397) through one call, each with its own pairing and its own
+ * verdict - SURVEY 8f rank 3's "verify_kzg_proof x N, each with its own pairing": the revm precompile's workload when every
+ * proof needs its own result (kzg_verify_kzg_proof_batch below gives ONE boolean for all).  commitments / proofs: n x 48 bytes,
+ * zs / ys: n x 32 big-endian bytes, host memory.  ok_out[i] = the result of proof i; err_out[i] (optional) = 1 where the
+ * reference would return Err for proof i (then ok_out[i] = false); without err_out any such proof fails the whole call with
+ * KZG_BADARGS.  Every proof is one instance of the one-proof programs (one workgroup each), 1 024 per launch. */
+KzgRet kzg_verify_kzg_proofs(bool *ok_out, uint8_t *err_out, const uint8_t *commitments, const uint8_t *zs, const uint8_t *ys,
+                             const uint8_t *proofs, size_t n, const KzgSettings *s);
 /* KzgProof::verify_kzg_proof_batch (src/kzg_proof.rs:399-444): n (commitment, z, y, proof) tuples checked with one
  * random linear combination (r from compute_r_powers, :291-348) and ONE pairing.  The reference takes decoded
  * &[G1Affine] / &[Scalar]; across the C ABI they are n*48 compressed bytes and n*32 big-endian canonical bytes in

@@ -117,6 +117,7 @@ def lib():
         L.kzg_compute_blob_kzg_proof.argtypes = [u8, u8, u8, sz, vp]
         L.kzg_verify_kzg_proof.argtypes = [bp, u8, u8, u8, u8, vp]
         L.kzg_verify_kzg_proof_batch.argtypes = [bp, u8, u8, u8, u8, sz, vp]
+        L.kzg_verify_kzg_proofs.argtypes = [bp, u8, u8, u8, u8, u8, sz, vp]
         L.kzg_verify_blob_kzg_proof.argtypes = [bp, u8, u8, u8, vp]
         L.kzg_verify_blob_kzg_proof_batch.argtypes = [bp, u8, u8, u8, sz, vp]
         L.kzg_verify_blob_kzg_proof_batch_device.argtypes = [bp, vp, vp, vp, sz, vp]
@@ -387,6 +388,22 @@ class KzgProof:
         _chk(lib().kzg_verify_blob_kzg_proof_batch_device(C.byref(ok), d_blobs, d_commitments, d_proofs, n,
                                                           kzg_settings._h))
         return bool(ok.value)
+
+
+def verify_kzg_proofs(commitments, zs, ys, proofs, kzg_settings):
+    """n INDEPENDENT verify_kzg_proof calls (src/kzg_proof.rs:353-397) through one C call, each with its own pairing: lists of
+    Bytes48 / Bytes32 (or bytes) of equal length -> a list with True / False per proof, or None where the reference would
+    return Err."""
+    n = len(commitments)
+    if not (len(zs) == len(ys) == len(proofs) == n):
+        raise InvalidBytesLength("verify_kzg_proofs: lists of unequal length")
+    if n == 0:
+        return []
+    raw = lambda xs: b"".join(x.data if hasattr(x, "data") else bytes(x) for x in xs)
+    ok = (C.c_bool * n)()
+    err = C.create_string_buffer(n)
+    _chk(lib().kzg_verify_kzg_proofs(ok, err, raw(commitments), raw(zs), raw(ys), raw(proofs), n, kzg_settings._h))
+    return [None if err.raw[i] else bool(ok[i]) for i in range(n)]
 
 
 def verify_blob_kzg_proof_batch_sharded(shards, kzg_settings):

@@ -86,6 +86,9 @@ struct KzgSettings {
     mutable hipStream_t s_copy = nullptr;  // host -> device staging copies of the host-fed stream (made on first use)
     mutable hipStream_t s_aux = nullptr;   // the one-proof path's third stream: the subgroup test beside the pairing (made on first use)
     mutable Fp* d_proof = nullptr;         // ... and its device buffers: SCALARS' inputs | VERIFY3's inputs (made on first use)
+    mutable Fp *d_proofs = nullptr, *d_proofs_out = nullptr;  // the same for MANY independent proofs (kzg_verify_kzg_proofs): [cap] records each
+    mutable uint8_t* h_proofs = nullptr;   // ... and their pinned mirror
+    mutable size_t cap_proofs = 0;
     mutable hipEvent_t ev_copy[2] = {nullptr, nullptr};
     mutable hipEvent_t ev_slice[17] = {};  // a host Vec<Blob> arriving in slices: [0] commitments + proofs landed, [1 + j] slice j landed
     mutable std::mutex mu;
@@ -153,17 +156,21 @@ static KzgRet upload_program2(DevProgram2& dp, const unsigned char* begin, const
 
 // the latency form: one workgroup of 2 to 4 wavefronts per instance (what the program was scheduled for)
 template <int LANES>
-static KzgRet launch_program2(const DevProgram2& dp, const Fp* d_in, const uint32_t* d_set29, Fp* d_out, int instances, hipStream_t st) {
+static KzgRet launch_program2(const DevProgram2& dp, const Fp* d_in, const uint32_t* d_set29, Fp* d_out, int instances, hipStream_t st, uint32_t in_stride,
+                              uint32_t out_stride) {
     const size_t lds = (size_t)dp.p.n_slots * SLP2_SLOT_WORDS * 4 + (size_t)SLP2_GROUP * LANES * sizeof(uint4);  // slots | descriptor ring
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp2_run<LANES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_slp2_run<LANES>, dim3(instances), dim3(LANES), lds, st, dp.p, d_in, d_set29, d_out);
+    hipLaunchKernelGGL(k_slp2_run<LANES>, dim3(instances), dim3(LANES), lds, st, dp.p, d_in, d_set29, d_out, in_stride ? in_stride : dp.p.n_in,
+                       out_stride ? out_stride : dp.p.n_out);
     HIPCHK(hipGetLastError());
     return KZG_OK;
 }
-static KzgRet run_program2(const DevProgram2& dp, const Fp* d_in, const uint32_t* d_set29, Fp* d_out, int instances, hipStream_t st) {
-    return dp.p.lanes == 128 ? launch_program2<128>(dp, d_in, d_set29, d_out, instances, st)
-         : dp.p.lanes == 192 ? launch_program2<192>(dp, d_in, d_set29, d_out, instances, st)
-                             : launch_program2<256>(dp, d_in, d_set29, d_out, instances, st);
+// in_stride / out_stride (elements between two instances' records; 0 = the program's own counts)
+static KzgRet run_program2(const DevProgram2& dp, const Fp* d_in, const uint32_t* d_set29, Fp* d_out, int instances, hipStream_t st, uint32_t in_stride = 0,
+                           uint32_t out_stride = 0) {
+    return dp.p.lanes == 128 ? launch_program2<128>(dp, d_in, d_set29, d_out, instances, st, in_stride, out_stride)
+         : dp.p.lanes == 192 ? launch_program2<192>(dp, d_in, d_set29, d_out, instances, st, in_stride, out_stride)
+                             : launch_program2<256>(dp, d_in, d_set29, d_out, instances, st, in_stride, out_stride);
 }
 // which form runs a launch of `instances` checks: option pairing=1 | 2 forces the one-wave / the latency program (A/B, cross-check)
 static bool pairing_latency_form(size_t instances) {
@@ -520,6 +527,9 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     ws_free(s->ws);
     if (s->d_eval_scratch) (void)hipFree(s->d_eval_scratch);
     if (s->d_proof) (void)hipFree(s->d_proof);
+    if (s->d_proofs) (void)hipFree(s->d_proofs);
+    if (s->d_proofs_out) (void)hipFree(s->d_proofs_out);
+    if (s->h_proofs) (void)hipHostFree(s->h_proofs);
     if (!s->borrowed) {  // (a lane reads its parent's tables)
         void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob, s->verify2.blob, s->d_prep29, s->scalars.blob, s->verify3.blob, s->d_fixed_base};
         for (void* p : ptrs)

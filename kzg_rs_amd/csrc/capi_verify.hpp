@@ -825,6 +825,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_device(bool* ok, const void* d
 }
 
 static KzgRet blob_single_locked(bool* ok, bool* general, const uint8_t* blob, const uint8_t* commitment, const uint8_t* proof, const KzgSettings* s);
+static KzgRet blobs_small_locked(bool* ok, bool* general, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n, const KzgSettings* s);
 static void proof_drain(const KzgSettings* s);
 extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs, const uint8_t* commitments,
                                                   const uint8_t* proofs, size_t n, const KzgSettings* s) try {
@@ -844,6 +845,15 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
     if (n == 1 && host_max >= 1 && !msm_path) {  // verify_blob_kzg_proof (:446-470, :482-489): host hash, one-proof tail
         bool general = false;
         if ((rc = blob_single_locked(ok, &general, blobs, commitments, proofs, s)) != KZG_OK) {
+            proof_drain(s);
+            return rc;
+        }
+        if (!general) return KZG_OK;
+    }
+    static const size_t small_max = (size_t)std::max(0L, std::min(256L, opt_int("small_batch_pairings_max", 64)));
+    if (n >= 2 && n <= small_max && n <= host_max && !msm_path) {  // a few blobs: one pairing each, side by side (blobs_small_locked)
+        bool general = false;
+        if ((rc = blobs_small_locked(ok, &general, blobs, commitments, proofs, n, s)) != KZG_OK) {
             proof_drain(s);
             return rc;
         }
@@ -1048,7 +1058,7 @@ static KzgRet proof_points_launch(const ProofStreams& ps, const uint8_t* commitm
     uint32_t* const h_full = reinterpret_cast<uint32_t*>(h + 176);
     h_pre[0] = h_pre[1] = h_full[0] = h_full[1] = G1_INVALID;
     Fp* const d_v3in = s->d_proof + SCALARS_INPUTS;
-    hipLaunchKernelGGL(k_proof_decompress, dim3(1), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), ps.sb, h + 64, d_v3in, h_pre);
+    hipLaunchKernelGGL(k_proof_decompress, dim3(1), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), ps.sb, h + 64, h + 112, 1, d_v3in, h_pre);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[6], ps.sb));
     struct RestoreS2 {
@@ -1070,7 +1080,7 @@ static KzgRet proof_tail_locked(bool* ok, bool* general, const ProofStreams& ps,
     Fp* const d_scal_in = s->d_proof;
     Fp* const d_v3in = s->d_proof + SCALARS_INPUTS;
     Fp* const h_out = reinterpret_cast<Fp*>(h + 1024);
-    hipLaunchKernelGGL(k_proof_select, dim3(1), dim3(128), 0, ps.sa, z, y, s->d_fixed_base, s->d_tau4, d_scal_in);
+    hipLaunchKernelGGL(k_proof_select, dim3(1), dim3(128), 0, ps.sa, z, y, 0u, s->d_fixed_base, s->d_tau4, d_scal_in);
     KzgRet rc = run_program2(s->scalars, d_scal_in, nullptr, d_v3in + 6, 1, ps.sa);
     if (rc != KZG_OK) return rc;
     if (ps.sb != ps.sa) HIPCHK(hipStreamWaitEvent(ps.sa, s->ev[6], 0));
@@ -1148,6 +1158,225 @@ static KzgRet blob_single_locked(bool* ok, bool* general, const uint8_t* blob, c
     return rc;
 }
 
+// MANY INDEPENDENT proofs, each with its own pairing and its own result ("verify_kzg_proof x N, each with its
+// own pairing" - the revm precompile's workload when every transaction's proof needs its own verdict): the one-proof path with
+// one program instance (= one workgroup, one CU) per proof - m proofs of a chunk run side by side.  Pinned mirror per proof:
+// [z | y LE 64 B] [status 4 words] [VERIFY3's outputs 8 x 48 B]; commitments and proofs as two arrays of 48 bytes each.
+constexpr size_t PROOFS_CHUNK = 1024;  // proofs per launch (the eight-lane subgroup-test kernel takes up to 8 x 256 points)
+constexpr size_t PROOFS_MIRROR_BYTES = 64 + 96 + 16 + 8 * sizeof(Fp);
+// one launch of m proofs: the pinned mirror [m][z | y LE] | [m][48] C | [m][48] pi | [m][2] decompression status | [2 m] full-decode
+// status (all C, then all pi) | [m][8] Fp VERIFY3's outputs, and the device buffers [m] SCALARS inputs | [m] VERIFY3 inputs
+struct ProofsLaunch {
+    size_t m;
+    uint32_t* h_zy;
+    uint8_t *h_c, *h_p;
+    uint32_t *h_pre, *h_full;
+    Fp *h_out, *d_scal_in, *d_v3in;
+};
+static KzgRet proofs_reserve(ProofStreams& ps, ProofsLaunch& pl, size_t m, int stage, const KzgSettings* s) {
+    KzgRet rc = proof_reserve(ps, s);
+    if (rc != KZG_OK) return rc;
+    if (m > s->cap_proofs) {
+        if (s->d_proofs) (void)hipFree(s->d_proofs);
+        if (s->d_proofs_out) (void)hipFree(s->d_proofs_out);
+        if (s->h_proofs) (void)hipHostFree(s->h_proofs);
+        s->d_proofs = s->d_proofs_out = nullptr;
+        s->h_proofs = nullptr;
+        s->cap_proofs = 0;
+        const size_t cap = std::max<size_t>(m, 64);
+        HIPCHK(hipMalloc(&s->d_proofs, sizeof(Fp) * (SCALARS_INPUTS + VERIFY3_INPUTS) * cap));
+        HIPCHK(hipMalloc(&s->d_proofs_out, sizeof(Fp) * VERIFY3_OUTPUTS * cap));
+        HIPCHK(hipHostMalloc(&s->h_proofs, PROOFS_MIRROR_BYTES * cap));
+        s->cap_proofs = cap;
+    }
+    if ((rc = ws_reserve(s, m, 1, stage)) != KZG_OK) return rc;
+    uint8_t* const h = s->h_proofs;
+    pl.m = m;
+    pl.h_zy = reinterpret_cast<uint32_t*>(h);
+    pl.h_c = h + 64 * m;
+    pl.h_p = pl.h_c + 48 * m;
+    pl.h_pre = reinterpret_cast<uint32_t*>(pl.h_p + 48 * m);
+    pl.h_full = pl.h_pre + 2 * m;
+    pl.h_out = reinterpret_cast<Fp*>(pl.h_full + 2 * m);
+    pl.d_scal_in = s->d_proofs;
+    pl.d_v3in = s->d_proofs + (size_t)SCALARS_INPUTS * m;
+    return KZG_OK;
+}
+// streams B and C for m proofs: the square roots (two lanes per proof) -> VERIFY3's point inputs (event ev[6]); the full
+// decode of all 2 m points for the subgroup verdicts
+static KzgRet proofs_points_launch(const ProofStreams& ps, const ProofsLaunch& pl, const uint8_t* commitments, const uint8_t* proofs, const KzgSettings* s) {
+    const size_t m = pl.m;
+    memcpy(pl.h_c, commitments, 48 * m);
+    memcpy(pl.h_p, proofs, 48 * m);
+    for (size_t i = 0; i < 2 * m; i++) pl.h_pre[i] = pl.h_full[i] = G1_INVALID;
+    hipLaunchKernelGGL(k_proof_decompress, dim3((unsigned)((2 * m + 63) / 64)), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), ps.sb, pl.h_c, pl.h_p, (int)m,
+                       pl.d_v3in, pl.h_pre);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s->ev[6], ps.sb));
+    struct RestoreS2 {
+        const KzgSettings* s;
+        hipStream_t keep;
+        ~RestoreS2() { s->s2 = keep; }
+    } restore{s, s->s2};
+    s->s2 = ps.sc;
+    const KzgRet rc = launch_decode(s, pl.h_c, pl.h_p, m, /*behind_sha=*/false);
+    if (rc != KZG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(pl.h_full, s->ws.d_pflag, 8 * m, hipMemcpyDeviceToHost, ps.sc));
+    return KZG_OK;
+}
+// stream A for m proofs: z and y (8 little-endian limbs each, stride_words apart; pinned host or device memory; behind what
+// stream sa already holds) -> select -> SCALARS -> (points there) -> VERIFY3 -> the mirror; waits for A and C
+static KzgRet proofs_tail_locked(const ProofStreams& ps, const ProofsLaunch& pl, const uint32_t* z, const uint32_t* y, uint32_t stride_words, const KzgSettings* s) {
+    const size_t m = pl.m;
+    hipLaunchKernelGGL(k_proof_select, dim3((unsigned)m), dim3(128), 0, ps.sa, z, y, stride_words, s->d_fixed_base, s->d_tau4, pl.d_scal_in);
+    KzgRet rc = run_program2(s->scalars, pl.d_scal_in, nullptr, pl.d_v3in + 6, (int)m, ps.sa, 0, VERIFY3_INPUTS);
+    if (rc != KZG_OK) return rc;
+    if (ps.sb != ps.sa) HIPCHK(hipStreamWaitEvent(ps.sa, s->ev[6], 0));
+    HIPCHK(hipEventRecord(s->ev[4], ps.sa));
+    if ((rc = run_program2(s->verify3, pl.d_v3in, s->d_prep29, s->d_proofs_out, (int)m, ps.sa)) != KZG_OK) return rc;
+    HIPCHK(hipMemcpyAsync(pl.h_out, s->d_proofs_out, sizeof(Fp) * VERIFY3_OUTPUTS * m, hipMemcpyDeviceToHost, ps.sa));
+    HIPCHK(hipEventRecord(s->ev[9], ps.sa));
+    HIPCHK(hipStreamSynchronize(ps.sa));
+    if (ps.sc != ps.sa) HIPCHK(hipStreamSynchronize(ps.sc));
+    elapsed(&s->timings[3], s->ev[4], s->ev[9]);
+    elapsed(&s->timings[0], s->ev[0], s->ev[9]);
+    return KZG_OK;
+}
+// proof i of the launch: a point the reference would not parse / the pairing's verdict / Q_i is the identity (z_i = tau)
+struct ProofVerdict {
+    bool bad_commitment, bad_proof, equal, q_identity;
+};
+static ProofVerdict proofs_verdict(const ProofsLaunch& pl, size_t i) {
+    ProofVerdict r;
+    r.bad_commitment = pl.h_pre[2 * i] == G1_INVALID || pl.h_full[i] == G1_INVALID;
+    r.bad_proof = pl.h_pre[2 * i + 1] == G1_INVALID || pl.h_full[pl.m + i] == G1_INVALID;
+    const uint32_t* o = reinterpret_cast<const uint32_t*>(pl.h_out + VERIFY3_OUTPUTS * i);
+    uint32_t any = 0, zq = 0;
+    for (int k = 0; k < 72; k++) any |= o[k];
+    for (int k = 72; k < 96; k++) zq |= o[k];
+    r.equal = any == 0;
+    r.q_identity = zq == 0;
+    return r;
+}
+
+static KzgRet proofs_independent_locked(bool* ok_out, uint8_t* err, const uint8_t* commitments, const uint8_t* zs, const uint8_t* ys, const uint8_t* proofs,
+                                        size_t n, const KzgSettings* s, std::vector<size_t>& general) {
+    for (size_t first = 0; first < n; first += PROOFS_CHUNK) {
+        const size_t m = std::min(PROOFS_CHUNK, n - first);
+        ProofStreams ps{};
+        ProofsLaunch pl{};
+        KzgRet rc = proofs_reserve(ps, pl, m, STAGE_CP, s);
+        if (rc != KZG_OK) return rc;
+        uint8_t* const h_zy = reinterpret_cast<uint8_t*>(pl.h_zy);
+        for (size_t i = 0; i < m; i++) {
+            const size_t g = first + i;
+            err[g] = be_geq_r(zs + 32 * g) || be_geq_r(ys + 32 * g);  // (:360-371) - the instance still runs, its result is not looked at
+            reverse32(h_zy + 64 * i, zs + 32 * g);
+            reverse32(h_zy + 64 * i + 32, ys + 32 * g);
+        }
+        HIPCHK(hipEventRecord(s->ev[0], ps.sa));
+        if ((rc = proofs_points_launch(ps, pl, commitments + 48 * first, proofs + 48 * first, s)) != KZG_OK) return rc;
+        if ((rc = proofs_tail_locked(ps, pl, pl.h_zy, pl.h_zy + 8, 16u, s)) != KZG_OK) return rc;
+        for (size_t i = 0; i < m; i++) {
+            const size_t g = first + i;
+            const ProofVerdict r = proofs_verdict(pl, i);
+            if (r.bad_commitment || r.bad_proof) err[g] = 1;
+            ok_out[g] = !err[g] && r.equal;
+            if (!err[g] && r.q_identity) general.push_back(g);  // z = tau: the general path decides this one
+        }
+    }
+    return KZG_OK;
+}
+
+// A FEW blobs from host memory (verify_blob_kzg_proof_batch, src/kzg_proof.rs:472-525, at the sizes a beacon node calls it
+// with: the 6-9 blobs of one block): every blob gets its own pairing on its own CU instead of the random linear combination
+// (:399-444) - the combination exists to save pairings on a CPU; here 64 pairings side by side cost what one does, and the
+// decode -> MSM -> pairing chain of the combined form is the longer critical path (3.0 ms against 1.8 ms).  The result is the
+// conjunction of the n verify_blob_kzg_proof verdicts - the statement the combined check tests probabilistically: it holds
+// whenever this does, and could hold without it only if the hash-derived r hit one of at most n - 1 roots in Fr (2^-248).
+// Host: per-blob challenges on SHA-NI threads while the blobs cross PCIe; device: evaluation -> y; then the m-proof tail with
+// z and y read from device memory.  *general = true: some z_i = tau - the caller takes the combined path.
+static KzgRet blobs_small_locked(bool* ok, bool* general, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n, const KzgSettings* s) {
+    *general = false;
+    ProofStreams ps{};
+    ProofsLaunch pl{};
+    KzgRet rc = proofs_reserve(ps, pl, n, STAGE_BLOBS, s);
+    if (rc != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    uint8_t* const h_z = reinterpret_cast<uint8_t*>(pl.h_zy);  // (the mirror's z | y area: 32 n bytes of challenges)
+    uint32_t* const h_status = pl.h_zy + 8 * n;
+    std::thread hasher;
+    struct Join {
+        std::thread& t;
+        ~Join() {
+            if (t.joinable()) t.join();
+        }
+    } join_hasher{hasher};
+    const size_t threads = (size_t)std::max(1L, std::min(16L, opt_int("host_threads", 16)));
+    auto work = [&, threads] { host_blob_challenges(h_z, blobs, commitments, n, threads); };
+    bool hashed = false;
+    try {
+        hasher = std::thread(work);
+    } catch (const std::system_error&) {
+        work();
+        hashed = true;
+    }
+    HIPCHK(hipEventRecord(s->ev[0], ps.sa));
+    if ((rc = proofs_points_launch(ps, pl, commitments, proofs, s)) != KZG_OK) return rc;
+    HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * n, ps.sa));
+    HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, n * (size_t)BLOB_BYTES, hipMemcpyHostToDevice, ps.sa));  // (pageable: returns when the bytes have left)
+    if (!hashed) hasher.join();
+    HIPCHK(hipMemcpyAsync(w.d_z, h_z, 32 * n, hipMemcpyHostToDevice, ps.sa));
+    if ((rc = launch_evaluate(s, w.d_stage_blobs, w.d_z, w.d_y, w.d_status, n)) != KZG_OK) return rc;  // (on s->s1 = sa)
+    HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * n, hipMemcpyDeviceToHost, ps.sa));
+    if ((rc = proofs_tail_locked(ps, pl, reinterpret_cast<const uint32_t*>(w.d_z), reinterpret_cast<const uint32_t*>(w.d_y), 8u, s)) != KZG_OK) return rc;
+    bool all = true;
+    for (size_t i = 0; i < n; i++) {
+        const ProofVerdict r = proofs_verdict(pl, i);
+        // (every parse failure of the batch form is the same BadArgs: commitments, blobs - a non-canonical element - and proofs)
+        if (r.bad_commitment || r.bad_proof || h_status[i] != 0) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+        if (r.q_identity) *general = true;
+        all = all && r.equal;
+    }
+    *ok = all;
+    return KZG_OK;
+}
+
+extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitments, const uint8_t* zs, const uint8_t* ys,
+                                             const uint8_t* proofs, size_t n, const KzgSettings* s);
+extern "C" KzgRet kzg_verify_kzg_proofs(bool* ok_out, uint8_t* err_out, const uint8_t* commitments, const uint8_t* zs, const uint8_t* ys,
+                                        const uint8_t* proofs, size_t n, const KzgSettings* s) try {
+    if (!ok_out || !s) return fail(KZG_BADARGS, "null argument");
+    if (n == 0) return KZG_OK;
+    if (!commitments || !zs || !ys || !proofs) return fail(KZG_BADARGS, "null argument");
+    std::vector<uint8_t> err_local;
+    if (!err_out) err_local.resize(n);
+    uint8_t* const err = err_out ? err_out : err_local.data();
+    std::vector<size_t> general;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        HIPCHK(hipSetDevice(s->device));
+        const KzgRet rc = proofs_independent_locked(ok_out, err, commitments, zs, ys, proofs, n, s, general);
+        if (rc != KZG_OK) {
+            proof_drain(s);
+            return rc;
+        }
+    }
+    for (size_t g : general) {  // (z = tau under a setup whose secret the caller knows: test rigs)
+        bool one = false;
+        const KzgRet rc = kzg_verify_kzg_proof_batch(&one, commitments + 48 * g, zs + 32 * g, ys + 32 * g, proofs + 48 * g, 1, s);
+        if (rc == KZG_BADARGS) err[g] = 1;
+        else if (rc != KZG_OK) return rc;
+        ok_out[g] = rc == KZG_OK && one;
+    }
+    if (!err_out)
+        for (size_t i = 0; i < n; i++)
+            if (err[i]) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    return KZG_OK;
+} catch (const std::bad_alloc&) {
+    return fail(KZG_MALLOC, "host buffers of the call");
+}
+
 extern "C" KzgRet kzg_verify_kzg_proof(bool* ok, const uint8_t commitment[48], const uint8_t z[32], const uint8_t y[32],
                                        const uint8_t proof[48], const KzgSettings* s) {
     // src/kzg_proof.rs:353-397.  One proof at a time takes the reference's own equation (proof_single_locked); option
@@ -1187,9 +1416,31 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
         if (be_geq_r(zs + 32 * i) || be_geq_r(ys + 32 * i)) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
+    KzgRet rc;
+    // a few tuples: one pairing each, side by side on CUs of their own, and the conjunction of the verdicts (the reasoning at
+    // blobs_small_locked) - 1.7 ms against the 2.9 ms of decode -> MSM -> pairing.  option small_batch_pairings_max=0: always combined
+    static const size_t small_max = (size_t)std::max(0L, std::min(256L, opt_int("small_batch_pairings_max", 64)));
+    static const bool msm_path = opt_is("proof_path", "msm");
+    if (n >= 2 && n <= small_max && !msm_path) {
+        std::vector<uint8_t> verdicts(2 * n);
+        std::vector<size_t> general;
+        bool* const each = reinterpret_cast<bool*>(verdicts.data());
+        if ((rc = proofs_independent_locked(each, verdicts.data() + n, commitments, zs, ys, proofs, n, s, general)) != KZG_OK) {
+            proof_drain(s);
+            return rc;
+        }
+        if (general.empty()) {  // (some z_i = tau: the combined path below decides)
+            bool all = true;
+            for (size_t i = 0; i < n; i++) {
+                if (verdicts[n + i]) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+                all = all && each[i];
+            }
+            *ok = all;
+            return KZG_OK;
+        }
+    }
     select_streams(s, n);
-    KzgRet rc = ws_reserve(s, n, 1, STAGE_CP);
-    if (rc != KZG_OK) return rc;
+    if ((rc = ws_reserve(s, n, 1, STAGE_CP)) != KZG_OK) return rc;
     Workspace& w = s->ws;
     HIPCHK(hipEventRecord(s->ev[0], s->s1));
     // z, y: big-endian -> the device's little-endian limb arrays (= the transcript's encoding)

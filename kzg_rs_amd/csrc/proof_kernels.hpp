@@ -21,10 +21,14 @@ constexpr int SCALARS_INPUTS = FB_WINDOWS * (int)(FB_G2_FP + FB_G1_FP) + 4;  // 
 constexpr int VERIFY3_INPUTS = 9 + 68 * 6 + 2;                                 // pi, C, [y]G, the lines of Q, Z of Q
 constexpr int VERIFY3_OUTPUTS = 8;                                             // the six pairing coefficients, Z.c0 and Z.c1 of Q
 
-// z, y: 8 little-endian 32-bit limbs each (canonical; pinned host memory or device memory)
-__global__ __launch_bounds__(128) void k_proof_select(const uint32_t* __restrict__ z, const uint32_t* __restrict__ y, const Fp* __restrict__ table,
-                                                      const Fp* __restrict__ tau4, Fp* __restrict__ out) {
+// One workgroup per proof.  z, y: 8 little-endian 32-bit limbs each (canonical; pinned host memory or device memory), instance i
+// at z + i * stride_words / y + i * stride_words; out: SCALARS' input record of instance i at out + i * SCALARS_INPUTS.
+__global__ __launch_bounds__(128) void k_proof_select(const uint32_t* __restrict__ z, const uint32_t* __restrict__ y, uint32_t stride_words,
+                                                      const Fp* __restrict__ table, const Fp* __restrict__ tau4, Fp* __restrict__ out) {
     const int t = threadIdx.x;
+    z += (size_t)blockIdx.x * stride_words;
+    y += (size_t)blockIdx.x * stride_words;
+    out += (size_t)blockIdx.x * SCALARS_INPUTS;
     if (t < 2 * FB_WINDOWS) {
         const bool g1 = t >= FB_WINDOWS;
         const int w = g1 ? t - FB_WINDOWS : t;
@@ -38,26 +42,29 @@ __global__ __launch_bounds__(128) void k_proof_select(const uint32_t* __restrict
     }
 }
 
-// cp: the 48 compressed bytes of C, then those of pi.  v3in[0..2] = pi, v3in[3..5] = C (VERIFY3's first six inputs);
-// flags[0] = status of C, flags[1] = status of pi (G1_OK / G1_INFINITY / G1_INVALID; the subgroup is NOT tested here).
-__global__ __launch_bounds__(64) void k_proof_decompress(const uint8_t* __restrict__ cp, Fp* __restrict__ v3in, uint32_t* __restrict__ flags) {
+// Two lanes per proof: lane 2 i decompresses commitments[i], lane 2 i + 1 proofs[i] (48 compressed bytes each) - all the
+// square roots of a wavefront in the same instructions.  v3in: VERIFY3's input record of proof i at v3in + i * VERIFY3_INPUTS,
+// [0..2] = pi, [3..5] = C.  flags[2 i] = status of C, flags[2 i + 1] = status of pi (G1_OK / G1_INFINITY / G1_INVALID; the
+// subgroup is NOT tested here).
+__global__ __launch_bounds__(64) void k_proof_decompress(const uint8_t* __restrict__ commitments, const uint8_t* __restrict__ proofs, int n,
+                                                         Fp* __restrict__ v3in, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint4 proof_park4[];  // PARK_UINT4_PER_THREAD per thread
-    const int lane = threadIdx.x;
-    if (lane >= 2) return;
-    const LdsPark pk = lds_park(proof_park4 + lane, blockDim.x);
+    const int t = blockIdx.x * 64 + threadIdx.x, inst = t >> 1, which = t & 1;
+    if (inst >= n) return;
+    const LdsPark pk = lds_park(proof_park4 + threadIdx.x, blockDim.x);
     Fp29 x, y;
-    const uint32_t st = g1_decompress29(x, y, cp + 48 * lane, pk);
-    Fp* const o = v3in + (lane == 0 ? 3 : 0);
+    const uint32_t st = g1_decompress29(x, y, (which ? proofs : commitments) + (size_t)48 * inst, pk);
+    Fp* const o = v3in + (size_t)inst * VERIFY3_INPUTS + (which ? 0 : 3);
     if (st == G1_OK) {
         o[0] = fp29_to_std(x);
         o[1] = fp29_to_std(y);
         o[2] = FpF::one();
-    } else {  // the identity (and a rejected encoding: the call fails on its flag, the pairing's result is not looked at)
+    } else {  // the identity (and a rejected encoding: the proof fails on its flag, the pairing's result is not looked at)
         o[0] = FpF::zero();
         o[1] = FpF::one();
         o[2] = FpF::zero();
     }
-    flags[lane] = st;
+    flags[2 * inst + which] = st;
 }
 
 }  // namespace kzg

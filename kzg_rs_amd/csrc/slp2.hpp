@@ -141,11 +141,13 @@ __device__ __forceinline__ void slp2_exec_load(uint32_t* slots, const uint4 d, c
 // prefetched descriptors must stay in them: spilled, the loads would be waited for at once)
 template <int LANES>
 __global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_slp2_run(Slp2Program prog, const Fp* __restrict__ inputs, const uint32_t* __restrict__ settings_inputs,
-                                                    Fp* __restrict__ outputs) {
+                                                    Fp* __restrict__ outputs, uint32_t in_stride, uint32_t out_stride) {
+    // in_stride / out_stride: elements between two instances' inputs / outputs (>= n_in / n_out: one program's outputs can land
+    // inside the next one's input records)
     extern __shared__ __attribute__((aligned(16))) uint32_t slots2[];
     const uint32_t tid = threadIdx.x, inst = blockIdx.x, n_steps = prog.n_steps - prog.n_load_steps;
     uint4* ring = reinterpret_cast<uint4*>(slots2 + (size_t)SLP2_SLOT_WORDS * prog.n_slots);  // [SLP2_GROUP][LANES]
-    const Fp* my_in = inputs + (size_t)inst * prog.n_in;
+    const Fp* my_in = inputs + (size_t)inst * in_stride;
     if (tid < SLP2_SLOT_WORDS) slots2[tid] = 0u;  // slot 0: the constant zero
     // the LOAD prefix (a handful of steps; independent of one another: one barrier after the last)
     for (uint32_t st = 0; st < prog.n_load_steps; st++)
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(LANES) __attribute__((amdgpu_waves_per_eu(1, 1))) v
             for (int i = 0; i < 12; i++) o.l[i] = 0u;
             o.l[0] = z ? 0u : 1u;
         }
-        outputs[(size_t)inst * prog.n_out + oi] = o;
+        outputs[(size_t)inst * out_stride + oi] = o;
     }
 }
 

@@ -1249,6 +1249,91 @@ def test_verify_kzg_proof_both_paths_and_the_z_equals_tau_corner():
     assert [call(*cases[i], sst) for i in (0, 1, 2, 3, 4, 10)] == [True, False, True, False, None, True]
 
 
+def test_verify_kzg_proofs_independent_verdicts():
+    """kzg_verify_kzg_proofs: n INDEPENDENT verify_kzg_proof calls (src/kzg_proof.rs:353-397) through one C call, one program
+    instance per proof, each with its own pairing and its own verdict.  (a) every well-sized reference vector (true, false
+    and Err cases side by side) in ONE call: entry i equals vector i's expected output, null <=> Err.  (b) under the known-tau
+    setup, 2 100 proofs (three launches: 1 024 + 1 024 + 52) with wrong y / wrong z / swapped proofs, points at infinity,
+    off-subgroup and off-curve encodings and out-of-range scalars sprinkled in: every entry equals the one-proof entry point's
+    answer, spot-checked against the oracle, and z = tau entries (general path) among them.  (c) without err_out the first
+    Err fails the whole call; n = 0; unequal lengths."""
+    import ctypes as C
+    from kzg_rs_amd import synth
+    st = api.KzgSettings.load_trusted_setup_file()
+    cols, want = [[], [], [], []], []
+    for c in G.vectors()["verify_kzg_proof"]:
+        args = [bytes.fromhex(c[k][2:] if c[k].startswith("0x") else c[k]) for k in ("commitment", "z", "y", "proof")]
+        if any(len(a) != n for a, n in zip(args, (48, 32, 32, 48))):
+            continue
+        for col, a in zip(cols, args):
+            col.append(a)
+        want.append(c["output"])
+    assert len(want) > 100 and {True, False, None} <= set(want)
+    assert api.verify_kzg_proofs(*cols, st) == want
+    # (b)
+    tau, tau_g2 = synth.synthetic_setup()
+    sst = api.KzgSettings.from_tau_g2(tau_g2)
+    osst = O.Settings.from_tau_g2(tau_g2)
+    n = 2100
+    cs, zs, ys, ps, _ = synth.make_valid_proofs(n, seed=33, settings=sst)
+    cs, zs, ys, ps = list(cs), list(zs), list(ys), list(ps)
+    off = G.off_subgroup_g1()
+    notcurve = bytes([0x80]) + bytes(46) + b"\x01"
+    expect = [True] * n
+    for i in range(0, n, 7):
+        kind = (i // 7) % 10
+        if kind == 0:
+            ys[i], expect[i] = ys[(i + 1) % n], False
+        elif kind == 1:
+            zs[i], expect[i] = zs[(i + 1) % n], False
+        elif kind == 2:
+            ps[i], expect[i] = ps[(i + 1) % n], False
+        elif kind == 3:
+            cs[i], expect[i] = off, None
+        elif kind == 4:
+            ps[i], expect[i] = notcurve, None
+        elif kind == 5:
+            zs[i], expect[i] = (R + i).to_bytes(32, "big"), None
+        elif kind == 6:
+            ys[i], expect[i] = (2 ** 256 - 1 - i).to_bytes(32, "big"), None
+        elif kind == 7:  # pi = O with C = [y]G
+            cs[i], ps[i] = api.g1_mul_generator([ys[i]], sst)[0], G1_INF
+        elif kind == 8:  # z = tau: the equation reads C == [y]G whatever pi is (general path)
+            zs[i] = tau.to_bytes(32, "big")
+            if (i // 70) % 2:
+                cs[i] = api.g1_mul_generator([ys[i]], sst)[0]
+            else:
+                expect[i] = False
+        else:  # the zero polynomial
+            cs[i], ys[i], ps[i] = G1_INF, bytes(32), G1_INF
+    got = api.verify_kzg_proofs(cs, zs, ys, ps, sst)
+    assert got == expect, [(i, got[i], expect[i]) for i in range(n) if got[i] != expect[i]][:10]
+    for i in list(range(0, 140, 7)) + [1, 2, 1023, 1024, 2047, 2048, 2099]:
+        try:
+            w = O.verify_kzg_proof(cs[i], zs[i], ys[i], ps[i], osst)
+        except O.OracleError:
+            w = None
+        assert got[i] is w, i
+        try:
+            one = KzgProof.verify_kzg_proof(Bytes48(cs[i]), Bytes32(zs[i]), Bytes32(ys[i]), Bytes48(ps[i]), sst)
+        except KzgError:
+            one = None
+        assert one is w, i
+    # (c)
+    ok = (C.c_bool * 8)()
+    raw = lambda xs: b"".join(xs)
+    rc = api.lib().kzg_verify_kzg_proofs(ok, None, raw(cs[:8]), raw(zs[:8]), raw(ys[:8]), raw(ps[:8]), 8, sst._h)
+    assert rc == 0 and list(ok) == [e is True for e in expect[:8]]  # (entry 0 is a wrong y, entry 7 a wrong z: false, no Err)
+    rc = api.lib().kzg_verify_kzg_proofs(ok, None, raw(cs[20:28]), raw(zs[20:28]), raw(ys[20:28]), raw(ps[20:28]), 8, sst._h)
+    assert None in expect[20:28] and rc == 1 and b"G1Affine" in api.lib().kzg_last_error()
+    assert api.verify_kzg_proofs([], [], [], [], sst) == []
+    with pytest.raises(KzgError):
+        api.verify_kzg_proofs(cs[:2], zs[:1], ys[:2], ps[:2], sst)
+    # the handle still serves the other entry points afterwards
+    assert KzgProof.verify_kzg_proof_batch([Bytes48(x) for x in cs[1:6]], [Bytes32(x) for x in zs[1:6]], [Bytes32(x) for x in ys[1:6]],
+                                           [Bytes48(x) for x in ps[1:6]], sst) is True
+
+
 def test_small_host_batches_hash_on_the_host_or_on_the_gpu_with_the_same_results():
     """Host batches of up to 256 blobs take their Fiat-Shamir challenges from the host's SHA-NI cores (beside the point decode;
     one blob: plus the one-proof tail), larger and device-resident ones from the GPU's SHA-256 kernels.  All 29 + 27 + 24
