@@ -128,7 +128,11 @@ KzgRet kzg_verify_kzg_proofs(bool *ok_out, uint8_t *err_out, const uint8_t *comm
  * random linear combination (r from compute_r_powers, :291-348) and ONE pairing.  The reference takes decoded
  * &[G1Affine] / &[Scalar]; across the C ABI they are n*48 compressed bytes and n*32 big-endian canonical bytes in
  * HOST memory, decoded on the device with the same checks as Bytes48/Bytes32 decoding (:17-43) - an undecodable
- * point or a non-canonical scalar is KZG_BADARGS.  n == 0 -> *ok = true (both sides are the identity). */
+ * point or a non-canonical scalar is KZG_BADARGS.  n == 0 -> *ok = true (both sides are the identity).
+ * 2 <= n <= 256 (KZG_OPTIONS small_batch_pairings_max): the same answer as the CONJUNCTION of n one-proof checks, one pairing
+ * per tuple on a CU of its own (1.7-2.6 ms against 2.9 ms for decode -> MSM -> pairing).  The combination is a probabilistic
+ * test of exactly that conjunction: it holds whenever the conjunction does, and could hold without it only if the
+ * hash-derived r were a root of a fixed non-zero polynomial of degree < n over Fr (probability < 2^-246). */
 KzgRet kzg_verify_kzg_proof_batch(bool *ok, const uint8_t *commitments, const uint8_t *zs, const uint8_t *ys,
                                   const uint8_t *proofs, size_t n, const KzgSettings *s);
 /* KzgProof::verify_blob_kzg_proof (src/kzg_proof.rs:446-470).  Host memory: the blob's Fiat-Shamir hash (:46-72) runs on the
@@ -142,7 +146,11 @@ KzgRet kzg_verify_blob_kzg_proof(bool *ok, const uint8_t *blob, const uint8_t co
  * Where the per-blob SHA-256 chains (:46-72) run: a HOST batch of up to 256 blobs (KZG_OPTIONS host_challenge_max_blobs) has
  * them hashed on up to 16 host threads beside the GPU's point decode - a chain is 2.8 ms on GPU lanes however few blobs
  * there are and 65 us on a SHA-NI core; larger host batches cross PCIe in slices with the chains running on the GPU behind
- * them, and device-resident input always hashes on the GPU.  Field and curve arithmetic is never done on the host. */
+ * them, and device-resident input always hashes on the GPU.  Field and curve arithmetic is never done on the host.
+ * The sizes a beacon node calls this with (the 6-9 blobs of a block; up to KZG_OPTIONS small_batch_pairings_max = 256 host
+ * blobs): every blob gets its own pairing, side by side on CUs of their own, and *ok is the conjunction of the n
+ * verify_blob_kzg_proof verdicts - 1.8-3.2 ms instead of 3.0-3.7 ms; see kzg_verify_kzg_proof_batch for why that is the
+ * same answer.  small_batch_pairings_max=0 keeps the combined form at every size. */
 KzgRet kzg_verify_blob_kzg_proof_batch(bool *ok, const uint8_t *blobs, const uint8_t *commitments,
                                        const uint8_t *proofs, size_t n, const KzgSettings *s);
 /* Same, with all three arrays already resident in DEVICE memory (HBM) - the form the throughput

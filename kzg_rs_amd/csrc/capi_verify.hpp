@@ -850,7 +850,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
         }
         if (!general) return KZG_OK;
     }
-    static const size_t small_max = (size_t)std::max(0L, std::min(256L, opt_int("small_batch_pairings_max", 64)));
+    static const size_t small_max = (size_t)std::max(0L, std::min(256L, opt_int("small_batch_pairings_max", 256)));
     if (n >= 2 && n <= small_max && n <= host_max && !msm_path) {  // a few blobs: one pairing each, side by side (blobs_small_locked)
         bool general = false;
         if ((rc = blobs_small_locked(ok, &general, blobs, commitments, proofs, n, s)) != KZG_OK) {
@@ -1419,7 +1419,7 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
     KzgRet rc;
     // a few tuples: one pairing each, side by side on CUs of their own, and the conjunction of the verdicts (the reasoning at
     // blobs_small_locked) - 1.7 ms against the 2.9 ms of decode -> MSM -> pairing.  option small_batch_pairings_max=0: always combined
-    static const size_t small_max = (size_t)std::max(0L, std::min(256L, opt_int("small_batch_pairings_max", 64)));
+    static const size_t small_max = (size_t)std::max(0L, std::min(256L, opt_int("small_batch_pairings_max", 256)));
     static const bool msm_path = opt_is("proof_path", "msm");
     if (n >= 2 && n <= small_max && !msm_path) {
         std::vector<uint8_t> verdicts(2 * n);

@@ -27,6 +27,7 @@ extern "C" {
     pub fn kzg_settings_g2_point(s: *const RawSettings, i: usize, out: *mut u8) -> c_int;
     pub fn kzg_verify_kzg_proof(ok: *mut bool, commitment: *const u8, z: *const u8, y: *const u8, proof: *const u8, s: *const RawSettings) -> c_int;
     pub fn kzg_verify_kzg_proof_batch(ok: *mut bool, commitments: *const u8, zs: *const u8, ys: *const u8, proofs: *const u8, n: usize, s: *const RawSettings) -> c_int;
+    pub fn kzg_verify_kzg_proofs(ok_out: *mut bool, err_out: *mut u8, commitments: *const u8, zs: *const u8, ys: *const u8, proofs: *const u8, n: usize, s: *const RawSettings) -> c_int;
     pub fn kzg_verify_blob_kzg_proof(ok: *mut bool, blob: *const u8, commitment: *const u8, proof: *const u8, s: *const RawSettings) -> c_int;
     pub fn kzg_verify_blob_kzg_proof_batch(ok: *mut bool, blobs: *const u8, commitments: *const u8, proofs: *const u8, n: usize, s: *const RawSettings) -> c_int;
     pub fn kzg_pairings_verify(ok: *mut bool, a1: *const u8, a2: *const u8, b1: *const u8, b2: *const u8, s: *const RawSettings) -> c_int;

@@ -50,6 +50,41 @@ impl KzgProof {
         Ok(ok)
     }
 
+    /// Not in kzg-rs: n independent `verify_kzg_proof` calls (`src/kzg_proof.rs:353-397`) through one library call, each
+    /// proof with its own pairing and its own result - what a caller looping over `verify_kzg_proof` (the revm point
+    /// evaluation precompile, one call per transaction) would write.  Entry i is what `verify_kzg_proof` returns for
+    /// tuple i.  The four slices must have equal lengths.
+    pub fn verify_kzg_proofs(
+        commitment_bytes: &[Bytes48],
+        zs: &[Bytes32],
+        ys: &[Bytes32],
+        proof_bytes: &[Bytes48],
+        kzg_settings: &KzgSettings,
+    ) -> Result<Vec<Result<bool, KzgError>>, KzgError> {
+        let n = commitment_bytes.len();
+        if zs.len() != n || ys.len() != n || proof_bytes.len() != n {
+            return Err(KzgError::InvalidBytesLength("verify_kzg_proofs: slices of unequal length".to_string()));
+        }
+        let mut ok = vec![false; n];
+        let mut err = vec![0u8; n];
+        // (`Bytes32` / `Bytes48` are `repr(transparent)` byte arrays: the slices are handed over as they lie in memory)
+        ffi::check(unsafe {
+            ffi::kzg_verify_kzg_proofs(
+                ok.as_mut_ptr(),
+                err.as_mut_ptr(),
+                commitment_bytes.as_ptr() as *const u8,
+                zs.as_ptr() as *const u8,
+                ys.as_ptr() as *const u8,
+                proof_bytes.as_ptr() as *const u8,
+                n,
+                kzg_settings.raw(),
+            )
+        })?;
+        Ok((0..n)
+            .map(|i| if err[i] != 0 { Err(KzgError::BadArgs("Failed to parse G1Affine from bytes".to_string())) } else { Ok(ok[i]) })
+            .collect())
+    }
+
     /// kzg-rs `src/kzg_proof.rs:446-470`.
     pub fn verify_blob_kzg_proof(blob: Blob, commitment_bytes: &Bytes48, proof_bytes: &Bytes48, kzg_settings: &KzgSettings) -> Result<bool, KzgError> {
         let mut ok = false;

@@ -1335,12 +1335,13 @@ def test_verify_kzg_proofs_independent_verdicts():
 
 
 def test_small_host_batches_hash_on_the_host_or_on_the_gpu_with_the_same_results():
-    """Host batches of up to 256 blobs take their Fiat-Shamir challenges from the host's SHA-NI cores (beside the point decode;
-    one blob: plus the one-proof tail), larger and device-resident ones from the GPU's SHA-256 kernels.  All 29 + 27 + 24
-    reference vectors for the two blob entry points in this process (host hashing: every batch vector has at most 7 blobs)
-    and again in a child process with KZG_OPTIONS=host_challenge_max_blobs=0 (GPU hashing, round 3's behaviour): strict
-    null <=> Err both ways; and a synthetic 40-blob host batch - valid, a wrong proof, a non-canonical element in the last
-    blob, an off-subgroup proof - against the oracle through both."""
+    """Host batches of up to 256 blobs take their Fiat-Shamir challenges from the host's SHA-NI cores and, by default, ONE
+    PAIRING PER BLOB side by side (blobs_small_locked: the conjunction of the per-blob verdicts instead of the random linear
+    combination); larger and device-resident ones hash on the GPU and take the combined form.  All 29 + 27 + 24 reference
+    vectors for the two blob entry points (every batch vector has at most 7 blobs) in three child processes - the default,
+    KZG_OPTIONS=small_batch_pairings_max=0 (host hashing, combined form) and host_challenge_max_blobs=0 (GPU hashing, combined
+    form: round 3's behaviour): strict null <=> Err in each; and a synthetic 40-blob host batch - valid, a wrong proof, a
+    non-canonical element in the last blob, an off-subgroup proof - against the oracle through all three."""
     import ctypes as C
     import subprocess
     import sys
@@ -1383,6 +1384,6 @@ def test_small_host_batches_hash_on_the_host_or_on_the_gpu_with_the_same_results
             "res = [run(blobs, ps), run(blobs, wrong), run(bb, ps), run(blobs, offp)]\n"
             "bad += res != [want(blobs, ps), want(blobs, wrong), want(bb, ps), want(blobs, offp)] or res != [True, False, None, None]\n"
             "print('SMALL-HOST mismatches', bad)\n" % (O.ROOT, os.path.join(O.ROOT, "tests")))
-    for opts in ("", "host_challenge_max_blobs=0"):
+    for opts in ("", "small_batch_pairings_max=0", "host_challenge_max_blobs=0"):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_OPTIONS=opts), capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "SMALL-HOST mismatches 0" in out.stdout, (opts, out.stdout[-500:], out.stderr[-2000:])

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import golden_data as G
 import oracle_lib as O
+from kzg_rs_amd import api
 from kzg_rs_amd.api import Blob, Bytes32, Bytes48, KzgError, KzgProof, KzgSettings
 
 R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
@@ -118,5 +119,10 @@ while time.time() < t_end:
     got = res(lambda: KzgProof.verify_kzg_proof(Bytes48(tc[0]), Bytes32(tz[0]), Bytes32(ty[0]), Bytes48(tp[0]), st))
     if got != want:
         print("MISMATCH single proof seed=%d case=%d got=%r want=%r" % (seed, cases, got, want)); sys.exit(1)
+    # the same tuples as m INDEPENDENT proofs through one call: entry i = verify_kzg_proof of tuple i
+    wants = [res(lambda: O.verify_kzg_proof(tc[i], tz[i], ty[i], tp[i], ost)) for i in range(m)]
+    gots = api.verify_kzg_proofs(tc, tz, ty, tp, st)
+    if gots != wants:
+        print("MISMATCH independent proofs seed=%d case=%d got=%r want=%r" % (seed, cases, gots, wants)); sys.exit(1)
     cases += 1
-print("fuzz campaign seed=%d: %d cases x 3 entry points, no mismatch; blob-batch outcomes %s" % (seed, cases, counts))
+print("fuzz campaign seed=%d: %d cases x 4 entry points, no mismatch; blob-batch outcomes %s" % (seed, cases, counts))

@@ -20,7 +20,7 @@ def call(n, proofs):
     return bool(ok.value)
 
 
-for n in (1, 2, 4, 6, 9, 16, 32, 64, 65, 128, 256, 512, 1024):
+for n in (1, 2, 4, 6, 9, 16, 32, 64, 65, 96, 128, 192, 256, 512, 1024):
     bad = list(ps)
     bad[n - 1] = ps[n % 1024] if n < 1024 else ps[0]
     assert call(n, ps) is True and call(n, bad) is False, n
