@@ -52,7 +52,7 @@ ALG_BYTES = {
     "k_msm": 3 * 128,                               # three (point, scalar) terms per blob, 96 + 32 B each
     "k_slp_run(pairing)": 0,
 }
-PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge", "k_blob_evaluate": "kzg::k_blob_evaluate_t<true>",
+PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge_t<4>", "k_blob_evaluate": "kzg::k_blob_evaluate_t<true>",
             "k_g1_decode_multiples": "kzg::k_g1_decode_multiples29<4, true>", "k_msm": "kzg::k_msm_window<kzg::Curve29Aff, true>",
             "k_slp_run(pairing)": "kzg::k_slp_run<false>"}
 PMC_FILES = ("r4_pmc.json", "r3_pmc.json")  # newest first; the first that exists is used (kernel names must match PMC_NAME)
@@ -419,7 +419,14 @@ def main():
         t, c = h.timing_totals(reset=True)  # the warm-up groups do not count (kept apart for the profiler cross-check below)
         warm_sum5 += t[5]
         warm_cnt += c
+        h.shader_clock(reset=True)
     elapsed, _ = timed(lambda: run_groups(K))
+    clk_cycles = clk_ticks = 0.0
+    for h in handles:  # the clock the SIMDs ran at during the timed region (every wave of the challenge kernel stamps it)
+        a, b = h.shader_clock(reset=True)
+        clk_cycles += a
+        clk_ticks += b
+    shader_mhz = 100.0 * clk_cycles / clk_ticks if clk_ticks else None
     # kernel times: on the library's own streams, AVERAGED over every launch group of the timed region (all handles)
     # - the quantity rocprofv3 --stats reports as the kernel's average duration for the same command
     sums, cnt = [0.0] * 8, 0
@@ -499,6 +506,8 @@ def main():
     self_check = None
     proof_ms = None
     blob_ms = None
+    small_ms = None
+    proofs_per_s = None
     solo_sums, solo_cnt = [0.0] * 8, 0
     sc_sums, sc_cnt = [0.0] * 8, 0
     if not args.no_self_check:
@@ -591,6 +600,27 @@ def main():
                 ts.append(time.perf_counter() - t0)
             assert okb is True
             blob_ms = round(sorted(ts[4:])[8] * 1e3, 4)
+            # a block's worth of blobs from host memory (the size a beacon node calls verify_blob_kzg_proof_batch with): median of 16
+            import ctypes as C
+            okc = C.c_bool(False)
+            raw6 = (blobs[:6].tobytes(), b"".join(cs[:6]), b"".join(ps[:6]))
+            ts = []
+            for _ in range(20):
+                t0 = time.perf_counter()
+                api._chk(api.lib().kzg_verify_blob_kzg_proof_batch(C.byref(okc), raw6[0], raw6[1], raw6[2], 6, settings._h))
+                ts.append(time.perf_counter() - t0)
+            assert okc.value is True
+            small_ms = round(sorted(ts[4:])[8] * 1e3, 4)
+            # 1 024 INDEPENDENT proofs, a verdict each, through one call (kzg_verify_kzg_proofs): median of 5 calls
+            qc, qz, qy, qp, _ = synth.make_valid_proofs(1024, seed=6, settings=settings)
+            qy[7] = qy[8]  # one wrong claim: exactly that verdict must be False
+            ts = []
+            for _ in range(6):
+                t0 = time.perf_counter()
+                verdicts = api.verify_kzg_proofs(qc, qz, qy, qp, settings)
+                ts.append(time.perf_counter() - t0)
+            assert verdicts == [i != 7 for i in range(1024)]
+            proofs_per_s = round(1024 / sorted(ts[1:])[2])
     backend_name = dist.get_backend() if dist else None
     if dist:
         # every rank leaves its GPU before rank 0 reports (and, at N > 1, drives all of them from one process)
@@ -641,8 +671,12 @@ def main():
         simds, clock = 1024, 2.4e9
         valu = {"wave_insts_per_blob": round(per_blob), "insts_per_cycle_per_simd": round(per_blob * (n * G * K / elapsed) / (simds * clock), 4),
                 "cycles_per_inst": round((simds * clock) / (per_blob * (n * G * K / elapsed)), 3),
+                "shader_clock_mhz_measured": round(shader_mhz, 1) if shader_mhz else None,
+                "cycles_per_inst_at_measured_clock": round((simds * shader_mhz * 1e6) / (per_blob * (n * G * K / elapsed)), 3) if shader_mhz else None,
                 "ceiling_insts_per_cycle_per_simd": {"multiply_add_kernels (evaluate, decode, MSM window, MSM reduce)": 0.238, "sha256 (k_blob_challenge)": 0.256},
-                "note": "VALU wave-instructions issued per SIMD cycle at the measured throughput (SQ_INSTS_VALU of every kernel of the path, profiles/"
+                "note": "insts_per_cycle_per_simd / cycles_per_inst assume the nominal 2.4 GHz; shader_clock_mhz_measured is what the SIMDs ran at during "
+                        "the timed region (s_memtime / s_memrealtime stamped by every wave of k_blob_challenge) and cycles_per_inst_at_measured_clock "
+                        "the figure to hold against the ceilings.  VALU wave-instructions issued per SIMD cycle at the measured throughput (SQ_INSTS_VALU of every kernel of the path, profiles/"
                         + pmc_file + ").  Ceilings per kernel class, from the builder's microbenchmarks: the multiply-add kernels are v_mad_u64_u32 / "
                         "carry-chain code at 4.2 cycles per wave-instruction on a saturated SIMD = 0.238 (profiles/r1_issuebench_valu_issue_cost.txt; "
                         "with the 2-4 wavefronts per SIMD their register budgets allow: 5.5 / 5.15 / 4.9 cycles, profiles/r3_depbench_mad_issue_vs_occupancy.txt); "
@@ -711,6 +745,8 @@ def main():
         "end_to_end": end2end,
         "verify_kzg_proof_ms": proof_ms,
         "verify_blob_kzg_proof_ms": blob_ms,
+        "verify_blob_kzg_proof_batch_6_host_blobs_ms": small_ms,
+        "verify_kzg_proofs_independent_per_s": proofs_per_s,
     }
     if world > 1:
         g = max(pipe.stats["groups"], 1)  # warm-up groups included; per-step averages of THIS rank's host time

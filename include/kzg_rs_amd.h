@@ -314,6 +314,11 @@ KzgRet kzg_pairings_verify(bool *ok, const uint8_t a1[48], const uint8_t a2[96],
 KzgRet kzg_last_timings(const KzgSettings *s, float out_ms[8]);
 /* The same intervals summed over every launch group finished on this handle since the last reset; *count = groups. */
 KzgRet kzg_timing_totals(const KzgSettings *s, double out_sum_ms[8], uint64_t *count, int reset);
+/* Diagnostic: the shader clock the throughput-form challenge kernel (k_blob_challenge) really ran at since the last reset:
+ * out = { shader cycles (s_memtime), 100 MHz reference ticks (s_memrealtime) } summed over its waves on this handle and its
+ * pipeline lanes; MHz = 100 * out[0] / out[1] (0 / 0 when that kernel has not run).  bench.py prices cycles per instruction
+ * with it instead of the nominal 2.4 GHz. */
+KzgRet kzg_debug_shader_clock(const KzgSettings *s, double out[2], int reset);
 
 const char *kzg_last_error(void);
 

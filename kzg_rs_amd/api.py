@@ -134,6 +134,7 @@ def lib():
         L.kzg_g1_mul_generator.argtypes = [u8, u8, sz, vp]
         L.kzg_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
         L.kzg_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        L.kzg_debug_shader_clock.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
         L.kzg_last_error.restype = C.c_char_p
         _lib = L
     return _lib
@@ -298,6 +299,13 @@ class KzgSettings:
         t, c = (C.c_double * 8)(), C.c_uint64(0)
         _chk(lib().kzg_timing_totals(self._h, t, C.byref(c), int(reset)))
         return list(t), int(c.value)
+
+    def shader_clock(self, reset=False):
+        """(shader cycles, 100 MHz reference ticks) summed over the waves of the throughput-form challenge kernel since the last
+        reset: MHz = 100 * cycles / ticks"""
+        o = (C.c_double * 2)()
+        _chk(lib().kzg_debug_shader_clock(self._h, o, int(reset)))
+        return float(o[0]), float(o[1])
 
     def close(self):
         if self._h:

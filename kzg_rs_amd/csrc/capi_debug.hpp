@@ -114,3 +114,23 @@ extern "C" KzgRet kzg_timing_totals(const KzgSettings* s, double out_sum_ms[8], 
     }
     return KZG_OK;
 }
+
+// diagnostic (bench.py `valu`): the shader clock the throughput-form challenge kernel ran at since the last reset - every wave
+// of it reads s_memtime (shader cycles) and s_memrealtime (100 MHz) at its start and end; out = { sum of cycles, sum of ticks }
+// over this handle and its pipeline lanes: MHz = 100 * out[0] / out[1].  The chip's DVFS decides this figure, and every
+// cycles-per-instruction statement about the path depends on it.
+extern "C" KzgRet kzg_debug_shader_clock(const KzgSettings* s, double out[2], int reset) {
+    if (!s || !out) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    out[0] = s->clk_sum[0];
+    out[1] = s->clk_sum[1];
+    for (const KzgSettings* l : s->lanes) {
+        out[0] += l->clk_sum[0];
+        out[1] += l->clk_sum[1];
+    }
+    if (reset) {
+        s->clk_sum[0] = s->clk_sum[1] = 0;
+        for (const KzgSettings* l : s->lanes) l->clk_sum[0] = l->clk_sum[1] = 0;
+    }
+    return KZG_OK;
+}

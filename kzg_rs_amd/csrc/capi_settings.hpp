@@ -98,6 +98,7 @@ struct KzgSettings {
     mutable float timings[8] = {};
     mutable double tsum[8] = {};   // the same, summed over every group finished on this handle since the last reset
     mutable uint64_t tcount = 0;
+    mutable double clk_sum[2] = {};  // shader cycles | 100 MHz reference ticks of the throughput-form challenge kernel's waves
     // A multi-device handle (capi_multi.hpp): this handle is shard 0 on the first device of the list and a complete
     // single-device handle in its own right; `peers` are the (private) single-device handles of the other entries, `multi`
     // the device list and the exchange (in-process RCCL communicators, or host staging).

@@ -78,10 +78,19 @@ static KzgRet launch_challenge(const KzgSettings* s, const void* d_blobs, const 
     if (form == 1) {
         unsigned long long* kt = s->ws.d_ktime;  // null for callers that never reserved the workspace
         if (kt) {
-            HIPCHK(hipMemsetAsync(kt, 0, 16, st));
+            HIPCHK(hipMemsetAsync(kt, 0, 32, st));
             s->ws.ktime_valid = true;
         }
-        hipLaunchKernelGGL(k_blob_challenge, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, bl, cm, d_z, (int)T, kt);
+        // 4 wavefronts per SIMD (114 VGPRs; the compiler's own choice was 146 = 3): the whole launch is resident at once.
+        // Measured and not taken: 5 wavefronts (spills: -2.3 %), the launch as 2 / 4 back-to-back halves / quarters
+        // so that the chain's waves leave registers for the other kernels of the pipeline (-2.6 % / -3.5 %).
+#if KZG_AB_VARIANTS
+        static const long occ = opt_int("challenge_occ", 4);
+        if (occ == 3) hipLaunchKernelGGL(k_blob_challenge_t<3>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, bl, cm, d_z, (int)T, kt);
+        else if (occ == 5) hipLaunchKernelGGL(k_blob_challenge_t<5>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, bl, cm, d_z, (int)T, kt);
+        else
+#endif
+            hipLaunchKernelGGL(k_blob_challenge_t<4>, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, bl, cm, d_z, (int)T, kt);
     } else if (form == 2) {
         hipLaunchKernelGGL(k_blob_challenge_split, dim3((unsigned)((T + 63) / 64)), dim3(128), 0, st, bl, cm, d_z, (int)T);
     } else {
@@ -129,7 +138,7 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, int stage) {
         HIPCHK(hipMalloc(&w.d_window_sl, sizeof(G1Jac) * 2 * MSM_WINDOWS * MSM_MAX_SLICES * 4));  // sliced launches have <= 4 batches
         HIPCHK(hipMalloc(&w.d_mult, MULT_ENTRY_BYTES * std::max((size_t)MSM_CHUNKS * np, (size_t)MSM_CHUNKS_LATENCY * std::min(np, (size_t)(2 * LATENCY_MAX_BLOBS + 1)))));
         HIPCHK(hipMalloc(&w.d_ab, sizeof(G1Jac) * 2 * capB));
-        HIPCHK(hipMalloc(&w.d_ktime, 16));
+        HIPCHK(hipMalloc(&w.d_ktime, 32));
         if (msm_affine_enabled()) HIPCHK(hipMalloc(&w.d_jtmp, sizeof(G1Jac29Mem) * np));
         HIPCHK(hipMalloc(&w.d_parts, sizeof(G1Jac) * 2 * capB * MAX_WORLD));
         HIPCHK(hipMalloc(&w.d_send, sizeof(G1Jac) * 2 * MAX_WORLD));
@@ -539,7 +548,7 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
         HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * T, hipMemcpyDeviceToHost, s->s1));
         HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * T, hipMemcpyDeviceToHost, s->s1));
     }
-    if (w.ktime_valid) HIPCHK(hipMemcpyAsync(h + 176 * T, w.d_ktime, 16, hipMemcpyDeviceToHost, s->s1));
+    if (w.ktime_valid) HIPCHK(hipMemcpyAsync(h + 176 * T, w.d_ktime, 32, hipMemcpyDeviceToHost, s->s1));
     w.pending_n = n;
     w.pending_b = B;
     return KZG_OK;
@@ -558,6 +567,8 @@ static KzgRet phase1_wait_locked(uint8_t* records_out, uint8_t* bad_out, const K
     if (w.ktime_valid) {  // the throughput-form kernel stamps its own execution interval (100 MHz ticks): no queueing time in it
         const unsigned long long* kt = reinterpret_cast<const unsigned long long*>(w.h_buf + 176 * T);
         if (kt[0] && kt[1] && kt[1] > ~kt[0]) s->timings[5] = (float)((double)(kt[1] - ~kt[0]) * 1e-5);
+        s->clk_sum[0] += (double)kt[2];  // shader cycles and 100 MHz reference ticks of the kernel's waves (kzg_debug_shader_clock)
+        s->clk_sum[1] += (double)kt[3];
     }
     elapsed(&s->timings[6], s->ev[5], s->ev[10]);
     elapsed(&s->timings[7], s->ev[10], s->ev[6]);

@@ -97,13 +97,21 @@ __device__ __forceinline__ void bswap4(uint32_t* w, const uint4& q) {
 // on some CUs and idle SIMDs on others.
 // ktime (optional): { max over waves of ~start, max of end } in ticks of the 100 MHz s_memrealtime counter - the kernel's
 // own execution interval, which a HIP-event pair around the launch cannot give while other launch groups share the chip
-// (the events also time the wait for free CUs).  Zeroed by the host before the launch.
-__global__ __launch_bounds__(256) void k_blob_challenge(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
-                                                       Fr* __restrict__ z_out, int n, unsigned long long* __restrict__ ktime) {
+// (the events also time the wait for free CUs); { sum of shader cycles (s_memtime), sum of reference ticks } over the waves in
+// ktime[2..3]: the shader clock the kernel ran at while the other kernels of the pipeline shared the chip.  Zeroed by the host
+// before the launch.
+template <int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_blob_challenge_t(const uint8_t* __restrict__ blobs, const uint8_t* __restrict__ commitments,
+                                                                Fr* __restrict__ z_out, int n, unsigned long long* __restrict__ ktime) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bool stamp = ktime && (threadIdx.x & 63) == 0;
-    if (stamp) atomicMax(&ktime[0], ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
+    unsigned long long clk0 = 0, ref0 = 0;
+    if (stamp) {
+        ref0 = __builtin_amdgcn_s_memrealtime();
+        clk0 = __builtin_amdgcn_s_memtime();
+        atomicMax(&ktime[0], ~ref0);
+    }
     const uint4* blob = reinterpret_cast<const uint4*>(blobs + (size_t)i * BLOB_BYTES);
     const uint4* cm = reinterpret_cast<const uint4*>(commitments + (size_t)i * 48);
     Sha256State st;
@@ -159,7 +167,12 @@ __global__ __launch_bounds__(256) void k_blob_challenge(const uint8_t* __restric
 #pragma unroll
     for (int k = 0; k < 8; k++) d.l[k] = st.h[7 - k];
     z_out[i] = FrF::from_mont(FrF::to_mont(d));
-    if (stamp) atomicMax(&ktime[1], (unsigned long long)__builtin_amdgcn_s_memrealtime());
+    if (stamp) {  // ktime[2] / ktime[3]: shader cycles / reference ticks summed over the waves = the clock the SIMDs really ran at
+        const unsigned long long clk1 = __builtin_amdgcn_s_memtime(), ref1 = __builtin_amdgcn_s_memrealtime();
+        atomicMax(&ktime[1], ref1);
+        atomicAdd(&ktime[2], clk1 - clk0);
+        atomicAdd(&ktime[3], ref1 - ref0);
+    }
 }
 
 // ---------------------------------------------------------------- challenge, producer / consumer form

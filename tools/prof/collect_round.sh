@@ -17,12 +17,13 @@ rm -rf gpurun_out/${tag}_stats; mkdir -p gpurun_out/${tag}_stats
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -o run --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_stats.log 2>&1
 grep '^{' gpurun_out/${tag}_stats.log | tail -1 > gpurun_out/${tag}_bench_profiled.json
 i=0
-for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
+# SKIP_PMC=1: only the stats pass and the unprofiled line (the PMC json under profiles/ already describes this code)
+[ "${SKIP_PMC:-0}" = "1" ] || for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
     i=$((i+1))
     out=gpurun_out/${tag}_pmc_$i
     rm -rf $out; mkdir -p $out
     KZG_OPTIONS=single_stream=1 KZG_PMC_CALIBRATE=1 rocprofv3 --pmc $ctrs --kernel-trace -d $out -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-latency --no-self-check --group $group --inflight 1 --steps 1 --warmup 0 > $out.log 2>&1
 done
-python3 tools/prof/pmc_to_json.py gpurun_out/${tag}_pmc $group > gpurun_out/${tag}_pmc.json
+[ "${SKIP_PMC:-0}" = "1" ] || python3 tools/prof/pmc_to_json.py gpurun_out/${tag}_pmc $group > gpurun_out/${tag}_pmc.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -1 gpurun_out/${tag}_bench.json | cut -c1-400
