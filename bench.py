@@ -769,7 +769,7 @@ def main():
     print(json.dumps(out))
 
 
-def run_single_process_child(devices, n, timeout=420):
+def run_single_process_child(devices, n, timeout=300):
     """The one-process leg in child processes (a failure or a hang there costs that leg, not the line): once with the default
     exchange (partial sums through pinned host memory) and once with the in-process RCCL all-gather (KZG_OPTIONS
     multi_exchange=rccl) - on a list of distinct devices that is the north star's collective over xGMI."""
