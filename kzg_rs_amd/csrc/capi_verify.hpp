@@ -1171,8 +1171,7 @@ static KzgRet blob_single_locked(bool* ok, bool* general, const uint8_t* blob, c
 
 // MANY INDEPENDENT proofs, each with its own pairing and its own result ("verify_kzg_proof x N, each with its
 // own pairing" - the revm precompile's workload when every transaction's proof needs its own verdict): the one-proof path with
-// one program instance (= one workgroup, one CU) per proof - m proofs of a chunk run side by side.  Pinned mirror per proof:
-// [z | y LE 64 B] [status 4 words] [VERIFY3's outputs 8 x 48 B]; commitments and proofs as two arrays of 48 bytes each.
+// one program instance (= one workgroup, one CU) per proof - m proofs of a chunk run side by side (mirror layout: ProofsLaunch).
 constexpr size_t PROOFS_CHUNK = 1024;  // proofs per launch (the eight-lane subgroup-test kernel takes up to 8 x 256 points)
 constexpr size_t PROOFS_MIRROR_BYTES = 64 + 96 + 16 + 8 * sizeof(Fp);
 // one launch of m proofs: the pinned mirror [m][z | y LE] | [m][48] C | [m][48] pi | [m][2] decompression status | [2 m] full-decode
@@ -1304,7 +1303,7 @@ static KzgRet proofs_independent_locked(bool* ok_out, uint8_t* err, const uint8_
 // (:399-444) - the combination exists to save pairings on a CPU; here 64 pairings side by side cost what one does, and the
 // decode -> MSM -> pairing chain of the combined form is the longer critical path (3.0 ms against 1.8 ms).  The result is the
 // conjunction of the n verify_blob_kzg_proof verdicts - the statement the combined check tests probabilistically: it holds
-// whenever this does, and could hold without it only if the hash-derived r hit one of at most n - 1 roots in Fr (2^-248).
+// whenever this does, and could hold without it only if the hash-derived r hit one of at most n - 1 roots in Fr (< 2^-246).
 // Host: per-blob challenges on SHA-NI threads while the blobs cross PCIe; device: evaluation -> y; then the m-proof tail with
 // z and y read from device memory.  *general = true: some z_i = tau - the caller takes the combined path.
 static KzgRet blobs_small_locked(bool* ok, bool* general, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n, const KzgSettings* s) {
