@@ -157,7 +157,7 @@ def single_process_leg(spec, n, steps, warmup):
       sharded_stream  the same batches through kzg_verify_blob_kzg_proof_batch_sharded_stream, 4 in flight: the transcript
                       hash of one batch beside the device phases of the others
       groups          independent 1 024-blob batches, launch groups of 32 routed to the device that owns them
-                      (kzg_verify_blob_kzg_proof_batch_groups_device, 3 groups in flight per device, no exchange)
+                      (kzg_verify_blob_kzg_proof_batch_groups_device, 4 groups in flight per device, no exchange)
     Prints one JSON object."""
     import ctypes as C
 
@@ -220,11 +220,11 @@ def single_process_leg(spec, n, steps, warmup):
                 t = keep[k]
                 glist.append((t[0].data_ptr() + off * BYTES_PER_BLOB, t[1].data_ptr() + 48 * off, (t[3] if last else t[2]).data_ptr() + 48 * off))
                 gwant.append([True] * (B - 1) + [not last])
-        assert api.verify_blob_kzg_proof_batch_groups_device(glist[-3 * D:], nb, B, st, in_flight=3) == gwant[-3 * D:]
+        assert api.verify_blob_kzg_proof_batch_groups_device(glist[-3 * D:], nb, B, st, in_flight=4) == gwant[-3 * D:]
         t0 = time.perf_counter()
-        gres = api.verify_blob_kzg_proof_batch_groups_device(glist, nb, B, st, in_flight=3)
+        gres = api.verify_blob_kzg_proof_batch_groups_device(glist, nb, B, st, in_flight=4)
         dtg = time.perf_counter() - t0
-        groups_leg = {"groups": len(glist), "groups_per_device": KG, "batches_per_group": B, "blobs_per_batch": nb, "in_flight_per_device": 3,
+        groups_leg = {"groups": len(glist), "groups_per_device": KG, "batches_per_group": B, "blobs_per_batch": nb, "in_flight_per_device": 4,
                       "value": round(len(glist) * B * nb / dtg, 2), "unit": "blobs/s", "ms": round(dtg * 1e3, 3), "results_as_expected": gres == gwant,
                       "what": "independent %d-blob batches in launch groups of %d, every group on the device that holds it, one pipeline and host "
                               "thread per device, no exchange" % (nb, B)}
