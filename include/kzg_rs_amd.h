@@ -261,7 +261,9 @@ KzgRet kzg_blob_to_kzg_commitment(uint8_t *out48, const uint8_t *blobs, size_t n
 /* c-kzg-4844's compute_kzg_proof for n (blob, z) pairs: ys_out[i] = p_i(z_i) (32 bytes big-endian), proofs_out[i] =
  * commitment to the quotient (p_i(X) - y_i) / (X - z_i) (48 bytes), z = a root of unity included.  zs: n * 32 bytes
  * big-endian canonical.  And compute_blob_kzg_proof: the same at z = compute_challenge(blob, commitment)
- * (src/kzg_proof.rs:46-72) - the proof verify_blob_kzg_proof accepts.  Host pointers. */
+ * (src/kzg_proof.rs:46-72) - the proof verify_blob_kzg_proof accepts.  Host pointers.  The blobs' challenge hashes run on the
+ * host's SHA-NI cores (KZG_OPTIONS host_challenge_max_blobs / host_threads, as for the verifier's small host batches); the
+ * buffers of these three entry points stay on the handle after the first call (~30 MB). */
 KzgRet kzg_compute_kzg_proof(uint8_t *proofs_out, uint8_t *ys_out, const uint8_t *blobs, const uint8_t *zs, size_t n,
                              const KzgSettings *s);
 KzgRet kzg_compute_blob_kzg_proof(uint8_t *proofs_out, const uint8_t *blobs, const uint8_t *commitments, size_t n,

@@ -40,6 +40,25 @@ static KzgRet prover_ready(const KzgSettings* s) {
     if (!s->g1_in_subgroup) return fail(KZG_BAD_SETUP, "a G1 setup point is outside the r-torsion subgroup");
     return KZG_OK;
 }
+// the prover's buffers live on the handle from the first prover call on (fourteen hipMallocs and frees were 0.8 ms of every
+// call); the caller holds the handle's lock
+static KzgRet prover_bufs(const KzgSettings* s, ProverBufs** out) {
+    if (!s->prover) {
+        ProverBufs* b = new ProverBufs();
+        const KzgRet rc = b->alloc();
+        if (rc != KZG_OK) {
+            delete b;
+            return rc;
+        }
+        s->prover = b;
+    }
+    *out = s->prover;
+    return KZG_OK;
+}
+static void prover_release(const KzgSettings* s) {
+    delete s->prover;
+    s->prover = nullptr;
+}
 // m MSMs: out[b] = compress(sum_i sc[b][i] * g1_points[i]); sc = plain canonical scalars (destroyed: GLV split in place)
 static KzgRet setup_msm(const KzgSettings* s, ProverBufs& b, size_t m) {
     const size_t NT = (size_t)FE_PER_BLOB;
@@ -82,8 +101,9 @@ extern "C" KzgRet kzg_blob_to_kzg_commitment(uint8_t* out48, const uint8_t* blob
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
     select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
-    ProverBufs b;
-    if ((rc = b.alloc()) != KZG_OK) return rc;
+    ProverBufs* bp = nullptr;
+    if ((rc = prover_bufs(s, &bp)) != KZG_OK) return rc;
+    ProverBufs& b = *bp;
     for (size_t lo = 0; lo < n; lo += PROVER_CHUNK) {
         const size_t m = std::min(PROVER_CHUNK, n - lo);
         const int total = (int)(m * FE_PER_BLOB);
@@ -113,9 +133,20 @@ static KzgRet compute_proofs(uint8_t* proofs48, uint8_t* ys32, const uint8_t* bl
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
     select_streams(s, (size_t)-1);
-    ProverBufs b;
-    if ((rc = b.alloc()) != KZG_OK) return rc;
+    ProverBufs* bp = nullptr;
+    if ((rc = prover_bufs(s, &bp)) != KZG_OK) return rc;
+    ProverBufs& b = *bp;
     std::vector<uint8_t> le(32 * PROVER_CHUNK);
+    hipStream_t const side = s->s2 && s->s2 != s->s1 ? s->s2 : nullptr;  // the commitments' validity check runs beside the chain
+    struct DrainSide {  // (nothing of the call stays in flight on the side stream, whatever path leaves)
+        hipStream_t st;
+        ~DrainSide() {
+            if (st) (void)hipStreamSynchronize(st);
+        }
+    } drain_side{side};
+    // a few blobs: their Fiat-Shamir challenges from the host's SHA-NI cores while the blobs cross PCIe - a chain is 2.8 ms on
+    // GPU lanes however few blobs there are and 65 us on a host core (the verifier's small host batches do the same)
+    const size_t host_hash_max = std::min<size_t>(PROVER_CHUNK, host_challenge_max_blobs());
     for (size_t lo = 0; lo < n; lo += PROVER_CHUNK) {
         const size_t m = std::min(PROVER_CHUNK, n - lo);
         HIPCHK(hipMemcpyAsync(b.d_blobs, blobs + (size_t)BLOB_BYTES * lo, (size_t)BLOB_BYTES * m, hipMemcpyHostToDevice, s->s1));
@@ -126,8 +157,21 @@ static KzgRet compute_proofs(uint8_t* proofs48, uint8_t* ys32, const uint8_t* bl
             HIPCHK(hipStreamSynchronize(s->s1));  // `le` is reused by the next chunk
         } else {
             HIPCHK(hipMemcpyAsync(b.d_cm, commitments + 48 * lo, 48 * m, hipMemcpyHostToDevice, s->s1));
-            hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s->s1, b.d_cm, b.d_cm, (int)m, b.d_cpts, b.d_cflag, (int)m, 1);
-            if ((rc = launch_challenge(s, b.d_blobs, b.d_cm, b.d_z, m)) != KZG_OK) return rc;
+            hipStream_t dec = s->s1;
+            if (side) {  // decode + subgroup test of the commitments (2.5 ms on one lane each): only their verdict is needed
+                HIPCHK(hipEventRecord(s->ev[5], s->s1));
+                HIPCHK(hipStreamWaitEvent(side, s->ev[5], 0));
+                dec = side;
+            }
+            hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, dec, b.d_cm, b.d_cm, (int)m, b.d_cpts, b.d_cflag, (int)m, 1);
+            if (m <= host_hash_max) {
+                const size_t threads = (size_t)std::max(1L, std::min(16L, opt_int("host_threads", 16)));
+                host_blob_challenges(le.data(), blobs + (size_t)BLOB_BYTES * lo, commitments + 48 * lo, m, threads);
+                HIPCHK(hipMemcpyAsync(b.d_z, le.data(), 32 * m, hipMemcpyHostToDevice, s->s1));
+                HIPCHK(hipStreamSynchronize(s->s1));  // `le` is reused by the next chunk
+            } else if ((rc = launch_challenge(s, b.d_blobs, b.d_cm, b.d_z, m)) != KZG_OK) {
+                return rc;
+            }
         }
         if ((rc = launch_evaluate(s, b.d_blobs, b.d_z, b.d_y, b.d_status, m, /*alone=*/true)) != KZG_OK) return rc;
         hipLaunchKernelGGL(k_blob_quotient, dim3((unsigned)m), dim3(64), 0, s->s1, b.d_blobs, b.d_z, b.d_y, s->d_M, b.d_sc, b.d_status);
@@ -138,8 +182,9 @@ static KzgRet compute_proofs(uint8_t* proofs48, uint8_t* ys32, const uint8_t* bl
         HIPCHK(hipMemcpyAsync(proofs48 + 48 * lo, b.d_out, 48 * m, hipMemcpyDeviceToHost, s->s1));
         HIPCHK(hipMemcpyAsync(st.data(), b.d_status, 4 * m, hipMemcpyDeviceToHost, s->s1));
         HIPCHK(hipMemcpyAsync(yl.data(), b.d_y, 32 * m, hipMemcpyDeviceToHost, s->s1));
-        if (!zs) HIPCHK(hipMemcpyAsync(cf.data(), b.d_cflag, 4 * m, hipMemcpyDeviceToHost, s->s1));
+        if (!zs) HIPCHK(hipMemcpyAsync(cf.data(), b.d_cflag, 4 * m, hipMemcpyDeviceToHost, side ? side : s->s1));
         HIPCHK(hipStreamSynchronize(s->s1));
+        if (!zs && side) HIPCHK(hipStreamSynchronize(side));
         for (size_t i = 0; i < m; i++) {
             if (cf[i] == G1_INVALID || st[i]) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
             if (ys32) reverse32(ys32 + 32 * (lo + i), yl.data() + 32 * i);

@@ -98,6 +98,7 @@ struct KzgSettings {
     mutable float timings[8] = {};
     mutable double tsum[8] = {};   // the same, summed over every group finished on this handle since the last reset
     mutable uint64_t tcount = 0;
+    mutable struct ProverBufs* prover = nullptr;  // the prover-side entry points' buffers, made by the first of those calls (capi_prover.hpp)
     mutable double clk_sum[2] = {};  // shader cycles | 100 MHz reference ticks of the throughput-form challenge kernel's waves
     // A multi-device handle (capi_multi.hpp): this handle is shard 0 on the first device of the list and a complete
     // single-device handle in its own right; `peers` are the (private) single-device handles of the other entries, `multi`
@@ -517,6 +518,7 @@ static void ws_free(Workspace& w) {
     w = Workspace();
 }
 
+static void prover_release(const KzgSettings* s);  // (capi_prover.hpp)
 extern "C" void kzg_settings_free(KzgSettings* s) {
     if (!s) return;
     int prev = -1;
@@ -531,6 +533,7 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     if (s->d_proofs) (void)hipFree(s->d_proofs);
     if (s->d_proofs_out) (void)hipFree(s->d_proofs_out);
     if (s->h_proofs) (void)hipHostFree(s->h_proofs);
+    prover_release(s);
     if (!s->borrowed) {  // (a lane reads its parent's tables)
         void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob, s->verify2.blob, s->d_prep29, s->scalars.blob, s->verify3.blob, s->d_fixed_base};
         for (void* p : ptrs)

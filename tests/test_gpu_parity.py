@@ -126,6 +126,23 @@ def test_compute_proofs(settings, osettings):
         api.compute_kzg_proof([blobs[0]], [R.to_bytes(32, "big")], settings)
     with pytest.raises(KzgError):
         api.compute_blob_kzg_proof([blobs[0]], [bytes([0x81]) + bytes(range(1, 48))], settings)
+    # 70 blobs: two launch chunks; an invalid commitment in the second chunk is found by the check that runs beside the chain
+    many = [i % 7 for i in range(70)]
+    assert api.compute_blob_kzg_proof([blobs[i] for i in many], [cs[i] for i in many], settings) == [ps[i] for i in many]
+    with pytest.raises(KzgError):
+        api.compute_blob_kzg_proof([blobs[i] for i in many], [cs[i] for i in many[:-1]] + [G.off_subgroup_g1()], settings)
+    # the challenges come from the host's SHA-NI cores by default; with every chain on the GPU (child process) the same proofs
+    import subprocess
+    import sys
+    code = ("import sys\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import golden_data as G\n"
+            "from kzg_rs_amd import api\n"
+            "st = api.KzgSettings.load_trusted_setup_file()\n"
+            "b, c, p = [list(x) for x in zip(*G.valid_blob_tuples())]\n"
+            "print('GPU-HASHED PROOFS', api.compute_blob_kzg_proof(b, c, st) == p)\n" % (O.ROOT, os.path.join(O.ROOT, "tests")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_OPTIONS="host_challenge_max_blobs=0"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "GPU-HASHED PROOFS True" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
 
 
 # ------------------------------------------------------------------ the reference's three vector tests
