@@ -1035,8 +1035,13 @@ def test_handles_release_device_memory_and_oom_is_malloc():
             h = KzgSettings.from_tau_g2(tau_g2)
             assert KzgProof.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 4, h) is True
             assert api.pairing_check(G1_GEN, G1_INF, h) is False
+            # the buffers of the one-proof / many-proofs / small-host-batch paths hang off the handle too
+            assert KzgProof.verify_blob_kzg_proof_batch([Blob(blobs[i].tobytes()) for i in range(4)], [Bytes48(c) for c in cs], [Bytes48(p) for p in ps], h) is True
+            assert api.verify_kzg_proofs(pc, pz, py, pp, h) == [True, True, True]
+            assert KzgProof.verify_kzg_proof(Bytes48(pc[0]), Bytes32(pz[0]), Bytes32(py[1]), Bytes48(pp[0]), h) is False
             h.close()
 
+    pc, pz, py, pp, _ = synth.make_valid_proofs(3, seed=82, settings=st0)
     cycle(3)  # first-use allocations of the runtime itself (code objects, stream pools) happen here
     assert KzgProof.verify_blob_kzg_proof_batch_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 4, st0) is True  # st0's own workspace
     torch.cuda.synchronize()
@@ -1045,6 +1050,24 @@ def test_handles_release_device_memory_and_oom_is_malloc():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < (8 << 20), "device memory not returned: %d bytes" % (free0 - free1)
+    # handles over the full setup that used the prover side (its buffers live on the handle from the first such call on)
+    tup = G.valid_blob_tuples()[0]
+
+    def prover_cycle(k):
+        for _ in range(k):
+            h = KzgSettings.load_trusted_setup_file()
+            assert api.blob_to_kzg_commitment([tup[0]], h) == [tup[1]]
+            assert api.compute_blob_kzg_proof([tup[0]], [tup[1]], h) == [tup[2]]
+            h.close()
+
+    prover_cycle(2)
+    torch.cuda.synchronize()
+    free_a, _ = torch.cuda.mem_get_info()
+    prover_cycle(6)
+    torch.cuda.synchronize()
+    free_b, _ = torch.cuda.mem_get_info()
+    assert free_a - free_b < (8 << 20), "prover buffers not returned: %d bytes" % (free_a - free_b)
+    free1 = free_b
     # (b) a launch group of 2^36 blobs: the very first workspace array (2 TiB) cannot be allocated - nothing is launched
     HipBackend(st0)  # declares the argtypes
     rc = api.lib().kzg_shard_phase1_launch(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), 1 << 36, 1, st0._h)
