@@ -1050,7 +1050,12 @@ struct ProofStreams {
 static KzgRet proof_reserve(ProofStreams& ps, const KzgSettings* s) {
     KzgRet rc = ws_reserve(s, 1, 1, STAGE_BLOBS);
     if (rc != KZG_OK) return rc;
-    select_streams(s, 1);
+    // The plain stream pair: these paths bring their own third stream and never use the CU-masked pair - and must not create
+    // it: a CU-masked stream holds a hardware queue of its own, the process has 8 (GPU_MAX_HW_QUEUES), and streams that share a
+    // queue run one behind the other.  Measured with 6-blob batches from T threads with a handle each (tools/prof/
+    // concurrent_small_batches.py, profiles/r4_concurrent_small_batches.txt): with the masked pair made on every handle 778
+    // batches/s at T = 8 and 414 at T = 16 (10 and 39 ms per call); without it 1 270 and 1 310 - 1 920 and 2 270 with 16 queues.
+    select_streams(s, (size_t)-1);
     if (!s->d_proof) HIPCHK(hipMalloc(&s->d_proof, sizeof(Fp) * (SCALARS_INPUTS + VERIFY3_INPUTS)));
     const bool one_stream = !s->s_plain[1];  // option single_stream: everything in sequence (profiling)
     if (!one_stream && !s->s_aux) HIPCHK(hipStreamCreateWithFlags(&s->s_aux, hipStreamNonBlocking));
