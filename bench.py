@@ -288,6 +288,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single_batch / end_to_end legs (profiling runs)")
     ap.add_argument("--no-self-check", action="store_true", help="skip the poisoned control group and the stand-alone group (profiling runs)")
+    ap.add_argument("--precall-single", action="store_true",
+                    help="measurement: one 1 024-blob call on the handle BEFORE the warm-up (it creates the handle's CU-masked stream pair, "
+                         "two more users of the 8 hardware queues the pipeline's lanes share)")
     ap.add_argument("--single-process-devices", default=None, metavar="0,1,...",
                     help="only the single-process multi-device leg: one handle over these devices, --blobs per device (default 32768)")
     args = ap.parse_args()
@@ -409,6 +412,9 @@ def main():
             el = float(t.item())
         return el, out
 
+    if args.precall_single:
+        v0 = variants[0]
+        assert api.KzgProof.verify_blob_kzg_proof_batch_device(v0[0].data_ptr(), v0[1].data_ptr(), v0[2].data_ptr(), n, settings) is True
     # warm-up: every handle allocates its workspace and runs every kernel once before the timed region
     W = max(args.warmup, n_handles) if args.warmup else 0
     if W:
