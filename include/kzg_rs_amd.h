@@ -20,12 +20,18 @@
  *         KZG_BAD_SETUP      <-> KzgError::InvalidTrustedSetup
  *     kzg_last_error() returns a thread-local message for the last non-OK return.
  *   - there is NO CPU fallback: without a usable gfx950 device every call returns KZG_ERROR.
- *   - thread safety: entry points may be called concurrently with one shared settings handle
- *     (calls on one handle are serialised internally); handles are immutable after creation.
+ *   - thread safety: a settings handle is shared freely between host threads, like the reference's &KzgSettings
+ *     (src/trusted_setup.rs:44-50,80-92).  The SMALL calls of concurrent callers - kzg_verify_kzg_proof, kzg_verify_blob_kzg_proof,
+ *     kzg_verify_blob_kzg_proof_batch / kzg_verify_kzg_proof_batch of up to 256 items, kzg_verify_kzg_proofs of up to 256 tuples -
+ *     are coalesced inside the library: whoever finds a free lane of the handle leads ONE launch that carries every call
+ *     waiting at that moment (up to 1 024 proofs / 256 blobs, one pairing per item, up to KZG_OPTIONS small_lanes = 2
+ *     launches in flight per device), and every caller gets its own verdict and its own Err (csrc/capi_coalesce.hpp); a call on an
+ *     idle handle starts at once.  Large calls (batches the GPU fills by itself, the many-batch and prover entry points)
+ *     take the handle's own lock one at a time and run beside the small launches.  Handles are immutable after creation.
  *   - environment: the library reads KZG_DEVICES (below) and KZG_OPTIONS ("key=value;key=value": tuning and test switches,
  *     listed in INTEGRATION.md) and writes nothing.  The launch-group pipeline wants 8 HIP hardware queues: set
  *     GPU_MAX_HW_QUEUES=8 in the host's environment before the HIP runtime initialises (ROCm's default is 4, ~5 % slower); a
- *     constructor that sees fewer returns KZG_OK and leaves a note in kzg_last_error().
+ *     constructor that sees fewer returns KZG_OK and says so in kzg_settings_note() (kzg_last_error() is empty after a success).
  */
 #ifndef KZG_RS_AMD_H
 #define KZG_RS_AMD_H
@@ -98,6 +104,9 @@ KzgRet kzg_settings_from_tau_g2_devices(KzgSettings **out, const uint8_t tau_g2[
  * 0 single device, 1 partial sums through host memory (kzg_last_error() then says why), 2 in-process RCCL all-gather. */
 KzgRet kzg_settings_devices(const KzgSettings *s, size_t *n_devices, int *devices_out, size_t cap, int *exchange);
 void kzg_settings_free(KzgSettings *s);
+/* What a successful constructor wants its caller to know about the handle ("" = nothing): fewer than 8 HIP hardware queues,
+ * the outcome of a multi-device handle's exchange self-test.  The string lives as long as the handle. */
+const char *kzg_settings_note(const KzgSettings *s);
 /* roots_of_unity[i] as 32 big-endian bytes (i < 4096), for parity tests of the settings tables. */
 KzgRet kzg_settings_root_of_unity(const KzgSettings *s, size_t i, uint8_t out[32]);
 /* The rest of the trusted setup (handles made by kzg_settings_load_trusted_setup only; verification does not read it):

@@ -89,6 +89,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise KzgError("InternalError", "libkzg_rs_amd.so is not built (python -m kzg_rs_amd.build); "
                                             "there is no CPU fallback")
+        # The HOST side of the boundary asks for 8 HIP hardware queues (ROCm's default is 4) before the HIP runtime starts, as
+        # INTEGRATION.md tells a Rust host to: the launch-group pipeline and the small-call lanes (3 streams each) want them.
+        # A value the process already has is kept; a runtime that is already initialised ignores it (KzgSettings.note() says so).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes cannot share a process.
         # When torch is installed, let it load its runtime first so this library binds to the same one.
         try:
@@ -136,6 +140,10 @@ def lib():
         L.kzg_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.kzg_debug_shader_clock.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
         L.kzg_last_error.restype = C.c_char_p
+        L.kzg_settings_note.argtypes = [vp]
+        L.kzg_settings_note.restype = C.c_char_p
+        L.kzg_debug_small_queue_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+        L.kzg_debug_concurrent_callers.argtypes = [C.POINTER(C.c_double), C.c_int, sz, C.c_double, u8, u8, u8, u8, u8, u8, sz, sz, vp]
         _lib = L
     return _lib
 
@@ -256,6 +264,29 @@ class KzgSettings:
         arr = (C.c_int * 64)()
         _chk(lib().kzg_settings_devices(self._h, C.byref(n), arr, 64, C.byref(ex)))
         return list(arr[: n.value]), ("none", "host", "rccl")[ex.value]
+
+    def note(self):
+        """What the constructor wants its caller to know about a handle it made successfully ("" = nothing): fewer than 8 HIP
+        hardware queues, how a multi-device handle exchanges its partial sums (include/kzg_rs_amd.h kzg_settings_note)."""
+        return lib().kzg_settings_note(self._h).decode(errors="replace")
+
+    def small_queue_stats(self, reset=False):
+        """The small-call queue of this handle (csrc/capi_coalesce.hpp) since the last reset:
+        {launches, requests, items, max_items (the largest launch), lanes}."""
+        o = (C.c_uint64 * 5)()
+        _chk(lib().kzg_debug_small_queue_stats(self._h, o, int(reset)))
+        return dict(zip(("launches", "requests", "items", "max_items", "lanes"), (int(x) for x in o)))
+
+    def concurrent_callers(self, kind, threads, seconds, c, p, expect, z=None, y=None, blobs=None, per_call=1):
+        """T host threads INSIDE the library (no interpreter lock) calling the public small entry points on this one handle for
+        `seconds`, every answer checked against `expect` (0 false / 1 true / 2 Err): kind "proof" = verify_kzg_proof per tuple,
+        "blobs" = verify_blob_kzg_proof_batch of per_call blobs (expect per call), "proofs" = kzg_verify_kzg_proofs of per_call
+        tuples (expect per tuple).  Returns {calls, seconds, calls_per_s, wrong, mean_ms, max_ms}."""
+        k = {"proof": 0, "blobs": 1, "proofs": 2}[kind]
+        n_items = len(c) // 48
+        o = (C.c_double * 5)()
+        _chk(lib().kzg_debug_concurrent_callers(o, k, threads, float(seconds), blobs, bytes(c), z, y, bytes(p), bytes(expect), n_items, per_call, self._h))
+        return {"calls": int(o[0]), "seconds": o[1], "calls_per_s": o[0] / o[1] if o[1] else 0.0, "wrong": int(o[2]), "mean_ms": o[3], "max_ms": o[4]}
 
     def multi_last_timings(self):
         t = (C.c_float * 8)()

@@ -69,7 +69,7 @@ extern "C" KzgRet kzg_debug_msm_sum_quads(uint8_t out[144], const uint8_t* point
     HIPCHK(hipMalloc(&t_in.p, sizeof(G1Jac) * npts));
     HIPCHK(hipMalloc(&t_out.p, sizeof(G1Jac)));
     HIPCHK(hipMemcpy(t_in.p, points, sizeof(G1Jac) * npts, hipMemcpyHostToDevice));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_sum_quads), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SUMQ_LDS_BYTES));
+    HIPCHK(DYN_LDS(k_msm_sum_quads, SUMQ_LDS_BYTES));
     hipLaunchKernelGGL(k_msm_sum_quads, dim3(1), dim3(256), SUMQ_LDS_BYTES, s->s1, t_in.as<G1Jac>(), t_out.as<G1Jac>(), npts);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->s1));

@@ -163,6 +163,8 @@ static KzgRet multi_build(KzgSettings* s, const uint8_t tau_g2[96], const std::v
         HIPCHK(hipSetDevice(devices[k]));
         KzgSettings* p = nullptr;
         if ((rc = settings_common(&p, tau_g2)) != KZG_OK) return rc;
+        delete p->small;  // (the handle the caller holds queues the small calls of every device)
+        p->small = nullptr;
         s->peers.push_back(p);
     }
     // every shard owns the group-sized buffers from the start (the fold and the warm-up collective below use them)
@@ -207,6 +209,7 @@ static KzgRet multi_build(KzgSettings* s, const uint8_t tau_g2[96], const std::v
         }
         if (m->exchange != MULTI_EXCHANGE_RCCL) return fail(KZG_ERROR, "multi_exchange=rccl but RCCL is unusable: " + m->exchange_note);
     }
+    if (s->small) s->small->max_lanes = std::min<size_t>(16, s->small->max_lanes * D);  // small calls: the same number of lanes on every device (lane i on shard i mod D)
     HIPCHK(hipSetDevice(s->device));
     return KZG_OK;
 }

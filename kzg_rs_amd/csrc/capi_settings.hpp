@@ -1,6 +1,10 @@
 // capi_settings.hpp - KzgSettings / Workspace and the construction of a handle (trusted-setup text parser, tables, prepared pairing lines).
 // Part of the single translation unit kzg_capi.hip; not a stand-alone header.
 
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
 // ---------------------------------------------------------------- settings
 struct DevProgram {
     SlpProgram p{};
@@ -47,6 +51,50 @@ struct Workspace {
     // pinned host mirrors
     uint8_t* h_buf = nullptr;
     size_t h_cap = 0;
+};
+
+// ---------------------------------------------------------------- the small-call queue of a handle (capi_coalesce.hpp)
+// One request = the small call of one host thread: n (commitment, z, y, proof) tuples, or n host blobs with their commitments
+// and proofs; every item gets its own pairing and the request gets its own results - what the entry point makes of them
+// (one verdict, a conjunction, a verdict per item) is the submitter's business.
+struct SmallReq {
+    enum Kind { PROOFS = 0, BLOBS = 1 };
+    Kind kind = PROOFS;
+    size_t n = 0;
+    const uint8_t *c = nullptr, *p = nullptr;  // n x 48 bytes each
+    const uint8_t *z = nullptr, *y = nullptr;  // PROOFS: n x 32 big-endian bytes each
+    const uint8_t* blobs = nullptr;            // BLOBS: n x 131072 bytes
+    hostpool::JobRef hash;                     // BLOBS: the challenges (the submitter's buffer behind hash->z_le), claimed blob by blob by whoever has time
+    // results.  PROOFS: per item.  BLOBS: [0] only - the conjunction over the request's blobs, any parse failure among them, any z = tau
+    bool* ok = nullptr;
+    uint8_t *err = nullptr, *general = nullptr;
+    KzgRet rc = KZG_OK;  // a failure of the launch that carried the request (every request of that launch gets it)
+    std::string msg;
+    std::atomic<bool> taken{false}, done{false};  // taken: written under the queue's lock; done: the leader's LAST access to the request
+};
+struct SmallLane {
+    KzgSettings* h = nullptr;  // a private lane (settings_lane) on one device of the handle
+    bool busy = false;
+    std::vector<uint8_t> c, z, y, p, okerr;  // the gathered tuples of a launch
+};
+struct SmallQueue {
+    std::mutex mu;
+    std::deque<SmallReq*> q;        // waiting requests, oldest first
+    std::vector<SmallLane*> lanes;  // made on demand, up to max_lanes
+    size_t max_lanes = 2;
+    bool lane_two_streams = false;  // option small_streams=2: chain C of the one-proof path behind chain B, two streams per lane (A/B measurement)
+    // The lanes' streams are made at the device's highest priority (option small_priority=0: normal).  Not for the priority
+    // itself: the HIP runtime keeps a separate pool of hardware queues per priority, so the lanes' streams do not share queues
+    // with each other's or with the launch-group pipeline's normal-priority streams.  Streams that share a hardware queue run
+    // one behind the other: with normal-priority lanes and GPU_MAX_HW_QUEUES=8, two threads calling verify_kzg_proof at once
+    // took 2.9 ms each instead of 1.7 (1.84 with 16 queues, 1.75 with priority lanes: profiles/r5_small_call_queues.txt).
+    int lane_priority = 1;
+    long linger_us = 250, linger_gap_us = 40;  // options small_linger_us / small_linger_gap_us (capi_coalesce.hpp small_submit); 0: never wait
+    std::atomic<uint32_t> epoch{0};    // the futex word every waiter sleeps on
+    std::atomic<uint64_t> arrivals{0};
+    uint64_t last_done_us = 0;         // when the last launch finished, and how many calls it carried
+    size_t last_done_items = 0;
+    uint64_t launches = 0, requests = 0, items = 0, max_items = 0;  // since the last kzg_debug_small_queue_stats(reset)
 };
 
 struct KzgSettings {
@@ -111,8 +159,15 @@ struct KzgSettings {
     uint8_t tau_g2_bytes[96] = {};  // g2_points[1] as given
     mutable float multi_ms[8] = {};  // host wall-clock stages of the last sharded call (kzg_multi_last_timings)
     mutable uint8_t multi_last_r[32] = {};  // the batch challenge of the last sharded call, little-endian (test hook kzg_debug_multi_last_r)
+    // concurrent small calls on this handle (capi_coalesce.hpp): their queue and the private lanes their launches run on; null
+    // on the handle's own lanes and peers, and with option coalesce=0
+    mutable SmallQueue* small = nullptr;
+    int stream_priority = 0;         // of the handle's own streams (stream_make)
+    bool proof_two_streams = false;  // a lane of that queue: the one-proof chains on two streams (proof_reserve)
+    std::string note;  // what a caller may want to know about a handle that was made successfully (kzg_settings_note)
 };
 static void multi_free(KzgSettings* s);
+static void small_free(KzgSettings* s);
 
 static KzgRet upload_program(DevProgram& dp, const unsigned char* begin, const unsigned char* end) {
     size_t len = (size_t)(end - begin);
@@ -161,7 +216,7 @@ template <int LANES>
 static KzgRet launch_program2(const DevProgram2& dp, const Fp* d_in, const uint32_t* d_set29, Fp* d_out, int instances, hipStream_t st, uint32_t in_stride,
                               uint32_t out_stride) {
     const size_t lds = (size_t)dp.p.n_slots * SLP2_SLOT_WORDS * 4 + (size_t)SLP2_GROUP * LANES * sizeof(uint4);  // slots | descriptor ring
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp2_run<LANES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(DYN_LDS(k_slp2_run<LANES>, lds));
     hipLaunchKernelGGL(k_slp2_run<LANES>, dim3(instances), dim3(LANES), lds, st, dp.p, d_in, d_set29, d_out, in_stride ? in_stride : dp.p.n_in,
                        out_stride ? out_stride : dp.p.n_out);
     HIPCHK(hipGetLastError());
@@ -184,10 +239,10 @@ static KzgRet run_verify(const KzgSettings* s, const Fp* d_in, Fp* d_out, int in
 static KzgRet run_program(const DevProgram& dp, const Fp* d_in, const Fp* d_set, Fp* d_out, int instances, hipStream_t st) {
     size_t lds = (size_t)dp.p.n_slots * 48 + (size_t)2 * SLP_GROUP * dp.p.lanes * sizeof(uint2);  // slots | descriptor ring
     if (dp.p.lanes == 64) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp_run<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(DYN_LDS(k_slp_run<false>, lds));
         hipLaunchKernelGGL(k_slp_run<false>, dim3(instances), dim3(64), lds, st, dp.p, d_in, d_set, d_out);
     } else {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_slp_run<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(DYN_LDS(k_slp_run<true>, lds));
         hipLaunchKernelGGL(k_slp_run<true>, dim3(instances), dim3(dp.p.lanes), lds, st, dp.p, d_in, d_set, d_out);
     }
     HIPCHK(hipGetLastError());
@@ -216,20 +271,38 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
         g_err = msg;
         return rc;
     }
+    if (opt_flag("coalesce", true)) {  // (a peer of a multi-device handle loses it again in multi_build: only the handle a caller holds has one)
+        s->small = new SmallQueue();
+        s->small->max_lanes = (size_t)std::max(1L, std::min(8L, opt_int("small_lanes", 2)));
+        s->small->lane_two_streams = opt_int("small_streams", 3) == 2;
+        s->small->lane_priority = opt_int("small_priority", 1) ? 1 : 0;
+        s->small->linger_us = std::max(0L, std::min(2000L, opt_int("small_linger_us", 250)));
+        s->small->linger_gap_us = std::max(1L, std::min(1000L, opt_int("small_linger_gap_us", 40)));
+    }
     *out = s;
     return KZG_OK;
 }
 // what every handle owns, a lane included: its streams and events (the workspace grows on first use)
-static KzgRet settings_streams(KzgSettings* s, bool single_stream) {
+static KzgRet stream_make(hipStream_t* st, int priority) {  // priority 0: the default; 1: the device's highest
+    if (priority) {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest));
+    } else HIPCHK(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    return KZG_OK;
+}
+static KzgRet settings_streams(KzgSettings* s, bool single_stream, int priority = 0) {
     HIPCHK(hipGetDevice(&s->device));  // the calling thread's current device (multi_build sets it per shard)
-    HIPCHK(hipStreamCreateWithFlags(&s->s_plain[0], hipStreamNonBlocking));
+    s->stream_priority = priority;
+    KzgRet rc_s = stream_make(&s->s_plain[0], priority);
+    if (rc_s != KZG_OK) return rc_s;
     s->s1 = s->s_sha = s->s_plain[0];
     HIPCHK(hipDeviceGetAttribute(&s->n_cus, hipDeviceAttributeMultiprocessorCount, s->device));
     // option single_stream=1 (profiling aid): run the point-decode chain on the same stream as the challenge chain, so
     // per-dispatch PMC counters are not polluted by a concurrent kernel
     if (single_stream) s->s2 = s->s1;
     else {
-        HIPCHK(hipStreamCreateWithFlags(&s->s_plain[1], hipStreamNonBlocking));
+        if ((rc_s = stream_make(&s->s_plain[1], priority)) != KZG_OK) return rc_s;
         s->s2 = s->s_plain[1];
     }
     for (auto& e : s->ev) HIPCHK(hipEventCreate(&e));
@@ -239,7 +312,7 @@ static KzgRet settings_streams(KzgSettings* s, bool single_stream) {
 // workspace and timings - that READS the parent's tables and pairing programs (they are immutable after construction): making
 // one costs two streams and a dozen events instead of the table kernels, three program uploads and a PREP pairing run.  The
 // caller has set the parent's device.  Freed with the parent (kzg_settings_free), never handed out.
-static KzgRet settings_lane(KzgSettings** out, const KzgSettings* parent) {
+static KzgRet settings_lane(KzgSettings** out, const KzgSettings* parent, int priority = 0) {
     KzgSettings* l = new KzgSettings();
     l->borrowed = true;
     l->d_M = parent->d_M; l->d_DM = parent->d_DM; l->d_M29 = parent->d_M29; l->d_DM29 = parent->d_DM29;
@@ -249,7 +322,7 @@ static KzgRet settings_lane(KzgSettings** out, const KzgSettings* parent) {
     l->prep = parent->prep; l->verify = parent->verify; l->verify2 = parent->verify2;
     l->scalars = parent->scalars; l->verify3 = parent->verify3; l->d_fixed_base = parent->d_fixed_base;
     memcpy(l->tau_g2_bytes, parent->tau_g2_bytes, 96);
-    KzgRet rc = settings_streams(l, /*single_stream=*/!parent->s_plain[1]);
+    KzgRet rc = settings_streams(l, /*single_stream=*/!parent->s_plain[1], priority);
     if (rc != KZG_OK) {
         const std::string msg = g_err;
         kzg_settings_free(l);
@@ -474,38 +547,42 @@ static KzgRet load_trusted_setup_on(KzgSettings** out, const char* txt, size_t l
     return KZG_OK;
 }
 
-// a constructor that succeeded under fewer than 8 hardware queues says so where kzg_last_error() finds it (the return stays KZG_OK)
-static KzgRet constructed(KzgRet rc) {
+// a constructor that succeeded under fewer than 8 hardware queues says so in the handle's note (kzg_settings_note); the error
+// channel stays empty after a success (rounds 3-4 left the note in kzg_last_error(), where a caller that logs a non-empty last
+// error saw an "error" after every successful constructor)
+static KzgRet constructed(KzgRet rc, KzgSettings** out) {
     if (rc == KZG_OK) {
         const char* note = hw_queues_note();
-        g_err = note ? note : "";
+        if (note) (*out)->note = (*out)->note.empty() ? note : (*out)->note + "; " + note;
+        g_err.clear();
     }
     return rc;
 }
+extern "C" const char* kzg_settings_note(const KzgSettings* s) { return s ? s->note.c_str() : ""; }
 extern "C" KzgRet kzg_settings_load_trusted_setup(KzgSettings** out, const char* txt, size_t len) {
     if (!out || !txt) return fail(KZG_BADARGS, "null argument");
     std::vector<int> devs;
     KzgRet rc = device_list(devs, nullptr, 0, /*from_env=*/true);
-    return rc != KZG_OK ? rc : constructed(load_trusted_setup_on(out, txt, len, devs));
+    return rc != KZG_OK ? rc : constructed(load_trusted_setup_on(out, txt, len, devs), out);
 }
 extern "C" KzgRet kzg_settings_load_trusted_setup_devices(KzgSettings** out, const char* txt, size_t len, const int* devices, size_t n_devices) {
     if (!out || !txt) return fail(KZG_BADARGS, "null argument");
     std::vector<int> devs;
     KzgRet rc = device_list(devs, devices, n_devices, false);
-    return rc != KZG_OK ? rc : constructed(load_trusted_setup_on(out, txt, len, devs));
+    return rc != KZG_OK ? rc : constructed(load_trusted_setup_on(out, txt, len, devs), out);
 }
 
 extern "C" KzgRet kzg_settings_from_tau_g2(KzgSettings** out, const uint8_t tau_g2[96]) {
     if (!out || !tau_g2) return fail(KZG_BADARGS, "null argument");
     std::vector<int> devs;
     KzgRet rc = device_list(devs, nullptr, 0, /*from_env=*/true);
-    return rc != KZG_OK ? rc : constructed(settings_on_devices(out, tau_g2, devs));
+    return rc != KZG_OK ? rc : constructed(settings_on_devices(out, tau_g2, devs), out);
 }
 extern "C" KzgRet kzg_settings_from_tau_g2_devices(KzgSettings** out, const uint8_t tau_g2[96], const int* devices, size_t n_devices) {
     if (!out || !tau_g2) return fail(KZG_BADARGS, "null argument");
     std::vector<int> devs;
     KzgRet rc = device_list(devs, devices, n_devices, false);
-    return rc != KZG_OK ? rc : constructed(settings_on_devices(out, tau_g2, devs));
+    return rc != KZG_OK ? rc : constructed(settings_on_devices(out, tau_g2, devs), out);
 }
 
 static void ws_free(Workspace& w) {
@@ -523,6 +600,7 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     if (!s) return;
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    small_free(s);  // the small-call queue's lanes (capi_coalesce.hpp)
     multi_free(s);  // communicators and peer handles first (each on its own device)
     for (KzgSettings* l : s->lanes) kzg_settings_free(l);
     s->lanes.clear();

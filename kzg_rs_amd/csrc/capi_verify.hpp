@@ -32,21 +32,18 @@ static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const F
     // three, 4.91-4.97 M with two (profiles/r4_ab_evaluate.txt).  Option eval_lds_pad=<bytes> overrides (measurement).
     static const long pad_opt = opt_int("eval_lds_pad", -1);
     const size_t lds_pad = pad_opt >= 0 ? (size_t)std::min(120L * 1024, pad_opt) : alone ? 0 : 16384;
-    size_t spread_lds = lds_pad;
-    if (lds_pad) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad) != hipSuccess) {
-            (void)hipGetLastError();
+    // (the attribute is a per-kernel maximum that dyn_lds_ensure only raises: concurrent launches with different paddings cannot
+    // fail each other; a launch whose request could not be raised goes without its padding - slower placement, same result)
+    size_t spread_lds = eval_blocks <= (unsigned)s->n_cus ? (size_t)EVAL_SPREAD_LDS : lds_pad;
+    if (spread_lds) {
+        bool attr_ok = DYN_LDS(k_blob_evaluate_t<true>, spread_lds) == hipSuccess;
+#if KZG_AB_VARIANTS
+        attr_ok = DYN_LDS(k_blob_evaluate_t<false>, spread_lds) == hipSuccess && attr_ok;
+#endif
+        if (!attr_ok) {
+            (void)hipGetLastError();  // nothing sticky is left for the callers' checks
             spread_lds = 0;
         }
-    }
-    if (eval_blocks <= (unsigned)s->n_cus) {
-        bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate_t<true>), hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_SPREAD_LDS) == hipSuccess;
-#if KZG_AB_VARIANTS
-        attr_ok = attr_ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_blob_evaluate_t<false>), hipFuncAttributeMaxDynamicSharedMemorySize, EVAL_SPREAD_LDS) == hipSuccess;
-#endif
-        if (attr_ok)
-            spread_lds = EVAL_SPREAD_LDS;
-        else (void)hipGetLastError();  // the launch below goes without the spreading request; nothing sticky is left for the callers' checks
     }
 #if KZG_AB_VARIANTS
     static const bool eval_r3 = opt_is("evaluate_kernel", "r3");  // round 3's kernel: 192 VGPRs, two wavefronts per SIMD (A/B measurement)
@@ -279,7 +276,7 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     // sums - one workgroup per output, four lanes per addition (option msm_sum_quads=0: the fold + combine kernels, A/B)
     static const bool sum_quads = opt_flag("msm_sum_quads", true);
     if (sum_quads && W == 1 && fp29_enabled() && slots * S >= 2 && slots * S <= (unsigned)SUMQ_MAX_POINTS && 2 * B < 64) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_sum_quads), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SUMQ_LDS_BYTES));
+        HIPCHK(DYN_LDS(k_msm_sum_quads, SUMQ_LDS_BYTES));
         hipLaunchKernelGGL(k_msm_sum_quads, dim3((unsigned)(2 * B)), dim3(256), SUMQ_LDS_BYTES, s->s1, d.window_sums, w.d_ab, (int)(slots * S));
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s->ev[3], s->s1));
@@ -336,12 +333,12 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
             blocks = (unsigned)((2 * T + DECQ_POINTS_PER_BLOCK - 1) / DECQ_POINTS_PER_BLOCK);
 #if KZG_AB_VARIANTS
             if (w.chunks != MSM_CHUNKS_LATENCY) {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_decode_multiples29_quads<MSM_CHUNKS_PROOFS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECQ_LDS_BYTES));
+                HIPCHK(DYN_LDS(k_g1_decode_multiples29_quads<MSM_CHUNKS_PROOFS>, DECQ_LDS_BYTES));
                 hipLaunchKernelGGL(k_g1_decode_multiples29_quads<MSM_CHUNKS_PROOFS>, dim3(blocks), dim3(64), DECQ_LDS_BYTES, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
             } else
 #endif
             {
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_g1_decode_multiples29_quads<MSM_CHUNKS_LATENCY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)DECQ_LDS_BYTES));
+                HIPCHK(DYN_LDS(k_g1_decode_multiples29_quads<MSM_CHUNKS_LATENCY>, DECQ_LDS_BYTES));
                 hipLaunchKernelGGL(k_g1_decode_multiples29_quads<MSM_CHUNKS_LATENCY>, dim3(blocks), dim3(64), DECQ_LDS_BYTES, s->s2, c, p, (int)T, w.d_points, w.d_pflag, mult, n2, np);
             }
         } else if (w.chunks == MSM_CHUNKS_LATENCY)
@@ -414,7 +411,7 @@ static void select_streams(const KzgSettings* s, size_t T) {
 struct HostBatch {
     const uint8_t *blobs, *commitments, *proofs;
     const uint8_t* z_le = nullptr;  // the challenges, computed on the host (host_blob_challenges): n x 32 little-endian bytes ...
-    std::thread* z_thread = nullptr;  // ... by this thread, which phase 1 joins where it needs them (the point decode runs meanwhile)
+    hostpool::Job* z_job = nullptr;  // ... by the hashing pool (host_only.hpp); phase 1 joins in where it needs them (the point decode runs meanwhile)
 };
 // HOST batches of up to this many blobs take their challenges from the host's SHA-NI cores (option host_challenge_max_blobs;
 // 0: never): a blob's SHA-256 chain is 2.8 ms on the GPU however few blobs there are and 65 us on a host core, and the hashing
@@ -515,7 +512,7 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
     }
     if (host && host->z_le) {  // the host hashes the blobs: z crosses as 32 bytes per blob (pinned mirror, bytes [192 T, 224 T))
         w.ktime_valid = false;
-        if (host->z_thread && host->z_thread->joinable()) host->z_thread->join();
+        if (host->z_job) hostpool::finish(*host->z_job);
         memcpy(w.h_buf + 192 * T, host->z_le, 32 * T);
         HIPCHK(hipMemcpyAsync(w.d_z, w.h_buf + 192 * T, 32 * T, hipMemcpyHostToDevice, s->s_sha));
     } else if (host && S > 1) {
@@ -835,7 +832,13 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch_device(bool* ok, const void* d
     return batch_device_locked(ok, d_blobs, d_commitments, d_proofs, n, s);
 }
 
-static KzgRet blob_single_locked(bool* ok, bool* general, const uint8_t* blob, const uint8_t* commitment, const uint8_t* proof, const KzgSettings* s);
+static KzgRet blob_single_locked(bool* ok, bool* general, const uint8_t* blob, const uint8_t* commitment, const uint8_t* proof, const KzgSettings* s,
+                                 hostpool::Job* job = nullptr);
+// the small-call queue of a shared handle (capi_coalesce.hpp)
+static bool small_enabled(const KzgSettings* s);
+static KzgRet small_proofs(bool* ok, uint8_t* err, uint8_t* general, const uint8_t* c, const uint8_t* z, const uint8_t* y, const uint8_t* p, size_t n,
+                           const KzgSettings* s);
+static KzgRet small_blobs(bool* ok, uint8_t* err, uint8_t* general, const uint8_t* blobs, const uint8_t* c, const uint8_t* p, size_t n, const KzgSettings* s);
 static KzgRet blobs_small_locked(bool* ok, bool* general, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n, const KzgSettings* s);
 static void proof_drain(const KzgSettings* s);
 extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs, const uint8_t* commitments,
@@ -846,14 +849,30 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
         return KZG_OK;
     }
     if (!blobs || !commitments || !proofs) return fail(KZG_BADARGS, "null argument");
+    const size_t host_max = host_challenge_max_blobs();
+    static const bool msm_path = opt_is("proof_path", "msm");
+    static const size_t small_max = (size_t)std::max(0L, std::min(256L, opt_int("small_batch_pairings_max", 256)));
+    // The sizes a beacon node calls this with (one blob; the 6-9 blobs of a block; up to small_max): a request in the handle's
+    // small-call queue - concurrent callers share launches on pooled lanes, nobody holds the handle's lock (capi_coalesce.hpp)
+    if (small_enabled(s) && !multi_takes(s, n) && ((n == 1 && host_max >= 1) || (n >= 2 && n <= small_max && n <= host_max))) {
+        bool each = false;
+        uint8_t err = 0, general = 0;
+        const KzgRet qrc = small_blobs(&each, &err, &general, blobs, commitments, proofs, n, s);
+        if (qrc != KZG_OK) return qrc;
+        if (err) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+        if (!general) {
+            *ok = each;
+            return KZG_OK;
+        }
+        // (some z_i = tau: the combined form below decides)
+    }
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
     // several devices: contiguous slices of the Vec<Blob>, each over its own device's PCIe link (capi_multi.hpp)
     if (multi_takes(s, n)) return multi_array_locked(ok, blobs, commitments, proofs, n, true, s);
     KzgRet rc;
-    const size_t host_max = host_challenge_max_blobs();
-    static const bool msm_path = opt_is("proof_path", "msm");
-    if (n == 1 && host_max >= 1 && !msm_path) {  // verify_blob_kzg_proof (:446-470, :482-489): host hash, one-proof tail
+    const bool queued = small_enabled(s);  // (the small forms ran above; what is left of them here is the z = tau fallback)
+    if (n == 1 && host_max >= 1 && !msm_path && !queued) {  // verify_blob_kzg_proof (:446-470, :482-489): host hash, one-proof tail
         bool general = false;
         if ((rc = blob_single_locked(ok, &general, blobs, commitments, proofs, s)) != KZG_OK) {
             proof_drain(s);
@@ -861,8 +880,7 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
         }
         if (!general) return KZG_OK;
     }
-    static const size_t small_max = (size_t)std::max(0L, std::min(256L, opt_int("small_batch_pairings_max", 256)));
-    if (n >= 2 && n <= small_max && n <= host_max && !msm_path) {  // a few blobs: one pairing each, side by side (blobs_small_locked)
+    if (n >= 2 && n <= small_max && n <= host_max && !msm_path && !queued) {  // a few blobs: one pairing each, side by side (blobs_small_locked)
         bool general = false;
         if ((rc = blobs_small_locked(ok, &general, blobs, commitments, proofs, n, s)) != KZG_OK) {
             proof_drain(s);
@@ -874,26 +892,16 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
     Workspace& w = s->ws;
     HostBatch host{blobs, commitments, proofs};  // phase 1 brings the batch over, in slices across the blobs (host_slices)
     std::vector<uint8_t> z_host;
-    std::thread hasher;
-    struct Join {  // (a joinable thread must never be destroyed: whatever path leaves this scope)
-        std::thread& t;
-        ~Join() {
-            if (t.joinable()) t.join();
-        }
-    } join_hasher{hasher};
+    hostpool::JobRef z_job;
     if (n <= host_max) {  // a few blobs: their challenges from the host's SHA-NI cores, beside the point decode on the GPU
         z_host.resize(32 * n);
         host.z_le = z_host.data();
-        const size_t threads = (size_t)std::max(1L, std::min(16L, opt_int("host_threads", 16)));
-        auto work = [&, threads] { host_blob_challenges(z_host.data(), blobs, commitments, n, threads); };
-        try {
-            hasher = std::thread(work);
-            host.z_thread = &hasher;
-        } catch (const std::system_error&) {
-            work();
-        }
+        z_job = hostpool::make(z_host.data(), blobs, commitments, n);
+        hostpool::post(z_job, (size_t)std::max(1L, std::min(16L, opt_int("host_threads", 16))));
+        host.z_job = z_job.get();
     }
     rc = batch_device_locked(ok, w.d_stage_blobs, w.d_stage_cp, w.d_stage_cp + 48 * n, n, s, &host);
+    if (z_job) hostpool::finish(*z_job);  // (an error path may not have come by: no worker may still read the caller's memory)
     if (rc != KZG_OK && s->s_copy) {  // nothing may still read the caller's memory when the error goes back
         const std::string msg = g_err;
         (void)hipStreamSynchronize(s->s_copy);
@@ -1058,10 +1066,18 @@ static KzgRet proof_reserve(ProofStreams& ps, const KzgSettings* s) {
     select_streams(s, (size_t)-1);
     if (!s->d_proof) HIPCHK(hipMalloc(&s->d_proof, sizeof(Fp) * (SCALARS_INPUTS + VERIFY3_INPUTS)));
     const bool one_stream = !s->s_plain[1];  // option single_stream: everything in sequence (profiling)
-    if (!one_stream && !s->s_aux) HIPCHK(hipStreamCreateWithFlags(&s->s_aux, hipStreamNonBlocking));
+    // A lane of the small-call queue runs chain C (the subgroup test) BEHIND chain B on B's stream: the square roots end at
+    // ~0.65 ms and the test at ~1.5 ms, still before A's pairing (~1.7 ms), and a lane then holds two streams instead of three -
+    // four lanes in flight fit the process's 8 hardware queues without two of their streams sharing one (streams that share a
+    // queue run one behind the other: measured with three streams per lane, launches of 3 lanes took 2.6 ms each instead of 1.7).
+    const bool two_streams = s->proof_two_streams && !one_stream;
+    if (!one_stream && !two_streams && !s->s_aux) {
+        const KzgRet rc_aux = stream_make(&s->s_aux, s->stream_priority);
+        if (rc_aux != KZG_OK) return rc_aux;
+    }
     ps.sa = s->s_plain[0];
     ps.sb = one_stream ? ps.sa : s->s_plain[1];
-    ps.sc = one_stream ? ps.sa : s->s_aux;
+    ps.sc = one_stream ? ps.sa : two_streams ? ps.sb : s->s_aux;
     return KZG_OK;
 }
 // B and C: the two square roots -> VERIFY3's point inputs (event ev[6]); the full decode for the subgroup verdict
@@ -1149,7 +1165,8 @@ static KzgRet proof_single_locked(bool* ok, bool* general, const uint8_t* commit
 // ONE blob from host memory (KzgProof::verify_blob_kzg_proof, src/kzg_proof.rs:446-470; the n == 1 branch of the batch form,
 // :482-489): the point chains start at once; the host hashes the blob (65 us) while the blob crosses PCIe; z follows as 32
 // bytes; the evaluation (one wavefront) gives y on the device; then the one-proof tail.  *general as in proof_single_locked.
-static KzgRet blob_single_locked(bool* ok, bool* general, const uint8_t* blob, const uint8_t* commitment, const uint8_t* proof, const KzgSettings* s) {
+static KzgRet blob_single_locked(bool* ok, bool* general, const uint8_t* blob, const uint8_t* commitment, const uint8_t* proof, const KzgSettings* s,
+                                 hostpool::Job* job) {
     *general = false;
     ProofStreams ps{};
     KzgRet rc = proof_reserve(ps, s);
@@ -1160,24 +1177,31 @@ static KzgRet blob_single_locked(bool* ok, bool* general, const uint8_t* blob, c
     if ((rc = proof_points_launch(ps, commitment, proof, s)) != KZG_OK) return rc;
     HIPCHK(hipMemsetAsync(w.d_status, 0, 4, ps.sa));
     HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blob, BLOB_BYTES, hipMemcpyHostToDevice, ps.sa));  // (pageable: the call returns when the bytes have left)
-    host_blob_challenge(h + 192, blob, commitment);
+    if (job) {  // (a caller that queued behind other calls hashed its blob while it waited: capi_coalesce.hpp)
+        hostpool::finish(*job);
+        memcpy(h + 192, job->z_le, 32);
+    } else host_blob_challenge(h + 192, blob, commitment);
     HIPCHK(hipMemcpyAsync(w.d_z, h + 192, 32, hipMemcpyHostToDevice, ps.sa));
     if ((rc = launch_evaluate(s, w.d_stage_blobs, w.d_z, w.d_y, w.d_status, 1)) != KZG_OK) return rc;  // (on s->s1 = sa)
     HIPCHK(hipMemcpyAsync(h + 224, w.d_status, 4, hipMemcpyDeviceToHost, ps.sa));
     rc = proof_tail_locked(ok, general, ps, reinterpret_cast<const uint32_t*>(w.d_z), reinterpret_cast<const uint32_t*>(w.d_y), s);
+    // A runtime failure inside the tail is reported as what it is: the mirrors below are only meaningful once the streams were
+    // synchronised (before that they hold the G1_INVALID they were initialised with, or are still being written), and an
+    // infrastructure failure must never look like the reference's Err(BadArgs) for an invalid input.
+    if (rc != KZG_OK && rc != KZG_BADARGS) return rc;
     // the reference parses the commitment (:453), the blob (:454: a non-canonical element is BadArgs), then the proof (:455)
     const uint32_t* h_pre = reinterpret_cast<const uint32_t*>(h + 160);
     const uint32_t* h_full = reinterpret_cast<const uint32_t*>(h + 176);
     if (h_pre[0] == G1_INVALID || h_full[0] == G1_INVALID) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
-    if (rc == KZG_OK || rc == KZG_BADARGS)
-        if (*reinterpret_cast<const uint32_t*>(h + 224) != 0) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");  // (sic) :38-40
+    if (*reinterpret_cast<const uint32_t*>(h + 224) != 0) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");  // (sic) :38-40
     return rc;
 }
 
 // MANY INDEPENDENT proofs, each with its own pairing and its own result ("verify_kzg_proof x N, each with its
 // own pairing" - the revm precompile's workload when every transaction's proof needs its own verdict): the one-proof path with
 // one program instance (= one workgroup, one CU) per proof - m proofs of a chunk run side by side (mirror layout: ProofsLaunch).
-constexpr size_t PROOFS_CHUNK = 1024;  // proofs per launch (the eight-lane subgroup-test kernel takes up to 8 x 256 points)
+constexpr size_t PROOFS_CHUNK = 1024;
+constexpr size_t SMALL_REQ_MAX_TUPLES = 256;  // a larger kzg_verify_kzg_proofs call fills launches by itself: it takes the handle's own path, not the small-call queue (capi_coalesce.hpp)  // proofs per launch (the eight-lane subgroup-test kernel takes up to 8 x 256 points)
 constexpr size_t PROOFS_MIRROR_BYTES = 64 + 96 + 16 + 8 * sizeof(Fp);
 // one launch of m proofs: the pinned mirror [m][z | y LE] | [m][48] C | [m][48] pi | [m][2] decompression status | [2 m] full-decode
 // status (all C, then all pi) | [m][8] Fp VERIFY3's outputs, and the device buffers [m] SCALARS inputs | [m] VERIFY3 inputs
@@ -1221,8 +1245,10 @@ static KzgRet proofs_reserve(ProofStreams& ps, ProofsLaunch& pl, size_t m, int s
 // decode of all 2 m points for the subgroup verdicts
 static KzgRet proofs_points_launch(const ProofStreams& ps, const ProofsLaunch& pl, const uint8_t* commitments, const uint8_t* proofs, const KzgSettings* s) {
     const size_t m = pl.m;
-    memcpy(pl.h_c, commitments, 48 * m);
-    memcpy(pl.h_p, proofs, 48 * m);
+    if (commitments) {  // (null: the caller gathered the points of several requests into the mirror itself)
+        memcpy(pl.h_c, commitments, 48 * m);
+        memcpy(pl.h_p, proofs, 48 * m);
+    }
     for (size_t i = 0; i < 2 * m; i++) pl.h_pre[i] = pl.h_full[i] = G1_INVALID;
     hipLaunchKernelGGL(k_proof_decompress, dim3((unsigned)((2 * m + 63) / 64)), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), ps.sb, pl.h_c, pl.h_p, (int)m,
                        pl.d_v3in, pl.h_pre);
@@ -1311,49 +1337,80 @@ static KzgRet proofs_independent_locked(bool* ok_out, uint8_t* err, const uint8_
 // whenever this does, and could hold without it only if the hash-derived r hit one of at most n - 1 roots in Fr (< 2^-246).
 // Host: per-blob challenges on SHA-NI threads while the blobs cross PCIe; device: evaluation -> y; then the m-proof tail with
 // z and y read from device memory.  *general = true: some z_i = tau - the caller takes the combined path.
-static KzgRet blobs_small_locked(bool* ok, bool* general, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n, const KzgSettings* s) {
-    *general = false;
+// ... generalised to the blobs of SEVERAL calls in one launch (capi_coalesce.hpp): part k = n blobs of one caller with its own
+// verdict (the conjunction over ITS blobs), its own Err and its own z = tau flag; `job` (optional) = that caller's challenges
+// on their way from the hashing pool (host_only.hpp), else they are hashed here.  m = the parts' blobs in all (<= 256).
+struct BlobsPart {
+    const uint8_t *blobs, *commitments, *proofs;
+    size_t n;
+    hostpool::Job* job;
+    bool ok, bad, general;  // out
+};
+static KzgRet blobs_parts_locked(BlobsPart* parts, size_t n_parts, size_t m, const KzgSettings* s) {
     ProofStreams ps{};
     ProofsLaunch pl{};
-    KzgRet rc = proofs_reserve(ps, pl, n, STAGE_BLOBS, s);
+    KzgRet rc = proofs_reserve(ps, pl, m, STAGE_BLOBS, s);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
-    uint8_t* const h_z = reinterpret_cast<uint8_t*>(pl.h_zy);  // (the mirror's z | y area: 32 n bytes of challenges)
-    uint32_t* const h_status = pl.h_zy + 8 * n;
-    std::thread hasher;
-    struct Join {
-        std::thread& t;
-        ~Join() {
-            if (t.joinable()) t.join();
+    uint8_t* const h_z = reinterpret_cast<uint8_t*>(pl.h_zy);  // (the mirror's z | y area: 32 m bytes of challenges)
+    uint32_t* const h_status = pl.h_zy + 8 * m;
+    std::vector<hostpool::JobRef> own(n_parts);
+    size_t off = 0;
+    for (size_t k = 0; k < n_parts; k++) {
+        BlobsPart& pt = parts[k];
+        memcpy(pl.h_c + 48 * off, pt.commitments, 48 * pt.n);
+        memcpy(pl.h_p + 48 * off, pt.proofs, 48 * pt.n);
+        if (!pt.job) {  // hashed from here: the pool's workers start at once, this thread joins them after the copies below
+            own[k] = hostpool::make(h_z + 32 * off, pt.blobs, pt.commitments, pt.n);
+            static const size_t threads = (size_t)std::max(1L, std::min(16L, opt_int("host_threads", 16)));
+            hostpool::post(own[k], threads);
         }
-    } join_hasher{hasher};
-    const size_t threads = (size_t)std::max(1L, std::min(16L, opt_int("host_threads", 16)));
-    auto work = [&, threads] { host_blob_challenges(h_z, blobs, commitments, n, threads); };
-    bool hashed = false;
-    try {
-        hasher = std::thread(work);
-    } catch (const std::system_error&) {
-        work();
-        hashed = true;
+        off += pt.n;
     }
     HIPCHK(hipEventRecord(s->ev[0], ps.sa));
-    if ((rc = proofs_points_launch(ps, pl, commitments, proofs, s)) != KZG_OK) return rc;
-    HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * n, ps.sa));
-    HIPCHK(hipMemcpyAsync(w.d_stage_blobs, blobs, n * (size_t)BLOB_BYTES, hipMemcpyHostToDevice, ps.sa));  // (pageable: returns when the bytes have left)
-    if (!hashed) hasher.join();
-    HIPCHK(hipMemcpyAsync(w.d_z, h_z, 32 * n, hipMemcpyHostToDevice, ps.sa));
-    if ((rc = launch_evaluate(s, w.d_stage_blobs, w.d_z, w.d_y, w.d_status, n)) != KZG_OK) return rc;  // (on s->s1 = sa)
-    HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * n, hipMemcpyDeviceToHost, ps.sa));
-    if ((rc = proofs_tail_locked(ps, pl, reinterpret_cast<const uint32_t*>(w.d_z), reinterpret_cast<const uint32_t*>(w.d_y), 8u, s)) != KZG_OK) return rc;
-    bool all = true;
-    for (size_t i = 0; i < n; i++) {
-        const ProofVerdict r = proofs_verdict(pl, i);
-        // (every parse failure of the batch form is the same BadArgs: commitments, blobs - a non-canonical element - and proofs)
-        if (r.bad_commitment || r.bad_proof || h_status[i] != 0) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
-        if (r.q_identity) *general = true;
-        all = all && r.equal;
+    if ((rc = proofs_points_launch(ps, pl, nullptr, nullptr, s)) != KZG_OK) return rc;
+    HIPCHK(hipMemsetAsync(w.d_status, 0, 4 * m, ps.sa));
+    off = 0;
+    for (size_t k = 0; k < n_parts; k++) {  // (pageable: each call returns when its bytes have left)
+        HIPCHK(hipMemcpyAsync(w.d_stage_blobs + off * (size_t)BLOB_BYTES, parts[k].blobs, parts[k].n * (size_t)BLOB_BYTES, hipMemcpyHostToDevice, ps.sa));
+        off += parts[k].n;
     }
-    *ok = all;
+    off = 0;
+    for (size_t k = 0; k < n_parts; k++) {
+        if (parts[k].job) {
+            hostpool::finish(*parts[k].job);
+            memcpy(h_z + 32 * off, parts[k].job->z_le, 32 * parts[k].n);
+        } else hostpool::finish(*own[k]);
+        off += parts[k].n;
+    }
+    HIPCHK(hipMemcpyAsync(w.d_z, h_z, 32 * m, hipMemcpyHostToDevice, ps.sa));
+    if ((rc = launch_evaluate(s, w.d_stage_blobs, w.d_z, w.d_y, w.d_status, m)) != KZG_OK) return rc;  // (on s->s1 = sa)
+    HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * m, hipMemcpyDeviceToHost, ps.sa));
+    if ((rc = proofs_tail_locked(ps, pl, reinterpret_cast<const uint32_t*>(w.d_z), reinterpret_cast<const uint32_t*>(w.d_y), 8u, s)) != KZG_OK) return rc;
+    off = 0;
+    for (size_t k = 0; k < n_parts; k++) {
+        BlobsPart& pt = parts[k];
+        pt.ok = true;
+        pt.bad = pt.general = false;
+        for (size_t i = off; i < off + pt.n; i++) {
+            const ProofVerdict r = proofs_verdict(pl, i);
+            // (every parse failure of the batch form is the same BadArgs: commitments, blobs - a non-canonical element - and proofs)
+            if (r.bad_commitment || r.bad_proof || h_status[i] != 0) pt.bad = true;
+            if (r.q_identity) pt.general = true;
+            pt.ok = pt.ok && r.equal;
+        }
+        off += pt.n;
+    }
+    return KZG_OK;
+}
+static KzgRet blobs_small_locked(bool* ok, bool* general, const uint8_t* blobs, const uint8_t* commitments, const uint8_t* proofs, size_t n, const KzgSettings* s) {
+    *general = false;
+    BlobsPart part{blobs, commitments, proofs, n, nullptr, false, false, false};
+    const KzgRet rc = blobs_parts_locked(&part, 1, n, s);
+    if (rc != KZG_OK) return rc;
+    if (part.bad) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+    *general = part.general;
+    *ok = part.ok;
     return KZG_OK;
 }
 
@@ -1368,7 +1425,13 @@ extern "C" KzgRet kzg_verify_kzg_proofs(bool* ok_out, uint8_t* err_out, const ui
     if (!err_out) err_local.resize(n);
     uint8_t* const err = err_out ? err_out : err_local.data();
     std::vector<size_t> general;
-    {
+    if (small_enabled(s) && n <= SMALL_REQ_MAX_TUPLES) {  // a few proofs: a request in the shared handle's small-call queue (capi_coalesce.hpp)
+        std::vector<uint8_t> gen(n);
+        const KzgRet rc = small_proofs(ok_out, err, gen.data(), commitments, zs, ys, proofs, n, s);
+        if (rc != KZG_OK) return rc;
+        for (size_t i = 0; i < n; i++)
+            if (gen[i] && !err[i]) general.push_back(i);
+    } else {
         std::lock_guard<std::mutex> lk(s->mu);
         HIPCHK(hipSetDevice(s->device));
         const KzgRet rc = proofs_independent_locked(ok_out, err, commitments, zs, ys, proofs, n, s, general);
@@ -1403,7 +1466,15 @@ extern "C" KzgRet kzg_verify_kzg_proof(bool* ok, const uint8_t commitment[48], c
     if (!msm_path) {
         if (be_geq_r(z) || be_geq_r(y)) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");  // (sic) :360-371
         bool general = false;
-        {
+        if (small_enabled(s)) {  // a request in the shared handle's small-call queue: concurrent callers share launches (capi_coalesce.hpp)
+            bool each = false;
+            uint8_t err = 0, gen = 0;
+            const KzgRet rc = small_proofs(&each, &err, &gen, commitment, z, y, proof, 1, s);
+            if (rc != KZG_OK) return rc;
+            if (err) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+            general = gen != 0;
+            if (!general) *ok = each;
+        } else {
             std::lock_guard<std::mutex> lk(s->mu);
             HIPCHK(hipSetDevice(s->device));
             const KzgRet rc = proof_single_locked(ok, &general, commitment, z, y, proof, s);
@@ -1429,14 +1500,32 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
     if (!commitments || !zs || !ys || !proofs) return fail(KZG_BADARGS, "null argument");
     for (size_t i = 0; i < n; i++)
         if (be_geq_r(zs + 32 * i) || be_geq_r(ys + 32 * i)) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
-    std::lock_guard<std::mutex> lk(s->mu);
-    HIPCHK(hipSetDevice(s->device));
-    KzgRet rc;
     // a few tuples: one pairing each, side by side on CUs of their own, and the conjunction of the verdicts (the reasoning at
     // blobs_small_locked) - 1.7 ms against the 2.9 ms of decode -> MSM -> pairing.  option small_batch_pairings_max=0: always combined
     static const size_t small_max = (size_t)std::max(0L, std::min(256L, opt_int("small_batch_pairings_max", 256)));
     static const bool msm_path = opt_is("proof_path", "msm");
-    if (n >= 2 && n <= small_max && !msm_path) {
+    bool queued = false;
+    if (n >= 2 && n <= small_max && small_enabled(s)) {  // ... as a request in the shared handle's small-call queue (capi_coalesce.hpp)
+        std::vector<uint8_t> res(3 * n);
+        bool* const each = reinterpret_cast<bool*>(res.data());
+        const KzgRet qrc = small_proofs(each, res.data() + n, res.data() + 2 * n, commitments, zs, ys, proofs, n, s);
+        if (qrc != KZG_OK) return qrc;
+        bool all = true, any_general = false;
+        for (size_t i = 0; i < n; i++) {
+            if (res[n + i]) return fail(KZG_BADARGS, "Failed to parse G1Affine from bytes");
+            any_general = any_general || res[2 * n + i];
+            all = all && each[i];
+        }
+        if (!any_general) {
+            *ok = all;
+            return KZG_OK;
+        }
+        queued = true;  // (some z_i = tau: the combined path below decides)
+    }
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    KzgRet rc;
+    if (n >= 2 && n <= small_max && !msm_path && !queued) {
         std::vector<uint8_t> verdicts(2 * n);
         std::vector<size_t> general;
         bool* const each = reinterpret_cast<bool*>(verdicts.data());

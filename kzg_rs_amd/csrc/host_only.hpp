@@ -11,6 +11,11 @@
 #include <algorithm>
 #include <string>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -275,22 +280,113 @@ static void host_blob_challenge(uint8_t z_le[32], const uint8_t* blob, const uin
     while (be_geq_r(dg)) be_sub_r(dg);  // digest mod r (:74-91)
     reverse32(z_le, dg);
 }
-static void host_blob_challenges(uint8_t* z_le, const uint8_t* blobs, const uint8_t* commitments, size_t n, size_t max_threads) {
-    auto range = [&](size_t i0, size_t i1) {
-        for (size_t i = i0; i < i1; i++) host_blob_challenge(z_le + 32 * i, blobs + (size_t)32 * KZG_HOST_FE_PER_BLOB * i, commitments + 48 * i);
-    };
-    const size_t nthr = std::max<size_t>(1, std::min(max_threads, n));
-    if (nthr == 1) return range(0, n);
-    std::vector<std::thread> pool;
-    for (size_t k = 1; k < nthr; k++) {
-        try {
-            pool.emplace_back(range, n * k / nthr, n * (k + 1) / nthr);
-        } catch (const std::system_error&) {
-            range(n * k / nthr, n * (k + 1) / nthr);
+// The per-blob challenge hashes of host batches run on ONE persistent pool of host threads per process (option host_threads,
+// default 16, started by the first job with more than one blob): rounds 3-4 spawned a thread plus up to 16 hashing threads in
+// every call, which T concurrent callers turned into 17 T threads.  A job is n independent chains; whoever holds it claims
+// blob indices from an atomic counter - the pool's workers, the thread that posted it, the leader of the launch that needs
+// its challenges (capi_coalesce.hpp) - so a job never waits for a worker to become free, and a caller that has to wait for
+// the GPU anyway hashes its own blobs meanwhile.
+namespace hostpool {
+struct Job {
+    const uint8_t *blobs = nullptr, *commitments = nullptr;
+    uint8_t* z_le = nullptr;  // n x 32 bytes, little-endian (the device limb layout)
+    size_t n = 0;
+    std::atomic<size_t> next{0}, done{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    bool unclaimed() const { return next.load(std::memory_order_relaxed) < n; }
+};
+using JobRef = std::shared_ptr<Job>;
+// claim and hash blobs of the job until none is left unclaimed (does not wait for the ones other threads hold)
+static void help(Job& j) {
+    for (;;) {
+        const size_t i = j.next.fetch_add(1, std::memory_order_relaxed);
+        if (i >= j.n) return;
+        host_blob_challenge(j.z_le + 32 * i, j.blobs + (size_t)32 * KZG_HOST_FE_PER_BLOB * i, j.commitments + 48 * i);
+        if (j.done.fetch_add(1, std::memory_order_acq_rel) + 1 == j.n) {
+            std::lock_guard<std::mutex> lk(j.mu);
+            j.cv.notify_all();
         }
     }
-    range(0, n / nthr);
-    for (auto& th : pool) th.join();
+}
+// help, then wait until every blob of the job has its challenge
+static void finish(Job& j) {
+    help(j);
+    if (j.done.load(std::memory_order_acquire) == j.n) return;
+    std::unique_lock<std::mutex> lk(j.mu);
+    j.cv.wait(lk, [&] { return j.done.load(std::memory_order_acquire) == j.n; });
+}
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<JobRef> jobs;
+    size_t workers = 0, idle = 0, max_workers = 16;
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            while (!jobs.empty() && !jobs.front()->unclaimed()) jobs.pop_front();
+            if (jobs.empty()) {
+                idle++;
+                cv.wait(lk);
+                idle--;
+                continue;
+            }
+            JobRef j = jobs.front();
+            lk.unlock();
+            help(*j);
+            lk.lock();
+        }
+    }
+};
+static Pool& pool() {  // (never destroyed: its detached workers may be parked in it when the process exits)
+    static Pool* p = [] {
+        Pool* q = new Pool();
+#ifdef KZG_HOST_THREADS_OPTION
+        const long v = KZG_HOST_THREADS_OPTION;
+#else
+        const long v = 16;
+#endif
+        const unsigned hc = std::thread::hardware_concurrency();
+        q->max_workers = (size_t)std::max(1L, std::min(v < 1 ? 1 : v, hc ? (long)hc : 16L));
+        return q;
+    }();
+    return *p;
+}
+// hand the job to the pool's workers (a job of one blob stays with its poster: waking a worker costs more than the chain);
+// max_threads caps how many workers are woken for it
+static void post(const JobRef& j, size_t max_threads = (size_t)-1) {
+    if (j->n < 2 || max_threads < 2) return;
+    Pool& P = pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    P.jobs.push_back(j);
+    size_t want = std::min(std::min(j->n, max_threads), P.max_workers);
+    while (P.workers < P.max_workers && P.workers < P.workers - P.idle + want) {  // started < busy + wanted
+        try {
+            std::thread(&Pool::worker, &P).detach();
+            P.workers++;
+        } catch (const std::system_error&) {
+            break;  // (the poster and whoever needs the result hash what no worker takes)
+        }
+    }
+    if (want >= P.idle) P.cv.notify_all();
+    else
+        for (size_t k = 0; k < want; k++) P.cv.notify_one();
+}
+static JobRef make(uint8_t* z_le, const uint8_t* blobs, const uint8_t* commitments, size_t n) {
+    JobRef j = std::make_shared<Job>();
+    j->blobs = blobs;
+    j->commitments = commitments;
+    j->z_le = z_le;
+    j->n = n;
+    return j;
+}
+}  // namespace hostpool
+// n challenges, on the calling thread and up to max_threads - 1 workers of the pool; returns when all are written
+static void host_blob_challenges(uint8_t* z_le, const uint8_t* blobs, const uint8_t* commitments, size_t n, size_t max_threads) {
+    if (n == 0) return;
+    hostpool::JobRef j = hostpool::make(z_le, blobs, commitments, n);
+    hostpool::post(j, max_threads);
+    hostpool::finish(*j);
 }
 
 static bool host_batch_challenges(uint8_t* r_out, const uint8_t* all_records, size_t B, size_t n, size_t n_total, size_t world) {

@@ -55,6 +55,7 @@ extern "C" const unsigned char kzg_slp_prep_begin[], kzg_slp_prep_end[], kzg_slp
 #include "capi_settings.hpp"
 #include "capi_verify.hpp"
 #include "capi_multi.hpp"
+#include "capi_coalesce.hpp"
 #include "capi_pipeline.hpp"
 #include "capi_pieces.hpp"
 #include "capi_prover.hpp"

@@ -180,6 +180,34 @@ int main(int argc, char** argv) {
     host_batch_challenges(rb.data(), big.data(), 40, 1024, 1024, 0);
     for (size_t b = 0; b < 40; b++) host_batch_challenges(rs.data() + 32 * b, big.data() + 160 * 1024 * b, 1, 1024, 1024, 0);
     CHECK(rb == rs);
+    {   // the per-blob challenges on the persistent pool (hostpool): 8 caller threads at once, each with jobs of 1..5 blobs, some of
+        // them posted and finished by different threads (the small-call queue's leader finishes jobs its followers posted)
+        const size_t BLOB = (size_t)32 * KZG_HOST_FE_PER_BLOB, NB = 5;
+        std::vector<uint8_t> blobs(BLOB * NB), cs(48 * NB), want(32 * NB);
+        for (auto& x : blobs) x = (uint8_t)rng();
+        for (auto& x : cs) x = (uint8_t)rng();
+        for (size_t i = 0; i < NB; i++) host_blob_challenge(want.data() + 32 * i, blobs.data() + BLOB * i, cs.data() + 48 * i);
+        std::atomic<int> wrong{0};
+        std::vector<std::thread> callers;
+        for (int t = 0; t < 8; t++)
+            callers.emplace_back([&, t] {
+                for (int rep = 0; rep < 6; rep++) {
+                    const size_t n = 1 + (size_t)((t + rep) % NB);
+                    std::vector<uint8_t> z(32 * n, 0xee);
+                    if (rep & 1) host_blob_challenges(z.data(), blobs.data(), cs.data(), n, 16);
+                    else {
+                        hostpool::JobRef j = hostpool::make(z.data(), blobs.data(), cs.data(), n);
+                        hostpool::post(j);
+                        std::thread other([j] { hostpool::finish(*j); });
+                        other.join();
+                        hostpool::finish(*j);  // (a second finish of a complete job returns at once)
+                    }
+                    if (memcmp(z.data(), want.data(), 32 * n) != 0) wrong++;
+                }
+            });
+        for (auto& th : callers) th.join();
+        CHECK(wrong.load() == 0);
+    }
     printf("failures %d\n", failures);
     return failures ? 1 : 0;
 }
