@@ -242,7 +242,7 @@ def single_process_leg(spec, n, steps, warmup):
         host = {"ms_per_call": round((time.perf_counter() - t0) / steps * 1e3, 4), "ok": bool(okh.value),
                 "stage_ms": {k: round(v, 4) for k, v in zip(stage_names, hst)}}
     devices, exchange = st.devices()
-    print(json.dumps({"devices": devices, "exchange": exchange, "batch": n * D, "blobs_per_device": n, "steps": steps,
+    print(json.dumps({"devices": devices, "exchange": exchange, "exchange_note": st.note(), "batch": n * D, "blobs_per_device": n, "steps": steps,
                       "sharded_batch": {"ms_per_call": round(dt * 1e3, 4), "value": round(n * D / dt, 2), "unit": "blobs/s", "ok": bool(ok),
                                         "corrupted_proof_on_last_device": neg,
                                         "stage_ms": {k: round(v, 4) for k, v in zip(stage_names, stages)}},
@@ -776,17 +776,19 @@ def main():
 
 
 def run_single_process_child(devices, n, timeout=300):
-    """The one-process leg in child processes (a failure or a hang there costs that leg, not the line): once with the default
-    exchange (partial sums through pinned host memory) and once with the in-process RCCL all-gather (KZG_OPTIONS
-    multi_exchange=rccl) - on a list of distinct devices that is the north star's collective over xGMI."""
+    """The one-process leg in child processes (a failure or a hang there costs that leg, not the line): with the exchange the
+    handle's own self-test selects (csrc/capi_multi.hpp multi_exchange_selftest: host memory vs ncclAllGather compared bit for
+    bit at construction; `exchange` and `exchange_note` of the leg say which one won and why), then with each exchange forced
+    (KZG_OPTIONS multi_exchange=host | rccl) - on a list of distinct devices the RCCL one is the north star's collective over xGMI."""
     import subprocess
     out = {}
-    for name, opts in (("host_exchange", None), ("rccl_exchange", "multi_exchange=rccl")):
+    for name, opts in (("selected_exchange", None), ("host_exchange", "multi_exchange=host"), ("rccl_exchange", "multi_exchange=rccl")):
         env = dict(os.environ)
-        if opts:
+        if opts and opts.endswith("rccl"):
             if len(set(devices.split(","))) != len(devices.split(",")):
                 out[name] = {"skipped": "the device list names a device twice: ncclCommInitAll needs distinct devices"}
                 continue
+        if opts:
             env["KZG_OPTIONS"] = ";".join(x for x in (env.get("KZG_OPTIONS"), opts) if x)
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-process-devices", devices, "--blobs", str(n)],

@@ -93,15 +93,18 @@ KzgRet kzg_settings_from_tau_g2(KzgSettings **out, const uint8_t tau_g2[96]);
  * The handle is also a complete single-device handle on devices[0]: the single-proof, prover-side and kzg_shard_* entry
  * points (the one-process-per-GPU form) run there.  The plain constructors above read KZG_DEVICES ("all" or "0,1,2,...")
  * from the environment, so an unchanged caller gets the same handle without a source change.
- * Exchange of the partial sums: through pinned host memory by default (288 bytes per chunk); KZG_OPTIONS
- * multi_exchange=rccl selects an in-process RCCL all-gather over xGMI (ncclCommInitAll + ncclAllGather) instead - an
- * opt-in because this project's test boxes have one GPU, so that leg has only ever run in a world of one; with =rccl a
- * handle on which RCCL is unusable (librccl missing, a device named twice) fails to construct. */
+ * Exchange of the partial sums (288 bytes per chunk): the constructor asks RCCL for in-process communicators over the device
+ * list and PROVES that leg before using it - two synthetic sharded batches (KZG_OPTIONS multi_selftest_blobs = 128 blobs per
+ * device) are verified once with the sums carried through pinned host memory and once with ncclAllGather over xGMI, and the
+ * gathered [devices][slots] x 288-byte buffers and the verdicts must agree bit for bit.  Equal: exchange = RCCL.  RCCL
+ * unusable (librccl missing, a device named twice) or any difference: exchange = host memory.  kzg_settings_note() carries the
+ * outcome either way.  KZG_OPTIONS multi_exchange=host | rccl forces one; with =rccl a handle on which RCCL is unusable or
+ * fails its self-test does not construct. */
 KzgRet kzg_settings_load_trusted_setup_devices(KzgSettings **out, const char *txt, size_t len, const int *devices,
                                                size_t n_devices);
 KzgRet kzg_settings_from_tau_g2_devices(KzgSettings **out, const uint8_t tau_g2[96], const int *devices, size_t n_devices);
 /* The shape of a handle: *n_devices shards, shard k on devices_out[k] (optional, `cap` entries); *exchange (optional) =
- * 0 single device, 1 partial sums through host memory (kzg_last_error() then says why), 2 in-process RCCL all-gather. */
+ * 0 single device, 1 partial sums through host memory (kzg_settings_note() says why), 2 in-process RCCL all-gather. */
 KzgRet kzg_settings_devices(const KzgSettings *s, size_t *n_devices, int *devices_out, size_t cap, int *exchange);
 void kzg_settings_free(KzgSettings *s);
 /* What a successful constructor wants its caller to know about the handle ("" = nothing): fewer than 8 HIP hardware queues,

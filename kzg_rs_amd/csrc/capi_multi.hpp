@@ -72,7 +72,8 @@ static RcclApi* rccl_api() {
     return &api;
 }
 
-enum { MULTI_EXCHANGE_NONE = 0, MULTI_EXCHANGE_HOST = 1, MULTI_EXCHANGE_RCCL = 2 };
+enum { MULTI_EXCHANGE_NONE = 0, MULTI_EXCHANGE_HOST = 1, MULTI_EXCHANGE_RCCL = 2,
+       MULTI_EXCHANGE_BOTH = 3 };  // BOTH: the self-test only - the same partial sums through RCCL and through host memory, folded and paired twice
 constexpr size_t MULTI_MAX_PIECES = MAX_WORLD;  // pieces of one sharded batch: each contributes one 288-byte partial to the fold
 struct MultiState {
     std::vector<int> devices;        // shard k runs on devices[k]; shard 0 is the handle itself
@@ -83,6 +84,7 @@ struct MultiState {
     size_t chunks_per_device = 8;    // a host (or single-device) array is dealt in about this many chunks per device (option multi_chunks)
     size_t min_chunk = 128;          // ... of at least this many blobs (option multi_min_chunk)
     std::mutex rccl_mu;              // collectives of concurrent lane sets go out one at a time: the same order on every communicator
+    std::mutex last_r_mu;            // the test hook's copy of the last batch challenge (batches of a sharded stream finish on several threads)
 };
 
 static const KzgSettings* shard_of(const KzgSettings* s, size_t k) { return k == 0 ? s : s->peers[k - 1]; }
@@ -143,11 +145,9 @@ static void multi_free(KzgSettings* s) {
     s->peers.clear();
 }
 
-// Peers of a freshly built shard 0 (s->device == devices[0]) and the exchange.  On failure the caller frees the handle.
-// The partial sums travel through pinned host memory unless option multi_exchange=rccl asks for the in-process RCCL
-// all-gather: that leg has run on this project's test boxes only in a world of ONE device (they have one GPU), so a
-// security-critical verifier does not pick it by itself; with =rccl a handle on which RCCL is unusable (library missing, a
-// device named twice - ncclCommInitAll refuses duplicates - or a failing communicator) is an error, never a silent fallback.
+static KzgRet multi_exchange_selftest(KzgSettings* s, bool& equal, std::string& verdict);
+// Peers of a freshly built shard 0 (s->device == devices[0]) and the exchange (chosen by a self-test, see below).  On failure
+// the caller frees the handle.
 static KzgRet multi_build(KzgSettings* s, const uint8_t tau_g2[96], const std::vector<int>& devices) {
     const bool force = opt_flag("multi_force", false);  // test rig: a list of ONE device still takes the sharded path
     if (devices.size() < 2 && !force) return KZG_OK;  // a plain single-device handle
@@ -173,15 +173,22 @@ static KzgRet multi_build(KzgSettings* s, const uint8_t tau_g2[96], const std::v
         HIPCHK(hipSetDevice(c->device));
         if ((rc = ws_reserve(c, 16, 1, STAGE_NONE)) != KZG_OK) return rc;
     }
+    // How the 288-byte partial sums travel.  KZG_OPTIONS multi_exchange=host | rccl forces one; otherwise the handle asks RCCL
+    // for in-process communicators and PROVES the leg on this very set of devices before trusting it: multi_exchange_selftest
+    // runs synthetic sharded batches through both exchanges and compares the gathered buffers bit for bit and the verdicts.
+    // Equal -> the north star's "RCCL all-gather over xGMI" is the exchange; RCCL unusable, or any difference -> pinned host
+    // memory, and the handle's note (kzg_settings_note) says why.  Rounds 3-4 kept RCCL an opt-in because no box this project
+    // ran on had two GPUs; the self-test is what lets the first box that has them switch it on safely.
     const char* ex = opt_str("multi_exchange");
-    const bool want_rccl = ex && strcmp(ex, "rccl") == 0;
+    const bool want_rccl = ex && strcmp(ex, "rccl") == 0, want_host = ex && strcmp(ex, "host") == 0;
     m->exchange = MULTI_EXCHANGE_HOST;
-    if (!want_rccl) m->exchange_note = "partial sums through pinned host memory (the default; option multi_exchange=rccl selects the in-process RCCL all-gather)";
+    if (want_host) m->exchange_note = "partial sums through pinned host memory (forced: multi_exchange=host)";
     else {
         bool distinct = true;
         for (size_t a = 0; a < D; a++)
             for (size_t b = a + 1; b < D; b++) distinct &= devices[a] != devices[b];
         RcclApi* api = distinct ? rccl_api() : nullptr;
+        bool usable = false;
         if (!distinct) m->exchange_note = "the device list names a device twice (ncclCommInitAll needs distinct devices)";
         else if (!api->CommInitAll) m->exchange_note = api->why;
         else {
@@ -200,15 +207,45 @@ static KzgRet multi_build(KzgSettings* s, const uint8_t tau_g2[96], const std::v
                     HIPCHK(hipSetDevice(h[k]->device));
                     HIPCHK(hipMemsetAsync(h[k]->ws.d_send, 0, 288, h[k]->s1));
                 }
-                if ((rc = multi_allgather_partials(s, h, 1)) != KZG_OK) return rc;
-                for (size_t k = 0; k < D; k++) {
+                rc = multi_allgather_partials(s, h, 1);
+                for (size_t k = 0; k < D && rc == KZG_OK; k++) {
                     HIPCHK(hipSetDevice(h[k]->device));
-                    HIPCHK(hipStreamSynchronize(h[k]->s1));
+                    if (hipStreamSynchronize(h[k]->s1) != hipSuccess) {
+                        (void)hipGetLastError();
+                        rc = fail(KZG_ERROR, "HIP: hipStreamSynchronize behind the warm-up collective");
+                    }
                 }
+                if (rc != KZG_OK) m->exchange_note = "the warm-up ncclAllGather failed: " + g_err;
+                else usable = true;
             }
         }
-        if (m->exchange != MULTI_EXCHANGE_RCCL) return fail(KZG_ERROR, "multi_exchange=rccl but RCCL is unusable: " + m->exchange_note);
+        if (usable) {
+            std::string verdict;
+            bool equal = false;
+            rc = multi_exchange_selftest(s, equal, verdict);
+            if (rc != KZG_OK) {
+                verdict = "exchange self-test could not run: " + g_err;
+                equal = false;
+            }
+            m->exchange_note = verdict;
+            if (!equal) {
+                usable = false;
+                fprintf(stderr, "kzg_rs_amd: %s - the partial sums of this handle travel through pinned host memory\n", verdict.c_str());
+            }
+        }
+        m->exchange = usable ? MULTI_EXCHANGE_RCCL : MULTI_EXCHANGE_HOST;
+        if (!usable) {
+            for (size_t k = 0; k < m->comms.size(); k++)
+                if (m->comms[k] && rccl_api()->CommDestroy) {
+                    (void)hipSetDevice(devices[k]);
+                    (void)rccl_api()->CommDestroy(m->comms[k]);
+                }
+            m->comms.clear();
+            if (want_rccl) return fail(KZG_ERROR, "multi_exchange=rccl but RCCL is unusable: " + m->exchange_note);
+            m->exchange_note = "partial sums through pinned host memory: " + m->exchange_note;
+        }
     }
+    s->note = "exchange: " + m->exchange_note;
     if (s->small) s->small->max_lanes = std::min<size_t>(16, s->small->max_lanes * D);  // small calls: the same number of lanes on every device (lane i on shard i mod D)
     HIPCHK(hipSetDevice(s->device));
     return KZG_OK;
@@ -235,6 +272,11 @@ struct MultiTimes {
     // [0] whole call [1] inputs onto the devices + phase 1, all pieces [2] what the transcript hash added after the last piece
     // [3] phase-2 launches [4] exchange [5] fold + pairing [6] the hash's own busy time [7] pieces
     float ms[8] = {};
+    // (the exchange self-test) the gathered partial sums as the fold sees them: [D][slots] x 288 B, slot j of shard k = its j-th
+    // piece's (A, B), unused slots all-zero = the identity - the same layout whichever way they travelled
+    std::vector<uint8_t>* capture = nullptr;
+    std::vector<uint8_t>* capture_rccl = nullptr;  // (exchange BOTH: capture = the host leg's buffer, capture_rccl = ncclAllGather's)
+    bool ok_rccl = false;                          // (exchange BOTH: the verdict of the fold + pairing fed by ncclAllGather; *ok = the host leg's)
 };
 
 // ONE batch as pieces, listed in global blob order; src_dev: the device the inputs lie on (MultiSrc::OneDevice).  The caller
@@ -420,17 +462,21 @@ static KzgRet multi_pieces_locked(bool* ok, std::vector<Piece>& pieces, size_t n
     // ---- r: the transcript was hashed as the pieces came in; close it
     uint8_t r_le[32] = {0};
     if (n_total > 1) transcript.r(r_le);
-    memcpy(s->multi_last_r, r_le, 32);
+    {
+        std::lock_guard<std::mutex> lk_r(m->last_r_mu);
+        memcpy(s->multi_last_r, r_le, 32);
+    }
     tm.ms[2] = (float)ms_since(t_last_piece);
     tm.ms[6] = (float)hash_busy;
     tm.ms[7] = (float)NP;
     // ---- phase 2 on every piece (launches only), then the exchange
     auto t0 = std::chrono::steady_clock::now();
-    const bool rccl = m->exchange == MULTI_EXCHANGE_RCCL;
+    const bool both = m->exchange == MULTI_EXCHANGE_BOTH;  // (the self-test: one set of partial sums, both ways)
+    const bool rccl = m->exchange == MULTI_EXCHANGE_RCCL || both;
     KzgRet rc = KZG_OK;
     for (size_t i = 0; i < NP; i++) {
         if (hipSetDevice(pieces[i].h->device) != hipSuccess) return drain_all(fail(KZG_ERROR, "HIP: hipSetDevice"));
-        if ((rc = phase2_launch_locked(nullptr, n_total, pieces[i].off, pieces[i].h, 0, r_le, /*want_partials=*/!rccl)) != KZG_OK) return drain_all(rc);
+        if ((rc = phase2_launch_locked(nullptr, n_total, pieces[i].off, pieces[i].h, 0, r_le, /*want_partials=*/!rccl || both)) != KZG_OK) return drain_all(rc);
     }
     tm.ms[3] = (float)ms_since(t0);
     t0 = std::chrono::steady_clock::now();
@@ -455,17 +501,33 @@ static KzgRet multi_pieces_locked(bool* ok, std::vector<Piece>& pieces, size_t n
         }
         if ((rc = multi_allgather_partials(s, h, cnt)) != KZG_OK) return drain_all(rc);
         if (hipSetDevice(fold->device) != hipSuccess) return drain_all(fail(KZG_ERROR, "HIP: hipSetDevice"));
+        std::vector<uint8_t>* const cap = both ? tm.capture_rccl : tm.capture;
+        if (cap) {  // (behind the collective on the fold's stream; read after finish_wait_locked has waited for that stream)
+            cap->assign(288 * D * cnt, 0);
+            if (hipMemcpyAsync(cap->data(), fold->ws.d_parts, 288 * D * cnt, hipMemcpyDeviceToHost, fold->s1) != hipSuccess)
+                return drain_all(fail(KZG_ERROR, "HIP: hipMemcpyAsync"));
+        }
         tm.ms[4] = (float)ms_since(t0);
         t0 = std::chrono::steady_clock::now();
         if ((rc = finish_launch_locked(nullptr, D * cnt, 1, fold, /*parts_on_device=*/true)) != KZG_OK) return drain_all(rc);
-    } else {
+    }
+    if (!rccl || both) {
         std::vector<uint8_t> parts(288 * NP);
         for (size_t i = 0; i < NP; i++) {
             if (hipSetDevice(pieces[i].h->device) != hipSuccess) return drain_all(fail(KZG_ERROR, "HIP: hipSetDevice"));
             if ((rc = phase2_wait_locked(parts.data() + 288 * i, pieces[i].h)) != KZG_OK) return drain_all(rc);
         }
         if (hipSetDevice(fold->device) != hipSuccess) return drain_all(fail(KZG_ERROR, "HIP: hipSetDevice"));
-        tm.ms[4] = (float)ms_since(t0);
+        // (the self-test: the pairing fed by ncclAllGather is in flight on the fold's stream - its verdict first; only now, because
+        // finish_wait_locked closes the fold handle's group and phase2_wait_locked above reads the group's size)
+        if (both && (rc = finish_wait_locked(&tm.ok_rccl, fold)) != KZG_OK) return drain_all(rc);
+        if (tm.capture) {
+            const size_t cnt = std::max<size_t>(1, max_per_shard);
+            tm.capture->assign(288 * D * cnt, 0);
+            for (size_t k = 0; k < D; k++)
+                for (size_t j = 0; j < of_shard[k].size(); j++) memcpy(tm.capture->data() + 288 * (k * cnt + j), parts.data() + 288 * of_shard[k][j], 288);
+        }
+        if (!both) tm.ms[4] = (float)ms_since(t0);
         t0 = std::chrono::steady_clock::now();
         if ((rc = finish_launch_locked(parts.data(), NP, 1, fold)) != KZG_OK) return drain_all(rc);
     }
@@ -520,6 +582,102 @@ static KzgRet multi_batch_resident(bool* ok, const std::vector<ShardIn>& in, con
         off += in[k].n;
     }
     return multi_pieces_locked(ok, pieces, off, MultiSrc::PerDevice, -1, s, lane, tm);
+}
+
+// First contact with this set of devices (multi_build): is the in-process RCCL all-gather of the partial sums THE SAME as
+// carrying them through host memory?  Two synthetic batches of `nb` blobs per shard, resident on their devices; the
+// partial sums of each batch travel BOTH ways (the very same device buffers: a partial sum is a Jacobian triple, and a second
+// MSM run may reach the same point through another order of additions and so another triple - the first form of this test
+// compared two runs and saw "DIFFER" with equal verdicts) - ncclAllGather into the fold's device buffer, and through the pinned
+// mirrors - with the gathered [D][slots] x 288-byte buffer captured as the fold reads it, and fold + pairing run once from each:
+//   batch 1: pseudo-random canonical blobs, commitments (3 + 2 i) G and proofs (5 + 7 i) G: not a valid batch under any setup
+//            (the verdict must be false both ways), but every shard's partial sums are non-trivial points that depend on every
+//            blob of the batch through r - a byte that goes missing or lands in the wrong slot changes the buffer;
+//   batch 2: all-zero blobs with commitment and proof at infinity: VALID under every setup (p = 0: C = O, y = 0, pi = O) -
+//            the verdict must be true both ways, and every slot is the identity.
+// equal = all four runs succeeded, the buffers are bit-identical per batch and the verdicts are false / true as expected.
+// option multi_selftest_blobs = blobs per shard (default 128; 0 skips the test and trusts RCCL as rounds 3-4's opt-in did).
+static KzgRet multi_exchange_selftest(KzgSettings* s, bool& equal, std::string& verdict) {
+    MultiState* m = s->multi;
+    const size_t D = shard_count(s);
+    const size_t nb = (size_t)std::max(0L, std::min(4096L, opt_int("multi_selftest_blobs", 128)));
+    equal = true;
+    if (nb == 0) {
+        verdict = "RCCL all-gather (in-process communicators), self-test skipped (multi_selftest_blobs=0)";
+        return KZG_OK;
+    }
+    const auto t_start = std::chrono::steady_clock::now();
+    KzgRet rc = multi_ensure_lanes(s, 1);
+    if (rc != KZG_OK) return rc;
+    std::vector<DevTmp> d_blobs(D), d_cp(D), d_sc(D);
+    std::vector<uint8_t> hb(nb * (size_t)BLOB_BYTES), hs(64 * nb);
+    std::vector<ShardIn> in(D);
+    const int saved_exchange = m->exchange;
+    bool verdicts[2][2] = {{false, false}, {false, false}};
+    std::vector<uint8_t> cap[2][2];
+    for (int batch = 0; batch < 2 && rc == KZG_OK; batch++) {
+        for (size_t k = 0; k < D && rc == KZG_OK; k++) {
+            const KzgSettings* c = shard_of(s, k);
+            HIPCHK(hipSetDevice(c->device));
+            if (!d_blobs[k].p) {
+                HIPCHK(hipMalloc(&d_blobs[k].p, nb * (size_t)BLOB_BYTES));
+                HIPCHK(hipMalloc(&d_cp[k].p, 96 * nb));
+                HIPCHK(hipMalloc(&d_sc[k].p, 64 * nb));
+            }
+            uint8_t* cp = d_cp[k].as<uint8_t>();
+            if (batch == 0) {
+                uint64_t x = 0x9E3779B97F4A7C15ull * (k + 1) + 0x1234567ull;  // xorshift64*: reproducible, different per shard
+                uint64_t* w = reinterpret_cast<uint64_t*>(hb.data());
+                for (size_t i = 0; i < hb.size() / 8; i++) {
+                    x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+                    w[i] = x * 0x2545F4914F6CDD1Dull;
+                }
+                for (size_t i = 0; i < hb.size(); i += 32) hb[i] &= 0x3F;  // every field element below 2^254 < r (big-endian: byte 0 leads)
+                memset(hs.data(), 0, hs.size());
+                for (size_t i = 0; i < nb; i++) {  // little-endian scalars: commitments (3 + 2 g) G | proofs (5 + 7 g) G, g = the global index
+                    const uint64_t g = k * nb + i, a = 3 + 2 * g, b = 5 + 7 * g;
+                    memcpy(hs.data() + 32 * i, &a, 8);
+                    memcpy(hs.data() + 32 * (nb + i), &b, 8);
+                }
+                HIPCHK(hipMemcpyAsync(d_blobs[k].p, hb.data(), hb.size(), hipMemcpyHostToDevice, c->s1));
+                HIPCHK(hipMemcpyAsync(d_sc[k].p, hs.data(), hs.size(), hipMemcpyHostToDevice, c->s1));
+                hipLaunchKernelGGL(k_g1_mul_generator, dim3((unsigned)((2 * nb + 63) / 64)), dim3(64), 0, c->s1, d_sc[k].as<Fr>(), cp, (int)(2 * nb));
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipStreamSynchronize(c->s1));  // (hb / hs are refilled for the next shard)
+            } else {
+                HIPCHK(hipMemsetAsync(d_blobs[k].p, 0, nb * (size_t)BLOB_BYTES, c->s1));
+                std::vector<uint8_t> inf(96 * nb, 0);
+                for (size_t i = 0; i < 2 * nb; i++) inf[48 * i] = 0xC0;
+                HIPCHK(hipMemcpyAsync(cp, inf.data(), inf.size(), hipMemcpyHostToDevice, c->s1));
+                HIPCHK(hipStreamSynchronize(c->s1));
+            }
+            in[k] = ShardIn{d_blobs[k].as<uint8_t>(), cp, cp + 48 * nb, nb};
+        }
+        if (rc == KZG_OK) {  // ONE run: the same partial sums through both exchanges, folded and paired once from each
+            m->exchange = MULTI_EXCHANGE_BOTH;
+            MultiTimes tm;
+            tm.capture = &cap[batch][0];
+            tm.capture_rccl = &cap[batch][1];
+            HIPCHK(hipSetDevice(s->device));
+            rc = multi_batch_resident(&verdicts[batch][0], in, s, 0, tm);
+            verdicts[batch][1] = tm.ok_rccl;
+        }
+    }
+    m->exchange = saved_exchange;
+    (void)hipSetDevice(s->device);
+    if (rc != KZG_OK) return rc;
+    const bool same0 = cap[0][0] == cap[0][1] && !cap[0][0].empty(), same1 = cap[1][0] == cap[1][1] && !cap[1][0].empty();
+    bool nontrivial = false;
+    for (uint8_t b : cap[0][0]) nontrivial |= b != 0;
+    const bool v_ok = !verdicts[0][0] && !verdicts[0][1] && verdicts[1][0] && verdicts[1][1];
+    equal = same0 && same1 && nontrivial && v_ok;
+    char buf[320];
+    snprintf(buf, sizeof buf, "exchange self-test on %zu device(s), 2 synthetic batches of %zu x %zu blobs, host vs ncclAllGather: gathered %zu-byte buffers %s, "
+                              "verdicts host %d/%d rccl %d/%d (want 0/1) - %s (%.0f ms)",
+             D, D, nb, cap[0][0].size(), same0 && same1 ? (nontrivial ? "bit-identical" : "identical but all-zero") : "DIFFER", (int)verdicts[0][0],
+             (int)verdicts[1][0], (int)verdicts[0][1], (int)verdicts[1][1], equal ? "RCCL all-gather selected" : "RCCL REJECTED", ms_since(t_start));
+    verdict = buf;
+    return KZG_OK;
 }
 
 // does this call of n blobs (one array, host or single-device resident) go through the shards?
@@ -816,7 +974,6 @@ extern "C" KzgRet kzg_settings_devices(const KzgSettings* s, size_t* n_devices, 
     if (devices_out)
         for (size_t k = 0; k < D && k < cap; k++) devices_out[k] = s->multi ? s->multi->devices[k] : s->device;
     if (exchange) *exchange = s->multi ? s->multi->exchange : MULTI_EXCHANGE_NONE;
-    if (s->multi && s->multi->exchange == MULTI_EXCHANGE_HOST) g_err = s->multi->exchange_note;  // readable through kzg_last_error()
     return KZG_OK;
 }
 
@@ -833,6 +990,9 @@ extern "C" KzgRet kzg_multi_last_timings(const KzgSettings* s, float out_ms[8]) 
 extern "C" KzgRet kzg_debug_multi_last_r(uint8_t out[32], const KzgSettings* s) {
     if (!s || !out) return fail(KZG_BADARGS, "null argument");
     std::lock_guard<std::mutex> lk(s->mu);
-    reverse32(out, s->multi_last_r);
+    if (s->multi) {
+        std::lock_guard<std::mutex> lk_r(s->multi->last_r_mu);
+        reverse32(out, s->multi_last_r);
+    } else reverse32(out, s->multi_last_r);
     return KZG_OK;
 }

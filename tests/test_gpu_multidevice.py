@@ -425,10 +425,10 @@ def test_stream_of_sharded_batches_in_flight(env):
     st3.close()
 
 
-def test_rccl_exchange_is_opt_in_and_never_a_silent_fallback(env):
-    """The partial sums travel through pinned host memory unless KZG_OPTIONS multi_exchange=rccl asks for the in-process
-    RCCL all-gather; with it, a handle on which RCCL cannot run (here: a list naming device 0 twice - ncclCommInitAll
-    refuses duplicates) fails to construct instead of quietly using the host path."""
+def test_rccl_exchange_is_never_a_silent_fallback(env):
+    """KZG_OPTIONS multi_exchange=rccl on a handle on which RCCL cannot run (here: a list naming device 0 twice -
+    ncclCommInitAll refuses duplicates) fails to construct instead of quietly using the host path; without the option the
+    same list gives a host-exchange handle whose note says why; multi_exchange=host never touches RCCL."""
     api = env["api"]
     from kzg_rs_amd import synth
     with api.options(multi_exchange="rccl"):
@@ -436,8 +436,47 @@ def test_rccl_exchange_is_opt_in_and_never_a_silent_fallback(env):
             api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1], devices=[0, 0])
     assert e.value.kind == "InternalError" and "RCCL is unusable" in e.value.msg
     st = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1], devices=[0, 0])
-    assert st.devices() == ([0, 0], "host")
+    assert st.devices() == ([0, 0], "host") and "names a device twice" in st.note(), st.note()
     st.close()
+    with api.options(multi_exchange="host", multi_force=1):
+        st = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1], devices=[0])
+    assert st.devices() == ([0], "host") and "forced" in st.note(), st.note()
+    st.close()
+
+
+_SELFTEST_CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+import torch
+import golden_data as G, oracle_lib as O
+from kzg_rs_amd import api
+st = api.KzgSettings.load_trusted_setup_file(devices=[0])
+devs, ex = st.devices()
+note = st.note()
+print("NOTE", note)
+assert devs == [0] and ex == "rccl", (devs, ex, note)
+assert "bit-identical" in note and "RCCL all-gather selected" in note and "verdicts host 0/1 rccl 0/1" in note, note
+assert api.lib().kzg_last_error() == b""
+blobs, cs, ps = [list(x) for x in zip(*G.valid_blob_tuples())]
+call = lambda p: api.KzgProof.verify_blob_kzg_proof_batch([api.Blob(b) for b in blobs], [api.Bytes48(c) for c in cs], [api.Bytes48(x) for x in p], st)
+assert call(ps) is True
+g = bytes.fromhex("97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb")
+p2 = list(ps); p2[5] = O.g1_add(ps[5], g)
+assert call(p2) is False
+st.close()
+print("selftest-ok")
+"""
+
+
+def test_exchange_self_test_selects_rccl_in_the_world_of_one():
+    """First contact with a set of devices is self-validating (csrc/capi_multi.hpp multi_exchange_selftest): with NO
+    multi_exchange option the constructor runs two synthetic sharded batches through the host exchange and through
+    ncclAllGather, compares the gathered 288-byte slots bit for bit and the verdicts (false for the random batch, true for the
+    all-zero one), and only then makes RCCL the exchange - here on the one-GPU rig (a device list of one entry forced through
+    the sharded path, KZG_OPTIONS multi_force=1); the handle's note carries the outcome and the mainnet vectors verify."""
+    e = dict(os.environ, KZG_OPTIONS="multi_force=1;multi_min_blobs=2;multi_min_chunk=2;multi_selftest_blobs=32")
+    r = subprocess.run([sys.executable, "-c", _SELFTEST_CHILD % {"root": ROOT, "here": HERE}], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "selftest-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 _RCCL_TWO = r"""
@@ -449,7 +488,9 @@ from kzg_rs_amd import api, synth
 nd = torch.cuda.device_count()
 devs = list(range(nd))
 st = api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1], devices=devs)
-assert st.devices() == (devs, "rccl"), st.devices()
+assert st.devices() == (devs, "rccl"), (st.devices(), st.note())
+assert "bit-identical" in st.note() and "RCCL all-gather selected" in st.note(), st.note()
+print("NOTE", st.note())
 n = 64 * nd + 5
 blobs, cs, ps, sst = synth.make_valid_batch(n, seed=31337)
 ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])
@@ -485,9 +526,10 @@ def test_in_process_rccl_exchange_between_distinct_devices(env):
     """The RCCL all-gather of the partial sums between at least TWO GPUs (ncclCommInitAll over distinct devices, grouped
     ncclAllGather on per-shard streams, the [world][slots] layout fed to the fold, identity slots of shards with fewer
     pieces) against the oracle: host array, per-device resident shards, a stream of sharded batches.  Skipped on a box with
-    one GPU - which is every box this project has run on so far, and why the RCCL exchange is an opt-in."""
+    one GPU - which is every box this project has run on so far.  No multi_exchange option: the constructor's self-test
+    (host exchange vs ncclAllGather, bit for bit) is what selects RCCL, and the test asserts that it did."""
     if env["torch"].cuda.device_count() < 2:
         pytest.skip("needs at least two GPUs")
-    e = dict(os.environ, KZG_OPTIONS="multi_exchange=rccl;multi_min_blobs=2;multi_min_chunk=16")
+    e = dict(os.environ, KZG_OPTIONS="multi_min_blobs=2;multi_min_chunk=16")
     r = subprocess.run([sys.executable, "-c", _RCCL_TWO % {"root": ROOT, "here": HERE}], env=e, capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0 and "rccl-two-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

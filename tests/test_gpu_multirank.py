@@ -184,6 +184,8 @@ def test_bench_script_bare_command_starts_its_own_ranks():
     assert sp["sharded_stream"]["results_as_expected"] is True and sp["sharded_stream"]["in_flight"] == 4, sp
     assert sp["host_vec_blob"]["ok"] is True
     assert "skipped" in d["multi_gpu"]["single_process"]["rccl_exchange"]  # (the shared-GPU rig names device 0 twice)
+    sel = d["multi_gpu"]["single_process"]["selected_exchange"]  # what the handle's own self-test picked, and why
+    assert sel["exchange"] == "host" and "names a device twice" in sel["exchange_note"] and sel["sharded_batch"]["ok"] is True, sel
 
 
 def _nccl_worker(port, q):
