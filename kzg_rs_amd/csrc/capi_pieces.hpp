@@ -117,15 +117,26 @@ extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const 
     return fail(KZG_MALLOC, "host buffers of the call");  // (nothing is thrown across the C ABI)
 }
 
+// G1Projective::msm_variable_base for n (point, scalar) pairs in host memory, on the SAME kernels as the verification path's
+// MSM (rounds 1-4 built this entry's tables with the round-1 kernels - k_g1_decode, k_g1_multiples, a format conversion - and
+// accumulated full Jacobian additions from a global sorted list: 20 ns per term at n = 2^20 against the hot path's 7):
+//   decode + subgroup test + table rows in one pass (k_g1_decode_multiples29 -> affine rows through k_mult_to_affine29),
+//   GLV split, then the window kernel in the hot path's SHAPE: the terms are cut into slices of at most 2 048 - what a
+//   1 024-blob batch's output B holds - so that every (window, slice) workgroup sorts its 4 x 2 048 list entries in LDS and
+//   adds mixed (affine) entries, 8 windows x 2 S workgroups (the terms are dealt to the kernel's two outputs, halves of one
+//   sum); the S window sums per window are folded by trees of 64 and the 8 windows combined as usual.
+// timings: [2] the MSM (split, windows, reduce, folds, combine), [6] decode + tables.
+constexpr size_t G1_MSM_SLICE_TERMS = 2048;
 extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uint8_t* scalars, size_t n, const KzgSettings* s) try {
     if (!s || !out || (n && (!points48 || !scalars))) return fail(KZG_BADARGS, "null argument");
+    if (n > ((size_t)1 << 26)) return fail(KZG_BADARGS, "kzg_g1_msm: more than 2^26 terms");  // (a list entry holds a 27-bit point index)
     std::lock_guard<std::mutex> lk(s->mu);
     HIPCHK(hipSetDevice(s->device));
     select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
     KzgRet rc = ws_reserve(s, (n + 1) / 2 + 1, 1, STAGE_NONE);
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
-    int mt = (int)(n ? n : 1);
+    const int np = (int)(n ? n : 1);  // table stride
     // scalars: big-endian, reduced mod r on the host (at most two subtractions), little-endian limbs on the device
     std::vector<uint8_t> le(32 * (n ? n : 1));
     for (size_t i = 0; i < n; i++) {
@@ -134,62 +145,91 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
         while (be_geq_r(t)) be_sub_r(t);
         reverse32(le.data() + 32 * i, t);
     }
+    const bool aff = msm_affine_enabled();
+    std::vector<uint32_t> st(n);
+    HIPCHK(hipEventRecord(s->ev[5], s->s1));
     if (n) {
         HIPCHK(hipMemcpyAsync(w.d_bytes, points48, 48 * n, hipMemcpyHostToDevice, s->s1));
         HIPCHK(hipMemcpyAsync(w.d_scalars, le.data(), 32 * n, hipMemcpyHostToDevice, s->s1));
-        hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_bytes, w.d_bytes, (int)n, w.d_points, w.d_pflag, (int)n, 1);
-        hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, (int)n);
-        hipLaunchKernelGGL(k_plain_terms, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar, (int)n);
+        HIPCHK(hipEventRecord(s->ev[5], s->s1));
+        const unsigned blocks256 = (unsigned)((n + 255) / 256);
+        if (aff) {
+            hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, true>), dim3(blocks256), dim3(256), 256 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s1, w.d_bytes,
+                               w.d_bytes, (int)n, w.d_points, w.d_pflag, w.d_mult, w.d_jtmp, (int)n, np);
+            const unsigned conv_blocks = (unsigned)((n + 64 * AFFINE_BATCH - 1) / (64 * AFFINE_BATCH));
+            hipLaunchKernelGGL(k_mult_to_affine29, dim3(conv_blocks), dim3(64), 0, s->s1, w.d_jtmp, w.d_pflag, (G1Aff29Mem*)w.d_mult, (int)n, np);
+        } else if (fp29_enabled()) {
+            hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s1,
+                               w.d_bytes, w.d_bytes, (int)n, w.d_points, w.d_pflag, w.d_mult, (G1Jac29Mem*)nullptr, (int)n, np);
+        }
+#if KZG_AB_VARIANTS
+        else
+            hipLaunchKernelGGL(k_g1_decode_multiples<MSM_CHUNKS>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_bytes, w.d_bytes, (int)n, w.d_points,
+                               w.d_pflag, (G1Jac*)w.d_mult, (int)n, np);
+#endif
         HIPCHK(hipGetLastError());
-        std::vector<uint32_t> st(n);
+        // (a point outside G1 has the digit 0 in every window - the kernel reads its flag - so the verdict on the inputs is
+        // looked at after the sum: one wait at the end)
         HIPCHK(hipMemcpyAsync(st.data(), w.d_pflag, 4 * n, hipMemcpyDeviceToHost, s->s1));
-        HIPCHK(hipStreamSynchronize(s->s1));
-        for (size_t i = 0; i < n; i++)
-            if (st[i] == G1_INVALID) return fail(KZG_BADARGS, "invalid G1 point");
     }
-    // the tables are made in the 12x32 form (the points are already decoded), then converted to the window kernel's format
-    DevTmp std_tab;
+    HIPCHK(hipEventRecord(s->ev[6], s->s1));
+    // the terms dealt to the kernel's two outputs: [0, h) and [h, n); slices of at most G1_MSM_SLICE_TERMS, a power of two of them
+    const size_t h = (n + 1) / 2;
+    unsigned S = 1;
+    while ((h + S - 1) / S > G1_MSM_SLICE_TERMS) S *= 2;
+    const unsigned W = MSM_WINDOWS / MSM_CHUNKS, gz = 2 * S;
+    DevTmp t_ws, t_f0, t_f1;
+    HIPCHK(hipMalloc(&t_ws.p, sizeof(G1Jac) * (size_t)gz * W));
+    HIPCHK(hipMalloc(&t_f0.p, sizeof(G1Jac) * (size_t)std::max(1u, gz / 2) * W));
+    HIPCHK(hipMalloc(&t_f1.p, sizeof(G1Jac) * (size_t)std::max(1u, gz / 4) * W));
+    HIPCHK(hipEventRecord(s->ev[2], s->s1));
     if (n) {
-        if (fp29_enabled()) HIPCHK(hipMalloc(&std_tab.p, sizeof(G1Jac) * MSM_CHUNKS * (size_t)mt));
-        G1Jac* d_std = std_tab.as<G1Jac>();
-        G1Jac* tab = fp29_enabled() ? d_std : (G1Jac*)w.d_mult;
-        hipLaunchKernelGGL(k_g1_multiples, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s->s1, w.d_points, w.d_pflag, tab, (int)n, mt, MSM_CHUNKS);
-        if (fp29_enabled())
-            hipLaunchKernelGGL(k_jac_to_jac29, dim3((unsigned)((MSM_CHUNKS * (size_t)mt + 255) / 256)), dim3(256), 0, s->s1, d_std, (G1Jac29Mem*)w.d_mult, (int)(MSM_CHUNKS * mt));
+        hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, (int)n);
+        hipLaunchKernelGGL(k_plain_terms, dim3((unsigned)((2 * h + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar, (int)(2 * h));
     }
     MsmDesc d{};
     d.mult = w.d_mult;
     d.pflag = w.d_pflag;
     d.scalars = w.d_scalars;
-    d.term_point = w.d_term_point;
+    d.term_point = w.d_term_point;  // output 1's list starts at entry max_terms = h: term_point[i] = i serves both
     d.term_scalar = w.d_term_scalar;
     d.sorted = w.d_sorted;
-    d.window_sums = w.d_window;
-    d.nterms[0] = (int)n;
-    d.nterms[1] = 0;
-    d.max_terms = mt;
-    d.stride = mt;
-    unsigned S = 1;  // slice a large MSM over more workgroups (msm.hpp MsmDesc::slices)
-    while (S < MSM_MAX_SLICES && 8 * MSM_CHUNKS * S < 768 && n / (2 * S) >= 1024) S *= 2;
+    d.window_sums = t_ws.as<G1Jac>();
+    d.nterms[0] = (int)h;
+    d.nterms[1] = (int)(n - h);
+    d.max_terms = (int)(h ? h : 1);
+    d.stride = np;
     d.slices = (int)S;
-    d.window_sums = S > 1 ? w.d_window_sl : w.d_window;
     d.chunks = MSM_CHUNKS;
-    d.chunks_per_block = 1;
-    HIPCHK(hipEventRecord(s->ev[2], s->s1));
-    if ((rc = msm_save_reserve(s, 8, MSM_CHUNKS, S)) != KZG_OK) return rc;
+    d.chunks_per_block = MSM_CHUNKS;  // one workgroup per (window, slice): the four chunks' entries in one sorted list
+    d.flags = (gz & 7) == 0 ? MSM_FLAG_XCD : 0;
+    if ((rc = msm_save_reserve(s, W, 1, gz)) != KZG_OK) return rc;
+    if (aff) msm_window_launch<Curve29Aff, true>(d, W, 1, gz, w.d_msm_save, w.cap_msm_save, s->s1);
+    else if (fp29_enabled()) msm_window_launch<Curve29, true>(d, W, 1, gz, w.d_msm_save, w.cap_msm_save, s->s1);
 #if KZG_AB_VARIANTS
-    if (!fp29_enabled()) msm_window_launch<Curve32, false>(d, 8, MSM_CHUNKS, S, w.d_msm_save, w.cap_msm_save, s->s1);
-    else
+    else msm_window_launch<Curve32, true>(d, W, 1, gz, w.d_msm_save, w.cap_msm_save, s->s1);
 #endif
-        msm_window_launch<Curve29, false>(d, 8, MSM_CHUNKS, S, w.d_msm_save, w.cap_msm_save, s->s1);
-    if (S > 1) hipLaunchKernelGGL(k_msm_fold_slices, dim3(MSM_CHUNKS * 8), dim3(64), 0, s->s1, w.d_window_sl, w.d_window, (int)S, 8);
-    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, w.d_window, w.d_ab, MSM_CHUNKS, 8);
+    // window sums [2 S][W] -> [1][W]: trees over up to 64 slices at a time
+    const G1Jac* cur = t_ws.as<G1Jac>();
+    G1Jac* bufs[2] = {t_f0.as<G1Jac>(), t_f1.as<G1Jac>()};
+    int which = 0;
+    for (unsigned left = gz; left > 1;) {
+        const unsigned f = std::min(left, 64u);
+        hipLaunchKernelGGL(k_msm_fold_slices, dim3(left / f * W), dim3(64), 0, s->s1, cur, bufs[which], (int)f, (int)W);
+        cur = bufs[which];
+        which ^= 1;
+        left /= f;
+    }
+    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, cur, w.d_ab, 1, (int)W);
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
     hipLaunchKernelGGL(k_jac_compress, dim3(1), dim3(64), 0, s->s1, w.d_ab, w.d_bytes, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, w.d_bytes, 48, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipStreamSynchronize(s->s1));
     elapsed(&s->timings[2], s->ev[2], s->ev[3]);
+    elapsed(&s->timings[6], s->ev[5], s->ev[6]);
+    for (size_t i = 0; i < n; i++)
+        if (st[i] == G1_INVALID) return fail(KZG_BADARGS, "invalid G1 point");
     return KZG_OK;
 } catch (const std::bad_alloc&) {
     return fail(KZG_MALLOC, "host buffers of the call");  // (nothing is thrown across the C ABI)

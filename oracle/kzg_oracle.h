@@ -89,6 +89,14 @@ void oracle_fr_inv(uint8_t out_be[32], const uint8_t a_be[32]);
 void oracle_constants(uint8_t fr_R[32], uint8_t fr_R2[32], uint64_t *fr_inv, uint8_t fp_R[48], uint8_t fp_R2[48],
                       uint64_t *fp_inv);
 
+/* bench_threads.c: the CPU baseline under T pthreads, each making independent single-threaded calls for `seconds` -
+ * kind 0: oracle_verify_kzg_proof per tuple, kind 1: oracle_verify_blob_kzg_proof_batch of per_call blobs.  out: [0] calls,
+ * [1] wall seconds, [2] calls that did not return Ok(true), [3] aggregate calls/s (sum of the threads' own rates), [4] / [5] the
+ * slowest / fastest thread's calls/s. */
+int oracle_bench_threads(double out[6], int kind, size_t threads, double seconds, const uint8_t *blobs, const uint8_t *c,
+                         const uint8_t *z, const uint8_t *y, const uint8_t *p, size_t n_items, size_t per_call,
+                         const oracle_settings *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -52,6 +52,7 @@ def lib():
         L.oracle_fr_mul.argtypes = [u8p, u8p, u8p]
         L.oracle_fr_inv.argtypes = [u8p, u8p]
         L.oracle_constants.argtypes = [u8p, u8p, C.POINTER(C.c_uint64), u8p, u8p, C.POINTER(C.c_uint64)]
+        L.oracle_bench_threads.argtypes = [C.POINTER(C.c_double), C.c_int, sz, C.c_double, u8p, u8p, u8p, u8p, u8p, sz, sz, vp]
         _lib = L
     return _lib
 
@@ -222,3 +223,13 @@ def constants():
     i1, i2 = C.c_uint64(0), C.c_uint64(0)
     lib().oracle_constants(a, b, C.byref(i1), c, d, C.byref(i2))
     return a.raw, b.raw, i1.value, c.raw, d.raw, i2.value
+
+
+def bench_threads(kind, threads, seconds, s, cs, ps, zs=None, ys=None, blobs=None, per_call=1):
+    """oracle/bench_threads.c: T pthreads of independent single-threaded calls for `seconds` - kind "proof": verify_kzg_proof per
+    tuple, "blobs": verify_blob_kzg_proof_batch of per_call blobs.  cs / ps / zs / ys / blobs: bytes, back to back (all valid).
+    Returns {calls, seconds, bad, calls_per_s, per_thread_min, per_thread_max}."""
+    o = (C.c_double * 6)()
+    n_items = len(cs) // 48
+    _chk(lib().oracle_bench_threads(o, 0 if kind == "proof" else 1, threads, float(seconds), blobs, cs, zs, ys, ps, n_items, per_call, s.h))
+    return {"calls": int(o[0]), "seconds": o[1], "bad": int(o[2]), "calls_per_s": o[3], "per_thread_min": o[4], "per_thread_max": o[5]}
