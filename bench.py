@@ -55,7 +55,7 @@ ALG_BYTES = {
 PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge_t<4>", "k_blob_evaluate": "kzg::k_blob_evaluate_t<true>",
             "k_g1_decode_multiples": "kzg::k_g1_decode_multiples29<4, true>", "k_msm": "kzg::k_msm_window<kzg::Curve29Aff, true>",
             "k_slp_run(pairing)": "kzg::k_slp_run<false>"}
-PMC_FILES = ("r4_pmc.json", "r3_pmc.json")  # newest first; the first that exists is used (kernel names must match PMC_NAME)
+PMC_FILES = ("r5_pmc.json", "r4_pmc.json", "r3_pmc.json")  # newest first; the first that exists is used (kernel names must match PMC_NAME)
 PATH_ALG_BYTES = BYTES_PER_BLOB + 48 + 48 + 64   # full verify, per blob: blob + commitment + proof read, z and y written
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
 
@@ -592,6 +592,7 @@ def main():
         warm_sum5 += t[5]
         warm_cnt += c
         h.shader_clock(reset=True)
+        h.kernel_stamp_totals(reset=True)
     elapsed, _ = timed(lambda: run_groups(K))
     clk_cycles = clk_ticks = 0.0
     for h in handles:  # the clock the SIMDs ran at during the timed region (every wave of the challenge kernel stamps it)
@@ -607,6 +608,14 @@ def main():
         sums = [a + b for a, b in zip(sums, t)]
         cnt += c
     tm = [x / max(cnt, 1) for x in sums]
+    # the kernels' OWN intervals in the timed region (in-kernel stamps: first wavefront in, last out - residency beside the other
+    # groups in flight, without the queueing a HIP-event pair would add)
+    stamp_sum, stamp_cnt = {}, 0
+    for h in handles:
+        ssum, c, _ = h.kernel_stamp_totals(reset=True)
+        stamp_sum = {k: stamp_sum.get(k, 0.0) + v for k, v in ssum.items()}
+        stamp_cnt += c
+    in_flight = {k: v / max(stamp_cnt, 1) for k, v in stamp_sum.items()}
     kernels = {"k_blob_challenge": tm[5], "k_blob_evaluate": tm[4], "k_g1_decode_multiples": tm[6], "k_msm": tm[2],
                "k_slp_run(pairing)": tm[3]}
 
@@ -675,6 +684,7 @@ def main():
     # ---- the kernels ALONE on the chip: one launch group on a single-stream handle, nothing else in flight.  With several
     # groups in flight a kernel's interval is its residency (how long it shared the chip), not its cost.
     standalone = None
+    solo_stamps = None
     self_check = None
     proof_ms = None
     blob_ms = None
@@ -693,6 +703,7 @@ def main():
             torch.cuda.synchronize()
             solo_res = api.verify_blob_kzg_proof_batches_device(v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), n, G, solo)
         st_tm = solo.last_timings()
+        solo_stamps = solo.kernel_stamp_totals()[2]   # the same group's in-kernel stamps (ms)
         standalone = {"k_blob_challenge": st_tm[5], "k_blob_evaluate": st_tm[4], "k_g1_decode_multiples": st_tm[6], "k_msm": st_tm[2],
                       "k_slp_run(pairing)": st_tm[3], "whole_group": st_tm[0]}
         if not all(r is True for r in solo_res):
@@ -863,6 +874,36 @@ def main():
         path_ratio = round(path_bytes / (PATH_ALG_BYTES * pmc["blobs_per_launch"]), 3)
     except Exception:
         pass
+    # ---- every big kernel of the path: its cost alone on the chip, its residency in the timed region, its algorithmic bytes and
+    # how close its instruction stream runs to the issue ceiling of its instruction mix
+    CEIL = {"k_blob_challenge": 3.9, "k_blob_evaluate": 4.2, "k_g1_decode_multiples": 4.2, "k_msm_window": 4.2}   # cycles per wave-instruction, builder's microbenchmarks
+    ALG = {"k_blob_challenge": ALG_BYTES["k_blob_challenge"], "k_blob_evaluate": ALG_BYTES["k_blob_evaluate"],
+           "k_g1_decode_multiples": ALG_BYTES["k_g1_decode_multiples"], "k_msm_window": ALG_BYTES["k_msm"]}
+    PMCN = dict(PMC_NAME, k_msm_window=PMC_NAME["k_msm"])
+    kernel_rows, mix_num, mix_den = [], 0.0, 0.0
+    clock_hz = (shader_mhz or 2400.0) * 1e6
+    for kname in ("k_blob_challenge", "k_blob_evaluate", "k_g1_decode_multiples", "k_msm_window"):
+        sa = (solo_stamps or {}).get(kname) or None
+        fl = in_flight.get(kname) or None
+        pk = prof.get(PMCN[kname], {})
+        insts = pk.get("SQ_INSTS_VALU")
+        scale = units / pmc["blobs_per_launch"] if pmc else 1.0
+        row = {"kernel": kname, "units_per_launch": units, "algorithmic_bytes_per_launch": ALG[kname] * units,
+               "standalone_ms": round(sa, 4) if sa else None, "in_flight_ms": round(fl, 4) if fl else None,
+               "achieved_standalone_GBps": round(ALG[kname] * units / sa / 1e6, 2) if sa else None,
+               "frac_standalone": round(ALG[kname] * units / sa / 1e6 / HBM_PEAK_GBS, 6) if sa else None,
+               "achieved_in_flight_GBps": round(ALG[kname] * units / fl / 1e6, 2) if fl else None,
+               "frac_in_flight": round(ALG[kname] * units / fl / 1e6 / HBM_PEAK_GBS, 6) if fl else None,
+               "hbm_traffic_bytes": round(pk["hbm_bytes_corrected"] * scale) if "hbm_bytes_corrected" in pk else None,
+               "hbm_traffic_ratio": round(pk["hbm_bytes_corrected"] * scale / (ALG[kname] * units), 3) if "hbm_bytes_corrected" in pk else None,
+               "valu_wave_insts_per_launch": round(insts * scale) if insts else None,
+               "cycles_per_inst_standalone": round(sa * 1e-3 * clock_hz * 1024 / (insts * scale), 3) if sa and insts else None,
+               "issue_ceiling_cycles_per_inst": CEIL[kname]}
+        if insts:
+            mix_num += insts * CEIL[kname]
+            mix_den += insts
+        kernel_rows.append(row)
+    mix_ceiling = mix_num / mix_den if mix_den else None
     path_gbps = PATH_ALG_BYTES * n * G * K / elapsed / 1e9   # per GPU
     out = {
         "metric": "blobs/sec verify_blob_kzg_proof_batch",
@@ -890,7 +931,10 @@ def main():
         # launch_ms / achieved / frac: the kernel's average duration over the launches of the timed region - what rocprofv3
         # --kernel-trace --stats reports for this command (with %d groups in flight that is its RESIDENCY: it shares the chip);
         # standalone_ms / frac_standalone: the same kernel with the chip to itself - its cost.
-        "roofline": {"bound": "hbm", "kernel": dom, "kernel_chosen_by": dom_source, "units_per_launch": units, "launch_ms": round(launch_ms, 4),
+        "roofline": {"bound": "valu-issue", "bound_note": "the bound that binds is VALU issue (wide-integer modular arithmetic and SHA-256: ~106 k wave-instructions per "
+                     "blob against 131 KB of input); achieved / peak / frac below are the HBM figures BASELINE.json's metric asks for, for the dominant kernel; "
+                     "kernels[] carries every big kernel with its cycles per instruction against the issue ceiling of its instruction mix",
+                     "kernel": dom, "kernel_chosen_by": dom_source, "units_per_launch": units, "launch_ms": round(launch_ms, 4),
                      "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                      "standalone_ms": round(sa_ms, 4) if sa_ms else None,
                      "achieved_standalone": round(sa_achieved, 3) if sa_achieved else None,
@@ -908,16 +952,25 @@ def main():
                                           "this same command averages into the kernel's AverageNs; standalone_ms: the same stamp from one launch group alone on "
                                           "the chip" % (cnt, F, warm_cnt)) if stamped else
                                          "live: HIP events around the kernel on a single-stream handle, one launch group alone on the chip",
+                     "kernels": kernel_rows,
+                     "kernels_note": "standalone_ms / in_flight_ms: the kernel's own interval, stamped inside the kernel with s_memrealtime (first wavefront in, last "
+                                     "out): one launch group alone on a single-stream handle | averaged over the %d launch groups of the timed region with %d in flight "
+                                     "(residency: the kernel shares the chip).  cycles_per_inst_standalone = standalone_ms x the measured shader clock x 1 024 SIMDs / "
+                                     "SQ_INSTS_VALU (profiles/%s), to hold against issue_ceiling_cycles_per_inst (microbenchmarks: 4.2 for v_mad_u64_u32 / carry-chain "
+                                     "code, 3.9 for SHA-256)" % (stamp_cnt, F, pmc_file),
                      "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 5)"},
         "path": {"algorithmic_bytes_per_blob": PATH_ALG_BYTES, "algorithmic_GBps": round(path_gbps, 2), "frac": round(path_gbps / HBM_PEAK_GBS, 6),
                  "hbm_traffic_ratio": path_ratio,
+                 "valu_mix_ceiling_cycles_per_inst": round(mix_ceiling, 3) if mix_ceiling else None,
+                 "valu_frac_of_mix_ceiling": round(mix_ceiling / valu["cycles_per_inst_at_measured_clock"], 4)
+                 if mix_ceiling and valu and valu.get("cycles_per_inst_at_measured_clock") else None,
                  "note": "whole path per GPU: 131 232 algorithmic bytes per blob x blobs/s; hbm_traffic_ratio = PMC HBM bytes of every kernel of the path / "
                          "algorithmic bytes (profiles/%s; the blob is streamed twice: hash, then evaluate)" % pmc_file},
         "valu": valu,
         "kernel_ms_standalone": {k: round(v, 4) for k, v in standalone.items()} if standalone else None,
-        "kernel_ms_in_flight": {"k_blob_challenge": round(kernels["k_blob_challenge"], 4),
-                                "note": "in-kernel stamp, %d groups in flight; the other kernels are not stamped and HIP-event intervals around them would "
-                                        "include queueing behind other groups - see kernel_ms_standalone" % F} if world == 1 or stamped else None,
+        "kernel_ms_in_flight": dict({k: round(v, 4) for k, v in in_flight.items()},
+                                    note="in-kernel stamps (first wavefront in, last wavefront out), averaged over the timed region's launch groups, %d in "
+                                         "flight: residency beside the other groups, not cost - see kernel_ms_standalone / roofline.kernels" % F),
         "self_check": self_check,
         "single_batch": single,
         "end_to_end": end2end,

@@ -139,6 +139,7 @@ def lib():
         L.kzg_last_timings.argtypes = [vp, C.POINTER(C.c_float)]
         L.kzg_timing_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.kzg_debug_shader_clock.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
+        L.kzg_kernel_stamp_totals.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_float), C.c_int]
         L.kzg_last_error.restype = C.c_char_p
         L.kzg_settings_note.argtypes = [vp]
         L.kzg_settings_note.restype = C.c_char_p
@@ -330,6 +331,15 @@ class KzgSettings:
         t, c = (C.c_double * 8)(), C.c_uint64(0)
         _chk(lib().kzg_timing_totals(self._h, t, C.byref(c), int(reset)))
         return list(t), int(c.value)
+
+    def kernel_stamp_totals(self, reset=False):
+        """The kernels' OWN execution intervals (in-kernel stamps, no queueing in them), ms: ({challenge, evaluate, decode, msm_window}
+        summed over the launch groups finished on this handle and its lanes since the last reset, groups, the same four of the
+        handle's last group)."""
+        t, c, last = (C.c_double * 4)(), C.c_uint64(0), (C.c_float * 4)()
+        _chk(lib().kzg_kernel_stamp_totals(self._h, t, C.byref(c), last, int(reset)))
+        names = ("k_blob_challenge", "k_blob_evaluate", "k_g1_decode_multiples", "k_msm_window")
+        return dict(zip(names, t)), int(c.value), dict(zip(names, last))
 
     def shader_clock(self, reset=False):
         """(shader cycles, 100 MHz reference ticks) summed over the waves of the throughput-form challenge kernel since the last

@@ -51,6 +51,12 @@ static KzgRet small_run_proofs(SmallLane& L, std::vector<SmallReq*>& batch, size
     if (m == 1) {  // nobody else was waiting: the one-proof path as it was (z, y through the pinned mirror, no gather)
         SmallReq& r = *batch[0];
         bool general = false, ok = false;
+        if (be_geq_r(r.z) || be_geq_r(r.y)) {  // (:360-371; kzg_verify_kzg_proof has refused these before they are queued, kzg_verify_kzg_proofs has not)
+            r.err[0] = 1;
+            r.ok[0] = false;
+            r.general[0] = 0;
+            return KZG_OK;
+        }
         const KzgRet rc = proof_single_locked(&ok, &general, r.c, r.z, r.y, r.p, l);
         if (rc == KZG_BADARGS) {
             r.err[0] = 1;

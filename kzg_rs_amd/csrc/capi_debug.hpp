@@ -115,6 +115,31 @@ extern "C" KzgRet kzg_timing_totals(const KzgSettings* s, double out_sum_ms[8], 
     return KZG_OK;
 }
 
+// The kernels' OWN execution intervals (in-kernel s_memrealtime stamps: first wavefront in, last wavefront out - no queueing
+// behind other launch groups in them), summed over the launch groups finished on this handle and its pipeline lanes since the
+// last reset, milliseconds: [0] k_blob_challenge (throughput form) [1] k_blob_evaluate [2] k_g1_decode_multiples29 (affine
+// layout) [3] k_msm_window; *count = groups.  last_ms (optional): the same four of the handle's last group.
+extern "C" KzgRet kzg_kernel_stamp_totals(const KzgSettings* s, double out_sum_ms[4], uint64_t* count, float last_ms[4], int reset) {
+    if (!s || !out_sum_ms || !count) return fail(KZG_BADARGS, "null argument");
+    std::lock_guard<std::mutex> lk(s->mu);
+    memcpy(out_sum_ms, s->kstamp_sum, sizeof(double) * 4);
+    *count = s->kstamp_count;
+    if (last_ms) memcpy(last_ms, s->kstamp_ms, sizeof(float) * 4);
+    for (const KzgSettings* l : s->lanes) {
+        for (int i = 0; i < 4; i++) out_sum_ms[i] += l->kstamp_sum[i];
+        *count += l->kstamp_count;
+    }
+    if (reset) {
+        memset(s->kstamp_sum, 0, sizeof s->kstamp_sum);
+        s->kstamp_count = 0;
+        for (const KzgSettings* l : s->lanes) {
+            memset(l->kstamp_sum, 0, sizeof l->kstamp_sum);
+            l->kstamp_count = 0;
+        }
+    }
+    return KZG_OK;
+}
+
 // diagnostic (bench.py `valu`): the shader clock the throughput-form challenge kernel ran at since the last reset - every wave
 // of it reads s_memtime (shader cycles) and s_memrealtime (100 MHz) at its start and end; out = { sum of cycles, sum of ticks }
 // over this handle and its pipeline lanes: MHz = 100 * out[0] / out[1].  The chip's DVFS decides this figure, and every

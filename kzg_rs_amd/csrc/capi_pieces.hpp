@@ -121,12 +121,12 @@ extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const 
 // MSM (rounds 1-4 built this entry's tables with the round-1 kernels - k_g1_decode, k_g1_multiples, a format conversion - and
 // accumulated full Jacobian additions from a global sorted list: 20 ns per term at n = 2^20 against the hot path's 7):
 //   decode + subgroup test + table rows in one pass (k_g1_decode_multiples29 -> affine rows through k_mult_to_affine29),
-//   GLV split, then the window kernel in the hot path's SHAPE: the terms are cut into slices of at most 2 048 - what a
-//   1 024-blob batch's output B holds - so that every (window, slice) workgroup sorts its 4 x 2 048 list entries in LDS and
+//   GLV split, then the window kernel in the hot path's SHAPE: the terms are cut into slices of at most 3 072 (a 1 024-blob
+//   batch's output B holds 2 049) - so that every (window, slice) workgroup sorts its 4 x 3 072 list entries in LDS and
 //   adds mixed (affine) entries, 8 windows x 2 S workgroups (the terms are dealt to the kernel's two outputs, halves of one
 //   sum); the S window sums per window are folded by trees of 64 and the 8 windows combined as usual.
 // timings: [2] the MSM (split, windows, reduce, folds, combine), [6] decode + tables.
-constexpr size_t G1_MSM_SLICE_TERMS = 2048;
+constexpr size_t G1_MSM_SLICE_TERMS = 3072;
 extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uint8_t* scalars, size_t n, const KzgSettings* s) try {
     if (!s || !out || (n && (!points48 || !scalars))) return fail(KZG_BADARGS, "null argument");
     if (n > ((size_t)1 << 26)) return fail(KZG_BADARGS, "kzg_g1_msm: more than 2^26 terms");  // (a list entry holds a 27-bit point index)
@@ -173,24 +173,34 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
         HIPCHK(hipMemcpyAsync(st.data(), w.d_pflag, 4 * n, hipMemcpyDeviceToHost, s->s1));
     }
     HIPCHK(hipEventRecord(s->ev[6], s->s1));
-    // the terms dealt to the kernel's two outputs: [0, h) and [h, n); slices of at most G1_MSM_SLICE_TERMS, a power of two of them
+    // the terms dealt to the kernel's two outputs: [0, h) and [h, n); slices of at most slice_terms terms (option
+    // g1_msm_slice_terms, default 3 072: 4 x 3 072 list entries = 48 KB of LDS, three workgroups per CU - measured at 2^20 terms
+    // against 2 048: fewer (window, slice) workgroups to reduce and fold), their number a multiple of 4 (the XCD placement of
+    // msm.hpp wants 2 S workgroup layers in eights)
+    static const size_t slice_terms = (size_t)std::max(256L, std::min(3072L, opt_int("g1_msm_slice_terms", (long)G1_MSM_SLICE_TERMS)));
     const size_t h = (n + 1) / 2;
-    unsigned S = 1;
-    while ((h + S - 1) / S > G1_MSM_SLICE_TERMS) S *= 2;
-    const unsigned W = MSM_WINDOWS / MSM_CHUNKS, gz = 2 * S;
+    unsigned S = (unsigned)((h + slice_terms - 1) / slice_terms);
+    S = S <= 1 ? 1 : (S + 3) & ~3u;
+    const unsigned W = MSM_WINDOWS / MSM_CHUNKS, gz = 2 * S, gz_pad = gz <= 64 ? gz : (gz + 63) & ~63u;
     DevTmp t_ws, t_f0, t_f1;
-    HIPCHK(hipMalloc(&t_ws.p, sizeof(G1Jac) * (size_t)gz * W));
-    HIPCHK(hipMalloc(&t_f0.p, sizeof(G1Jac) * (size_t)std::max(1u, gz / 2) * W));
-    HIPCHK(hipMalloc(&t_f1.p, sizeof(G1Jac) * (size_t)std::max(1u, gz / 4) * W));
+    HIPCHK(hipMalloc(&t_ws.p, sizeof(G1Jac) * (size_t)gz_pad * W));
+    HIPCHK(hipMalloc(&t_f0.p, sizeof(G1Jac) * (size_t)std::max(1u, gz_pad / 2) * W));
+    HIPCHK(hipMalloc(&t_f1.p, sizeof(G1Jac) * (size_t)std::max(1u, gz_pad / 4) * W));
+    if (gz_pad != gz) {  // (Z = 0: the identity) the padding of the window sums, and of the first fold's output where a second full level reads it
+        HIPCHK(hipMemsetAsync(t_ws.as<G1Jac>() + (size_t)gz * W, 0, sizeof(G1Jac) * (size_t)(gz_pad - gz) * W, s->s1));
+        HIPCHK(hipMemsetAsync(t_f0.p, 0, sizeof(G1Jac) * (size_t)(gz_pad / 2) * W, s->s1));
+    }
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     if (n) {
-        hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, (int)n);
+        hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, (int)n, w.d_digits);
         hipLaunchKernelGGL(k_plain_terms, dim3((unsigned)((2 * h + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar, (int)(2 * h));
     }
     MsmDesc d{};
     d.mult = w.d_mult;
     d.pflag = w.d_pflag;
     d.scalars = w.d_scalars;
+    d.digits_t = n ? w.d_digits : nullptr;
+    d.nsc = (int)n;
     d.term_point = w.d_term_point;  // output 1's list starts at entry max_terms = h: term_point[i] = i serves both
     d.term_scalar = w.d_term_scalar;
     d.sorted = w.d_sorted;
@@ -209,18 +219,20 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
 #if KZG_AB_VARIANTS
     else msm_window_launch<Curve32, true>(d, W, 1, gz, w.d_msm_save, w.cap_msm_save, s->s1);
 #endif
-    // window sums [2 S][W] -> [1][W]: trees over up to 64 slices at a time
+    // window sums [2 S (padded to whole groups of 64 with identities)][W] -> [1][W]: trees over up to 64 slices at a time
     const G1Jac* cur = t_ws.as<G1Jac>();
     G1Jac* bufs[2] = {t_f0.as<G1Jac>(), t_f1.as<G1Jac>()};
     int which = 0;
-    for (unsigned left = gz; left > 1;) {
-        const unsigned f = std::min(left, 64u);
-        hipLaunchKernelGGL(k_msm_fold_slices, dim3(left / f * W), dim3(64), 0, s->s1, cur, bufs[which], (int)f, (int)W);
+    for (unsigned left = gz_pad; left > 1;) {
+        const unsigned f = std::min(left, 64u), groups = (left + f - 1) / f;  // (left > 64: a multiple of 64; the last level takes any count)
+        hipLaunchKernelGGL(k_msm_fold_slices, dim3(groups * W), dim3(64), 0, s->s1, cur, bufs[which], (int)f, (int)W);
         cur = bufs[which];
         which ^= 1;
-        left /= f;
+        left = groups;
     }
-    hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, cur, w.d_ab, 1, (int)W);
+    // 8 windows of one output: the Horner chain with four lanes per doubling / addition (0.8 -> ~0.2 ms of a 2^20-term call)
+    if (fp29_enabled()) hipLaunchKernelGGL(k_msm_combine_quad, dim3(1), dim3(64), 0, s->s1, cur, w.d_ab, (int)W);
+    else hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, cur, w.d_ab, 1, (int)W);
     HIPCHK(hipEventRecord(s->ev[3], s->s1));
     hipLaunchKernelGGL(k_jac_compress, dim3(1), dim3(64), 0, s->s1, w.d_ab, w.d_bytes, 1);
     HIPCHK(hipGetLastError());

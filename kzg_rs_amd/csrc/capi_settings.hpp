@@ -37,8 +37,13 @@ struct Workspace {
     uint32_t* d_msm_save = nullptr;  // the window kernel's bucket sums between its row and column trees (msm.hpp MsmDesc::save)
     size_t cap_msm_save = 0;         // bytes
     void* d_mult = nullptr;  // MSM tables: G1Jac29Mem / G1Aff29Mem / G1Jac entries (fp29_enabled(), msm_affine_enabled())
-    unsigned long long* d_ktime = nullptr;  // execution interval of the last throughput-form challenge kernel (fr_kernels.hpp)
-    bool ktime_valid = false;
+    // in-kernel stamps of the last launch group (field.hpp kstamp_in / kstamp_out): 16 words - [0, 4) the throughput-form
+    // challenge kernel (its interval and its clock, fr_kernels.hpp), [4, 6) k_blob_evaluate, [6, 8) the decode pass, [8, 10) the
+    // MSM window kernel
+    unsigned long long* d_ktime = nullptr;
+    bool ktime_valid = false;   // [0, 4) were written (the challenge took its throughput form)
+    bool kstamps_valid = false; // [4, 10) belong to the group in flight
+    uint8_t* d_digits = nullptr;  // the split scalars' digit bytes, digit-major [32][scalars of the launch] (msm.hpp k_glv_split)
     G1Jac29Mem* d_jtmp = nullptr;  // 2^64 P of every decoded point on its way to the affine table (k_mult_to_affine29)
     bool mult_affine = false;      // format of d_mult as the last decode left it
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
@@ -148,6 +153,11 @@ struct KzgSettings {
     mutable uint64_t tcount = 0;
     mutable struct ProverBufs* prover = nullptr;  // the prover-side entry points' buffers, made by the first of those calls (capi_prover.hpp)
     mutable double clk_sum[2] = {};  // shader cycles | 100 MHz reference ticks of the throughput-form challenge kernel's waves
+    // the kernels' own execution intervals (in-kernel stamps), ms: challenge | evaluate | decode + multiples | MSM window - of the
+    // last launch group, and summed over the groups finished since the last reset (kzg_kernel_stamp_totals)
+    mutable float kstamp_ms[4] = {};
+    mutable double kstamp_sum[4] = {};
+    mutable uint64_t kstamp_count = 0;
     // A multi-device handle (capi_multi.hpp): this handle is shard 0 on the first device of the list and a complete
     // single-device handle in its own right; `peers` are the (private) single-device handles of the other entries, `multi`
     // the device list and the exchange (in-process RCCL communicators, or host staging).
@@ -588,7 +598,7 @@ extern "C" KzgRet kzg_settings_from_tau_g2_devices(KzgSettings** out, const uint
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
                     w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_send, w.d_mult, w.d_jtmp, w.d_ktime, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
-                    w.d_records, w.d_hstage[0], w.d_hstage[1], w.d_msm_save, w.d_sha_mid};
+                    w.d_records, w.d_hstage[0], w.d_hstage[1], w.d_msm_save, w.d_sha_mid, w.d_digits};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w.h_buf) (void)hipHostFree(w.h_buf);

@@ -4,7 +4,10 @@
 // The evaluation kernel over T blobs on stream s1 (radix-2^29 form; option evaluate_kernel=32 of the A/B build selects the 8x32
 // form, kept for measurement and as a cross-check).
 // alone: the evaluation is the whole call (kzg_evaluate_polynomials*, BASELINE configs[2]) - nothing else wants the CUs.
-static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr* d_z, Fr* d_y, uint32_t* d_status, size_t T, bool alone = false) {
+// stamp: the kernel records its own execution interval in the workspace's stamp words (phase 1 has zeroed them)
+static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const Fr* d_z, Fr* d_y, uint32_t* d_status, size_t T, bool alone = false,
+                              bool stamp = false) {
+    unsigned long long* const kt = stamp && s->ws.d_ktime ? s->ws.d_ktime + 4 : nullptr;
 #if KZG_AB_VARIANTS
     static const bool use32 = opt_is("evaluate_kernel", "32");
     if (use32) {
@@ -49,11 +52,11 @@ static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const F
     static const bool eval_r3 = opt_is("evaluate_kernel", "r3");  // round 3's kernel: 192 VGPRs, two wavefronts per SIMD (A/B measurement)
     if (eval_r3)
         hipLaunchKernelGGL(k_blob_evaluate_t<false>, dim3(eval_blocks), dim3(64 * EVAL_BLOBS_PER_BLOCK), spread_lds, s->s1,
-                           (const uint8_t*)d_blobs, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, s->d_eval_scratch, d_status, (int)T);
+                           (const uint8_t*)d_blobs, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, s->d_eval_scratch, d_status, (int)T, kt);
     else
 #endif
         hipLaunchKernelGGL(k_blob_evaluate_t<true>, dim3(eval_blocks), dim3(64 * EVAL_BLOBS_PER_BLOCK), spread_lds, s->s1,
-                           (const uint8_t*)d_blobs, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, s->d_eval_scratch, d_status, (int)T);
+                           (const uint8_t*)d_blobs, EvalTables{s->d_eval_a, s->d_eval_b, s->d_eval_c}, s->d_eval_scratch, d_status, (int)T, kt);
     hipLaunchKernelGGL(k_eval_finish, dim3(per_lane), dim3(64), 0, s->s1, s->d_eval_scratch, d_y, (int)T);
     return KZG_OK;
 }
@@ -135,7 +138,8 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, int stage) {
         HIPCHK(hipMalloc(&w.d_window_sl, sizeof(G1Jac) * 2 * MSM_WINDOWS * MSM_MAX_SLICES * 4));  // sliced launches have <= 4 batches
         HIPCHK(hipMalloc(&w.d_mult, MULT_ENTRY_BYTES * std::max((size_t)MSM_CHUNKS * np, (size_t)MSM_CHUNKS_LATENCY * std::min(np, (size_t)(2 * LATENCY_MAX_BLOBS + 1)))));
         HIPCHK(hipMalloc(&w.d_ab, sizeof(G1Jac) * 2 * capB));
-        HIPCHK(hipMalloc(&w.d_ktime, 32));
+        HIPCHK(hipMalloc(&w.d_ktime, 128));
+        HIPCHK(hipMalloc(&w.d_digits, 32 * nsc));
         if (msm_affine_enabled()) HIPCHK(hipMalloc(&w.d_jtmp, sizeof(G1Jac29Mem) * np));
         HIPCHK(hipMalloc(&w.d_parts, sizeof(G1Jac) * 2 * capB * MAX_WORLD));
         HIPCHK(hipMalloc(&w.d_send, sizeof(G1Jac) * 2 * MAX_WORLD));
@@ -219,6 +223,9 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     d.nterms[1] = (int)(2 * n + 1);
     d.max_terms = mt;
     d.stride = 2 * T + 1;
+    d.digits_t = w.d_digits;
+    d.nsc = (int)(B * (2 * n + 1));
+    d.ktime = w.kstamps_valid ? w.d_ktime + 8 : nullptr;
     d.chunks = w.chunks;
     d.chunks_per_block = w.chunks == MSM_CHUNKS ? msm_chunks_per_block(B) : 1;
     // option msm_xcd=0: A/B measurement of the XCD placement (msm.hpp MSM_FLAG_XCD; profiles/r3_ab_msm.txt: +2 % throughput)
@@ -250,7 +257,7 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     d.window_sums = S > 1 ? w.d_window_sl : w.d_window;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     const int nsc = (int)(B * (2 * n + 1));
-    hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc);
+    hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc, w.d_digits);
     const unsigned gz = (unsigned)(2 * B * S);
     KzgRet rc_save = msm_save_reserve(s, W, slots, gz);
     if (rc_save != KZG_OK) return rc_save;
@@ -314,7 +321,8 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
         // affine tables: rows 0 and 2 straight from the decode pass, rows 1 and 3 from 2^64 P through one inversion per 16 points
         G1Aff29Mem* mult = (G1Aff29Mem*)w.d_mult;
         // 256-thread workgroups: their four waves are dealt one to each SIMD of a CU (single-wave workgroups are placed unevenly)
-        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, true>), dim3((unsigned)((2 * T + 255) / 256)), dim3(256), 256 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, w.d_jtmp, n2, np);
+        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, true>), dim3((unsigned)((2 * T + 255) / 256)), dim3(256), 256 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s2, c, p, (int)T, w.d_points, w.d_pflag, w.d_mult, w.d_jtmp, n2, np,
+                           w.kstamps_valid ? w.d_ktime + 6 : nullptr);
         const unsigned conv_blocks = (unsigned)((n2 + 64 * AFFINE_BATCH - 1) / (64 * AFFINE_BATCH));
         hipLaunchKernelGGL(k_mult_to_affine29, dim3(conv_blocks), dim3(64), 0, s->s2, w.d_jtmp, w.d_pflag, mult, n2, np);
         HIPCHK(hipEventRecord(s->ev[10], s->s2));
@@ -488,6 +496,8 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
     KzgRet rc;
     select_streams(s, T);
     const unsigned S = host && !host->z_le ? host_slices(T) : 1;
+    w.kstamps_valid = w.d_ktime != nullptr;
+    if (w.kstamps_valid) HIPCHK(hipMemsetAsync(w.d_ktime, 0, 128, s->s1));  // (before ev[0]: every stream of the launch is ordered behind it)
     HIPCHK(hipEventRecord(s->ev[0], s->s1));
     if (host && S == 1) {  // one copy of everything, on the stream the kernels follow on
         HIPCHK(hipMemcpyAsync(const_cast<void*>(d_commitments), host->commitments, 48 * T, hipMemcpyHostToDevice, s->s1));
@@ -523,7 +533,7 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
         HIPCHK(hipStreamWaitEvent(s->s1, s->ev[7], 0));
         HIPCHK(hipStreamWaitEvent(s->s1, s->ev[6], 0));
     }
-    if ((rc = launch_evaluate(s, d_blobs, w.d_z, w.d_y, w.d_status, T)) != KZG_OK) return rc;
+    if ((rc = launch_evaluate(s, d_blobs, w.d_z, w.d_y, w.d_status, T, false, w.kstamps_valid)) != KZG_OK) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s->ev[8], s->s1));
     if (s->s_sha == s->s1) HIPCHK(hipStreamWaitEvent(s->s1, s->ev[6], 0));
@@ -545,7 +555,7 @@ static KzgRet phase1_launch_locked(const void* d_blobs, const void* d_commitment
         HIPCHK(hipMemcpyAsync(h_status, w.d_status, 4 * T, hipMemcpyDeviceToHost, s->s1));
         HIPCHK(hipMemcpyAsync(h_pflag, w.d_pflag, 8 * T, hipMemcpyDeviceToHost, s->s1));
     }
-    if (w.ktime_valid) HIPCHK(hipMemcpyAsync(h + 176 * T, w.d_ktime, 32, hipMemcpyDeviceToHost, s->s1));
+    if (w.ktime_valid || w.kstamps_valid) HIPCHK(hipMemcpyAsync(h + 176 * T, w.d_ktime, 64, hipMemcpyDeviceToHost, s->s1));  // challenge | evaluate | decode
     w.pending_n = n;
     w.pending_b = B;
     return KZG_OK;
@@ -569,6 +579,13 @@ static KzgRet phase1_wait_locked(uint8_t* records_out, uint8_t* bad_out, const K
     }
     elapsed(&s->timings[6], s->ev[5], s->ev[10]);
     elapsed(&s->timings[7], s->ev[10], s->ev[6]);
+    {  // the kernels' own intervals (100 MHz ticks): challenge (its throughput form only) | evaluate | decode + multiples
+        const unsigned long long* kt = reinterpret_cast<const unsigned long long*>(w.h_buf + 176 * T);
+        auto ms_of = [&](int k) { return kt[k] && kt[k + 1] && kt[k + 1] > ~kt[k] ? (float)((double)(kt[k + 1] - ~kt[k]) * 1e-5) : 0.f; };
+        s->kstamp_ms[0] = w.ktime_valid ? ms_of(0) : 0.f;
+        s->kstamp_ms[1] = w.kstamps_valid ? ms_of(4) : 0.f;
+        s->kstamp_ms[2] = w.kstamps_valid ? ms_of(6) : 0.f;
+    }
     uint8_t* h = w.h_buf;
     uint32_t* h_status = reinterpret_cast<uint32_t*>(h + 160 * T);
     uint32_t* h_pflag = h_status + T;
@@ -653,6 +670,7 @@ static KzgRet finish_launch_locked(const uint8_t* partials, size_t world, size_t
     if (rc != KZG_OK) return rc;
     HIPCHK(hipEventRecord(s->ev[9], s->s1));
     if (!direct) HIPCHK(hipMemcpyAsync(w.h_buf + w.off_out, w.d_slp_out, sizeof(Fp) * 6 * B, hipMemcpyDeviceToHost, s->s1));
+    if (w.kstamps_valid && w.pending_n) HIPCHK(hipMemcpyAsync(w.h_buf + 176 * w.pending_n * w.pending_b + 64, w.d_ktime + 8, 16, hipMemcpyDeviceToHost, s->s1));  // the MSM window kernel's interval
     w.finish_b = B;
     return KZG_OK;
 }
@@ -671,6 +689,13 @@ static KzgRet finish_wait_locked(bool* ok /* B */, const KzgSettings* s) {
     elapsed(&s->timings[0], s->ev[0], s->ev[9]);
     for (int i = 0; i < 8; i++) s->tsum[i] += s->timings[i];
     s->tcount++;
+    if (w.kstamps_valid && w.pending_n) {
+        const unsigned long long* kt = reinterpret_cast<const unsigned long long*>(w.h_buf + 176 * w.pending_n * w.pending_b + 64);
+        s->kstamp_ms[3] = kt[0] && kt[1] && kt[1] > ~kt[0] ? (float)((double)(kt[1] - ~kt[0]) * 1e-5) : 0.f;
+        for (int i = 0; i < 4; i++) s->kstamp_sum[i] += s->kstamp_ms[i];
+        s->kstamp_count++;
+        w.kstamps_valid = false;
+    }
     w.pending_n = w.pending_b = w.finish_b = 0;  // the group is done: the handle holds no live state (kzg_shard_finish_launch tests this)
     return KZG_OK;
 }
@@ -1064,6 +1089,7 @@ static KzgRet proof_reserve(ProofStreams& ps, const KzgSettings* s) {
     // concurrent_small_batches.py, profiles/r4_concurrent_small_batches.txt): with the masked pair made on every handle 778
     // batches/s at T = 8 and 414 at T = 16 (10 and 39 ms per call); without it 1 270 and 1 310 - 1 920 and 2 270 with 16 queues.
     select_streams(s, (size_t)-1);
+    s->ws.kstamps_valid = false;  // (no launch group on this handle: the decode pass of these paths does not stamp)
     if (!s->d_proof) HIPCHK(hipMalloc(&s->d_proof, sizeof(Fp) * (SCALARS_INPUTS + VERIFY3_INPUTS)));
     const bool one_stream = !s->s_plain[1];  // option single_stream: everything in sequence (profiling)
     // A lane of the small-call queue runs chain C (the subgroup test) BEHIND chain B on B's stream: the square roots end at
@@ -1546,6 +1572,7 @@ extern "C" KzgRet kzg_verify_kzg_proof_batch(bool* ok, const uint8_t* commitment
     select_streams(s, n);
     if ((rc = ws_reserve(s, n, 1, STAGE_CP)) != KZG_OK) return rc;
     Workspace& w = s->ws;
+    w.kstamps_valid = false;
     HIPCHK(hipEventRecord(s->ev[0], s->s1));
     // z, y: big-endian -> the device's little-endian limb arrays (= the transcript's encoding)
     std::vector<uint8_t> records(160 * n);

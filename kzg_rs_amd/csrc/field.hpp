@@ -15,6 +15,24 @@
 #include <stdint.h>
 
 namespace kzg {
+// A kernel's own execution interval, for the launches that share the chip with other launch groups (a HIP-event pair around
+// such a launch also times the wait for free CUs): kt[0] = max over the waves of ~start, kt[1] = max of end, in ticks of the
+// 100 MHz s_memrealtime counter; the first lane of every wavefront stamps, the host zeroes kt before the launch and reads
+// end - start = kt[1] - ~kt[0].  kt == nullptr: no stamp.
+__device__ __forceinline__ void kstamp_in(unsigned long long* kt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (kt && (threadIdx.x & 63) == 0) atomicMax(&kt[0], ~__builtin_amdgcn_s_memrealtime());
+#else
+    (void)kt;
+#endif
+}
+__device__ __forceinline__ void kstamp_out(unsigned long long* kt) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (kt && (threadIdx.x & 63) == 0) atomicMax(&kt[1], __builtin_amdgcn_s_memrealtime());
+#else
+    (void)kt;
+#endif
+}
 namespace consts {
 #define KZG_CONST static constexpr
 #include "constants.inc"

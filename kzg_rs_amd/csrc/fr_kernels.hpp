@@ -665,7 +665,8 @@ constexpr int EVAL_SPREAD_LDS = 96 * 1024;  // dynamic LDS nobody touches: with 
 // kernel (192 VGPRs, two wavefronts per SIMD), kept in the A/B build (option evaluate_kernel=r3) for measurement.
 template <bool SPLIT>
 __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void k_blob_evaluate_t(const uint8_t* __restrict__ blobs, const EvalTables tab,
-                                                       uint32_t* __restrict__ scratch, uint32_t* __restrict__ status, int T) {
+                                                       uint32_t* __restrict__ scratch, uint32_t* __restrict__ status, int T,
+                                                       unsigned long long* __restrict__ ktime) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int blob_idx = blockIdx.x * EVAL_BLOBS_PER_BLOCK + wave;
     const bool active = blob_idx < T;
@@ -676,6 +677,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void k_blob_evaluate_t(const ui
     uint4 (*stack_a)[64] = stack_as[wave], (*stack_b)[64] = stack_bs[wave];
     uint32_t (*stack_c)[64] = stack_cs[wave];
     if (!active) return;  // no workgroup barrier below: a wavefront only ever touches its own part of the LDS
+    kstamp_in(ktime);
     // (the wavefront's blob index is uniform, but derived from threadIdx: readfirstlane makes that provable - the blob's
     // addresses then live in scalar registers, and a buffer operation is not wrapped in a waterfall loop)
     const int blob_u = SPLIT ? __builtin_amdgcn_readfirstlane(blob_idx) : blob_idx;
@@ -855,6 +857,7 @@ __global__ __launch_bounds__(256, SPLIT ? 3 : 2) void k_blob_evaluate_t(const ui
         my[15 * 9 + lane] = vs;
     }
     if (lane == 0 && any_bad) atomicOr(&status[blob_u], 1u);
+    kstamp_out(ktime);
 }
 
 // ---------------------------------------------------------------- quotient polynomial (prover side)

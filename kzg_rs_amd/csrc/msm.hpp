@@ -20,6 +20,7 @@
 // then k_msm_combine folds the chunk sums and the 8 windows (Horner, 8 doublings per window).
 #pragma once
 #include <algorithm>
+#include "dyn_lds.hpp"
 #include "g1.hpp"
 #include "g1_29.hpp"
 
@@ -174,13 +175,15 @@ __device__ unsigned long long g_decode_dbg[4];  // HW_ID | XCC_ID | shader cycle
 template <int CHUNKS, bool AFF>
 __global__ __launch_bounds__(256, KZG_DECODE_OCC) void k_g1_decode_multiples29(const uint8_t* __restrict__ bytes0, const uint8_t* __restrict__ bytes1,
                                                                  int n0, G1Aff* __restrict__ points, uint32_t* __restrict__ pflag,
-                                                                 void* __restrict__ mult_, G1Jac29Mem* __restrict__ jtmp, int n, int stride) {
+                                                                 void* __restrict__ mult_, G1Jac29Mem* __restrict__ jtmp, int n, int stride,
+                                                                 unsigned long long* __restrict__ ktime = nullptr) {
     static_assert(!AFF || CHUNKS == 4, "the affine layout has one Jacobian multiple per point");
     constexpr int HALF = CHUNKS / 2, STEP = 256 / CHUNKS;
     extern __shared__ __attribute__((aligned(16))) uint4 park4[];  // PARK_UINT4_PER_THREAD per thread (g1_29.hpp LdsPark)
     const LdsPark pk = lds_park(park4 + threadIdx.x, blockDim.x);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    kstamp_in(ktime);
     const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_t0 = wall_clock64();
     const uint8_t* src = i < n0 ? bytes0 + (size_t)i * 48 : bytes1 + (size_t)(i - n0) * 48;
     Fp29 x, y;
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(256, KZG_DECODE_OCC) void k_g1_decode_multiples29(c
         g_decode_dbg[2] = __builtin_readcyclecounter() - dbg_c0;
         g_decode_dbg[3] = wall_clock64() - dbg_t0;
     }
+    kstamp_out(ktime);
 }
 
 // jtmp[i] = 2^64 P_i (Jacobian) -> table rows 1 and 3 of the affine layout: (X / Z^2, Y / Z^3) and its -phi image.
@@ -281,7 +285,12 @@ __global__ void k_jac_to_jac29(const G1Jac* __restrict__ in, G1Jac29Mem* __restr
 
 // in place: canonical k (< r) -> k1 (limbs 0..3) | k2 (limbs 4..7) with k = k1 + k2 * x^2.
 // Barrett with M = floor(2^383 / x^2): the quotient estimate is low by at most 1 for k < 2^255.
-__global__ __launch_bounds__(256) void k_glv_split(Fr* __restrict__ scalars, int count) {
+// digits_t (optional): the 32 digit bytes of every split scalar once more, DIGIT-major - digits_t[b * count + i] = byte b of
+// scalar i.  A (window, chunk) workgroup of k_msm_window sorts its terms by ONE byte of each scalar: from the scalar array that
+// is a 1-byte load at a 32-byte stride (a 32-byte sector of HBM / L2 traffic per byte, repeated by the 32 workgroups that read
+// the same scalar - the window kernel moved 11.8x its algorithmic bytes, profiles/r4_pmc.json); from here consecutive terms
+// are consecutive bytes.
+__global__ __launch_bounds__(256) void k_glv_split(Fr* __restrict__ scalars, int count, uint8_t* __restrict__ digits_t = nullptr) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     Fr k = scalars[i];
@@ -333,6 +342,12 @@ __global__ __launch_bounds__(256) void k_glv_split(Fr* __restrict__ scalars, int
         out.l[4 + j] = addc(q[j], 0u, carry);
     }
     scalars[i] = out;
+    if (digits_t) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) digits_t[(size_t)(4 * j + k) * count + i] = (uint8_t)(out.l[j] >> (8 * k));
+    }
 }
 
 // ---------------------------------------------------------------- bucket accumulation + reduction
@@ -361,6 +376,9 @@ struct MsmDesc {
     int z0;                       // logical blockIdx.z of this launch's first z-layer (a grid too large for the save area
                                   // is launched in pieces)
     int flags;                    // MSM_FLAG_*
+    const uint8_t* digits_t;      // (optional) the scalars' digit bytes, digit-major: [32][nsc] (k_glv_split)
+    int nsc;                      // scalars in that array
+    unsigned long long* ktime;    // (optional) the window kernel's execution interval (field.hpp kstamp_in / kstamp_out)
     int chunks_per_block;         // 1: a block per (window, chunk) - most parallel, lowest latency;  4: a block per window
                                   // sums the four chunks' terms into ONE bucket set - a quarter of the reductions and
                                   // fuller, better balanced buckets (throughput mode).  gridDim.y = chunks / chunks_per_block
@@ -846,6 +864,7 @@ template <class CV, bool LDSSORT = false>
 __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window(MsmDesc d) {  // (the latency variant has a CU to itself)
     using Pt = typename CV::Pt;
     constexpr bool TWOPASS = msm_two_pass<CV>();
+    kstamp_in(d.ktime);
     // blockIdx.z = (2*batch + output) * slices + slice
     int zz = (int)blockIdx.z + d.z0;  // logical z: (2 batch + output) * slices + slice
     int w = blockIdx.x;
@@ -884,11 +903,15 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     if (tid == 0) n_long = 0;
     __syncthreads();
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(d.scalars);
+    const uint8_t* const dt = d.digits_t;  // (uniform) digit-major copy of the same bytes, when the caller made one
+    auto digit_of = [&](uint32_t scalar_index, int byte) -> uint32_t {
+        return dt ? dt[(size_t)byte * (size_t)d.nsc + scalar_index] : sb[(size_t)scalar_index * 32 + byte];
+    };
     // 1. counting sort by digit of the cpb * nt (chunk, term) pairs; entry = chunk << 27 | point index (32 chunks at most, 2^27 points)
     for (int c = 0; c < cpb; c++) {
         const int byte = W * (j0 + c) + w;
         for (int t = tid; t < nt; t += 256) {
-            uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
+            uint32_t dig = d.pflag[tp[t]] ? 0u : digit_of(tsc[t], byte);
             atomicAdd(&cnt[dig], 1u);
         }
     }
@@ -905,7 +928,7 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     for (int c = 0; c < cpb; c++) {
         const int byte = W * (j0 + c) + w;
         for (int t = tid; t < nt; t += 256) {
-            uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
+            uint32_t dig = d.pflag[tp[t]] ? 0u : digit_of(tsc[t], byte);
             uint32_t pos = atomicAdd(&cur[dig], 1u);
             if constexpr (LDSSORT) lst[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << MSM_ENTRY_CHUNK_SHIFT;
             else sorted_global[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << MSM_ENTRY_CHUNK_SHIFT;
@@ -987,6 +1010,7 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
         // evens out the threads' work (a block lives as long as its fullest bucket: 49 entries at an average of 32), but the
         // second accumulator cost the hot loop 100 spilled registers and 4 GB of scratch writes: +0.2 %.  Not kept.)
         put(bucket, accumulate(bucket > 0 ? off[bucket] : 0u, bucket > 0 ? off[bucket + 1] : 0u));
+        kstamp_out(d.ktime);
         return;
     } else if constexpr (CV::SPLIT) {
         // (the latency variant: Curve29Quads) the same loop with the long buckets' tails left to the quads
@@ -1177,6 +1201,7 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
             d.window_sums[wi] = CV::to_std(CV::add(r, CV::lds_load(rc, 16)));
         }
     }
+    kstamp_out(d.ktime);
 }
 
 // ---- pass 2 of the two-pass form: sum_b b B_b of one window block from its 256 bucket sums in the save area.
@@ -1265,13 +1290,17 @@ __global__ __launch_bounds__(256, SAFE ? 1 : 2) void k_msm_reduce(const uint32_t
 }
 
 // Host side: launch the window kernel over grid (gx, gy, gz) in z-pieces that fit the save area (save_bytes >= one z-layer).
+// (Measured and not kept, round 5: the z-layers of ONE large sum in four pieces with the bucket reduction of piece k on a second
+// stream beside the window kernel of piece k + 1 - the reduction is a 1 ms chain of ~28 point additions per slot whatever the
+// number of slots - made a 2^20-term sum SLOWER, 10.5 ms against 8.5: four launches of long workgroups have four tails, and the
+// reduction's 198-VGPR wavefronts take SIMD slots from the window kernel.  profiles/r5_config4_experiments.txt.)
 template <class CV, bool LDSSORT>
 inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, uint32_t* save, size_t save_bytes, hipStream_t st) {
     const size_t layer = (size_t)gx * gy * (256 * (msm_two_pass<CV>() ? MSM_SAVE2_WORDS : CV::WORDS) + 1) * 4;  // (+ 1: the window's flag)
     unsigned per = (unsigned)std::min<size_t>(gz, std::max<size_t>(1, save_bytes / layer));
     d.save = save;
-    if (CV::QUADS)  // static + dynamic LDS pass 64 KB (set per call: the attribute belongs to the current device's copy of the kernel)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_msm_window<CV, LDSSORT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_QUADS_LDS_BYTES);
+    if (CV::QUADS)  // static + dynamic LDS pass 64 KB (raised once per device: dyn_lds.hpp)
+        (void)DYN_LDS((k_msm_window<CV, LDSSORT>), MSM_QUADS_LDS_BYTES);
     if (msm_two_pass<CV>() && per == gz && d.slices == 1 && (gz & 1) == 0 && d.nterms[1] > d.nterms[0]) d.flags |= MSM_FLAG_BFIRST;
     for (unsigned z = 0; z < gz; z += per) {
         d.z0 = (int)z;
@@ -1296,9 +1325,11 @@ __global__ __launch_bounds__(64) void k_msm_fold_slices(const G1Jac* __restrict_
     const int gw = blockIdx.x, g = gw / W, w = gw % W, tid = threadIdx.x;  // g runs over (2B x slots)
     __shared__ uint32_t pts[64 * 36];
     if (tid < slices) lds_store_jac(pts, tid, sums[((size_t)g * slices + tid) * W + w]);
+    int width = 1;  // (any count up to 64: the tree runs over the next power of two, the missing leaves stay out of it)
+    while (width < slices) width <<= 1;
     __syncthreads();
-    for (int half = slices >> 1; half >= 1; half >>= 1) {
-        const bool active = tid < half;
+    for (int half = width >> 1; half >= 1; half >>= 1) {
+        const bool active = tid < half && tid + half < slices;
         G1Jac x = g1_identity(), y = g1_identity();
         if (active) {
             x = lds_load_jac(pts, tid);
@@ -1364,6 +1395,35 @@ __global__ __launch_bounds__(256) void k_msm_sum_quads(const G1Jac* __restrict__
     if (tid < 3) {  // one coordinate each
         const Fp c = fp29_to_std(sumq_load(pts + 16 * tid));
         Fp* dst = tid == 0 ? &out[o].x : tid == 1 ? &out[o].y : &out[o].z;
+        *dst = c;
+    }
+}
+
+// out[o] = sum_w 2^(8 w) S[o][w] for ONE chunk group (nslots = 1) with FOUR LANES per point operation: the Horner chain of a
+// single output is 56 doublings and 7 additions in a row - 0.8 ms of a 2^20-term MSM on one lane of k_msm_combine - and a quad
+// does a doubling in three product rounds and an addition in five (g1j29_dbl_quad / g1j29_add_quad).  One wavefront per output.
+__global__ __launch_bounds__(64) void k_msm_combine_quad(const G1Jac* __restrict__ window_sums, G1Jac* __restrict__ out, int W) {
+    __shared__ __attribute__((aligned(16))) uint32_t pts[(32 + 1) * 48 + SUMQ_SCRATCH_WORDS];
+    const int o = blockIdx.x, tid = threadIdx.x, r = tid & 3;
+    uint32_t* const acc = pts + 32 * 48;
+    uint32_t* const scr = pts + 33 * 48;
+    if (tid < 3 * W) {  // thread 3 w + c: coordinate c of S_w
+        const int w = tid / 3, c = tid % 3;
+        const G1Jac& p = window_sums[(size_t)o * W + w];
+        sumq_store(pts + w * 48 + 16 * c, fp29_from_std(c == 0 ? p.x : c == 1 ? p.y : p.z));
+    }
+    __syncthreads();
+    if (tid >= 4) return;  // (one quad: its LDS instructions execute in order)
+    if (r < 3) sumq_store(acc + 16 * r, sumq_load(pts + (W - 1) * 48 + 16 * r));
+#pragma unroll 1
+    for (int w = W - 2; w >= 0; w--) {
+#pragma unroll 1
+        for (int k = 0; k < MSM_C; k++) g1j29_dbl_quad<SumqLayout16>(acc, acc, scr, r);
+        g1j29_add_quad<SumqLayout16>(acc, pts + w * 48, acc, scr, r, tid);
+    }
+    if (r < 3) {
+        const Fp c = fp29_to_std(sumq_load(acc + 16 * r));
+        Fp* dst = r == 0 ? &out[o].x : r == 1 ? &out[o].y : &out[o].z;
         *dst = c;
     }
 }

@@ -25,5 +25,19 @@ i=0
     KZG_OPTIONS=single_stream=1 KZG_PMC_CALIBRATE=1 rocprofv3 --pmc $ctrs --kernel-trace -d $out -o run --output-format csv -- python3 bench.py --no-cpu-baseline --no-latency --no-self-check --group $group --inflight 1 --steps 1 --warmup 0 > $out.log 2>&1
 done
 [ "${SKIP_PMC:-0}" = "1" ] || python3 tools/prof/pmc_to_json.py gpurun_out/${tag}_pmc $group > gpurun_out/${tag}_pmc.json
+# 4. BASELINE configs[2] / configs[3] alone (tools/prof/config_legs.py = bench.config_legs): kernel stats, then the same PMC passes
+#    -> gpurun_out/<tag>_config_stats/, gpurun_out/<tag>_config_pmc.json (its "kernels" hold the 2^20-term launch of k_msm_window and
+#    the 16 384-blob launch of k_blob_evaluate: their largest dispatches in that process)
+rm -rf gpurun_out/${tag}_config_stats; mkdir -p gpurun_out/${tag}_config_stats
+rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_config_stats -o run --output-format csv -- python3 tools/prof/config_legs.py --no-cpu > gpurun_out/${tag}_config_stats.log 2>&1
+grep '^{' gpurun_out/${tag}_config_stats.log | tail -1 > gpurun_out/${tag}_config_legs_profiled.json
+i=0
+[ "${SKIP_PMC:-0}" = "1" ] || for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
+    i=$((i+1))
+    out=gpurun_out/${tag}_config_pmc_$i
+    rm -rf $out; mkdir -p $out
+    KZG_OPTIONS="single_stream=1;g1_msm_overlap=0" rocprofv3 --pmc $ctrs --kernel-trace -d $out -o run --output-format csv -- python3 tools/prof/config_legs.py --no-cpu > $out.log 2>&1
+done
+[ "${SKIP_PMC:-0}" = "1" ] || python3 tools/prof/pmc_to_json.py gpurun_out/${tag}_config_pmc 0 > gpurun_out/${tag}_config_pmc.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -1 gpurun_out/${tag}_bench.json | cut -c1-400
