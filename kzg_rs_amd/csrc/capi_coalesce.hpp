@@ -34,7 +34,8 @@ constexpr size_t SMALL_MAX_BLOBS = 256;            // blobs per launch (= the ra
 
 static void small_free(KzgSettings* s) {
     if (!s->small) return;
-    for (SmallLane* l : s->small->lanes) {
+    for (size_t i = 0; i < s->small->n_lanes; i++) {
+        SmallLane* l = s->small->lanes[i];
         if (l && l->h) {
             (void)hipSetDevice(l->h->device);
             kzg_settings_free(l->h);
@@ -143,16 +144,16 @@ static KzgRet small_run_blobs(SmallLane& L, std::vector<SmallReq*>& batch, size_
 // a lane for a new leader: a free one, or a new one while the handle has fewer than max_lanes (the slot is taken under the
 // lock, the lane itself - two streams, a dozen events - is made by the leader outside it); -1: all busy
 static int small_take_lane(SmallQueue& Q) {
-    for (size_t i = 0; i < Q.lanes.size(); i++)
+    for (size_t i = 0; i < Q.n_lanes; i++)
         if (!Q.lanes[i]->busy) {
             Q.lanes[i]->busy = true;
             return (int)i;
         }
-    if (Q.lanes.size() < Q.max_lanes) {
+    if (Q.n_lanes < Q.max_lanes && Q.n_lanes < SMALL_LANES_MAX) {
         SmallLane* L = new SmallLane();
         L->busy = true;
-        Q.lanes.push_back(L);
-        return (int)Q.lanes.size() - 1;
+        Q.lanes[Q.n_lanes] = L;
+        return (int)Q.n_lanes++;
     }
     return -1;
 }
@@ -165,11 +166,25 @@ static int small_take_lane(SmallQueue& Q) {
 #include <sys/syscall.h>
 #include <unistd.h>
 static void small_sleep(std::atomic<uint32_t>& word, uint32_t seen) {
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&word), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&word), FUTEX_WAIT_PRIVATE, (unsigned long)seen, nullptr, nullptr, 0UL);
 }
-static void small_wake_all(std::atomic<uint32_t>& word) {
+static void small_wake(std::atomic<uint32_t>& word, int how_many) {
     word.fetch_add(1, std::memory_order_release);
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&word), FUTEX_WAKE_PRIVATE, 0x7fffffff, nullptr, nullptr, 0);
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&word), FUTEX_WAKE_PRIVATE, (unsigned long)how_many, nullptr, nullptr, 0UL);
+}
+static void small_wake_all(std::atomic<uint32_t>& word) { small_wake(word, 0x7fffffff); }
+// Everybody asleep on `from` goes to sleep on `to` instead, without waking (FUTEX_CMP_REQUEUE): the callers a leader has just
+// taken into its launch move from the queue's word to the lane's, so that the launch's completion wakes exactly them - with one
+// word for everybody every completion woke the callers of the OTHER launch in flight as well, 256 threads of which half went
+// straight back to sleep (10 host cores at 256 threads; the cgroups of this project's boxes give a job 16).  `from` is bumped
+// first: a caller that was about to sleep on it (it read the old value) does not, and finds its lane on the way round.
+// Returns false when the word moved under us (then the caller wakes everybody instead: they sort themselves out).
+static bool small_requeue_all(std::atomic<uint32_t>& from, std::atomic<uint32_t>& to) {
+    const uint32_t now = from.fetch_add(1, std::memory_order_acq_rel) + 1;
+    // (uaddr, op, nr_wake = 0, nr_requeue in the timeout slot, uaddr2, the value uaddr must still hold)
+    const long rc = syscall(SYS_futex, reinterpret_cast<uint32_t*>(&from), FUTEX_CMP_REQUEUE_PRIVATE, 0UL, (unsigned long)0x7fffffff, reinterpret_cast<uint32_t*>(&to),
+                            (unsigned long)now);
+    return rc >= 0;
 }
 static uint64_t small_now_us() {
     return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -200,7 +215,9 @@ static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
     }
     Q.arrivals.fetch_add(1, std::memory_order_relaxed);
     for (;;) {
-        const uint32_t seen = Q.epoch.load(std::memory_order_acquire);
+        const int my_lane = r.lane.load(std::memory_order_acquire);
+        std::atomic<uint32_t>& word = my_lane >= 0 ? Q.lanes[my_lane]->word : Q.epoch;  // where this caller sleeps: its launch's lane, or the queue
+        const uint32_t seen = word.load(std::memory_order_acquire);
         if (r.done.load(std::memory_order_acquire)) break;
         int li = -1;
         std::unique_lock<std::mutex> lk(Q.mu, std::defer_lock);
@@ -211,7 +228,7 @@ static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
         }
         if (li < 0) {
             if (r.hash && r.hash->unclaimed()) hostpool::help(*r.hash);  // nothing to lead: hash the own blobs instead of sleeping
-            else small_sleep(Q.epoch, seen);
+            else small_sleep(word, seen);
             continue;
         }
         // ---- leader (holds the lock and lane li)
@@ -248,6 +265,7 @@ static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
             for (auto it = Q.q.begin(); it != Q.q.end();) {
                 SmallReq* x = *it;
                 if (x->kind == kind && m + x->n <= cap) {
+                    x->lane.store(li, std::memory_order_release);
                     x->taken.store(true, std::memory_order_relaxed);
                     m += x->n;
                     batch.push_back(x);
@@ -266,8 +284,11 @@ static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
         Q.max_items = std::max<uint64_t>(Q.max_items, m);
         const bool more = !Q.q.empty();
         const size_t shard = (size_t)li % shard_count(s);
+        // the callers of this launch: from the queue's word to the lane's (everybody asleep on the queue's word is in the launch
+        // when the queue is empty now; with requests of the other kind, or beyond the launch's capacity, left in the queue -
+        // another lane may be free for them - everybody is woken and finds its place)
+        if (more || !small_requeue_all(Q.epoch, L.word)) small_wake_all(Q.epoch);
         lk.unlock();
-        if (more) small_wake_all(Q.epoch);  // (requests are left, and another lane may be free: one of them leads the next launch right away)
         KzgRet rc = KZG_OK;
         std::string msg;
         const KzgSettings* const home = shard_of(s, shard);
@@ -303,13 +324,15 @@ static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
         L.busy = false;
         Q.last_done_us = small_now_us();
         Q.last_done_items = batch.size();
+        const bool waiting = !Q.q.empty();
         lk.unlock();
         for (SmallReq* x : batch) {
             x->rc = rc;
             if (rc != KZG_OK) x->msg = msg;
             x->done.store(true, std::memory_order_release);  // (the owner may return, and its request die, from here on)
         }
-        small_wake_all(Q.epoch);  // the launch's callers; and the lane is free again: one of the waiting requests leads
+        small_wake_all(L.word);                // the launch's callers
+        if (waiting) small_wake(Q.epoch, 1);   // the lane is free again: ONE of the callers still in the queue leads (it takes the others along)
     }
     if (r.rc != KZG_OK) g_err = r.msg;
     return r.rc;
@@ -366,7 +389,7 @@ extern "C" KzgRet kzg_debug_small_queue_stats(const KzgSettings* s, uint64_t out
     out[1] = s->small->requests;
     out[2] = s->small->items;
     out[3] = s->small->max_items;
-    out[4] = s->small->lanes.size();
+    out[4] = s->small->n_lanes;
     if (reset) s->small->launches = s->small->requests = s->small->items = s->small->max_items = 0;
     return KZG_OK;
 }

@@ -63,6 +63,16 @@ static bool opt_is(const char* key, const char* value) {
     const char* v = opt_str(key);
     return v && strcmp(v, value) == 0;
 }
+// ab_flag / ab_int: switches whose only use is to select a form kept for A/B MEASUREMENT (a superseded kernel form, a tuning
+// value that was swept once): compiled into the A/B build only - the product build takes the default at compile time, so its
+// KZG_OPTIONS surface is the deployment and test switches, not the lab's.
+#if KZG_AB_VARIANTS
+static bool ab_flag(const char* key, bool dflt) { return opt_flag(key, dflt); }
+static long ab_int(const char* key, long dflt) { return opt_int(key, dflt); }
+#else
+static constexpr bool ab_flag(const char*, bool dflt) { return dflt; }
+static constexpr long ab_int(const char*, long dflt) { return dflt; }
+#endif
 #define KZG_HOST_THREADS_OPTION opt_int("host_threads", 16)
 #include "host_only.hpp"
 static const char* hw_queues_note() {
@@ -120,7 +130,7 @@ static bool fp29_enabled() {
 // Throughput layout of the verification MSM (MSM_CHUNKS tables) with AFFINE entries and mixed additions (msm.hpp
 // k_mult_to_affine29); option msm_affine=0 keeps Jacobian entries (A/B measurement).  Radix-2^29 field only.
 static bool msm_affine_enabled() {
-    static const bool v = fp29_enabled() && opt_flag("msm_affine", true);
+    static const bool v = fp29_enabled() && ab_flag("msm_affine", true);
     return v;
 }
 constexpr size_t MULT_ENTRY_BYTES = sizeof(G1Jac29Mem) > sizeof(G1Jac) ? sizeof(G1Jac29Mem) : sizeof(G1Jac);

@@ -246,7 +246,7 @@ static KzgRet multi_build(KzgSettings* s, const uint8_t tau_g2[96], const std::v
         }
     }
     s->note = "exchange: " + m->exchange_note;
-    if (s->small) s->small->max_lanes = std::min<size_t>(16, s->small->max_lanes * D);  // small calls: the same number of lanes on every device (lane i on shard i mod D)
+    if (s->small) s->small->max_lanes = std::min<size_t>(SMALL_LANES_MAX, s->small->max_lanes * D);  // small calls: the same number of lanes on every device (lane i on shard i mod D)
     HIPCHK(hipSetDevice(s->device));
     return KZG_OK;
 }

@@ -177,7 +177,7 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     // g1_msm_slice_terms, default 3 072: 4 x 3 072 list entries = 48 KB of LDS, three workgroups per CU - measured at 2^20 terms
     // against 2 048: fewer (window, slice) workgroups to reduce and fold), their number a multiple of 4 (the XCD placement of
     // msm.hpp wants 2 S workgroup layers in eights)
-    static const size_t slice_terms = (size_t)std::max(256L, std::min(3072L, opt_int("g1_msm_slice_terms", (long)G1_MSM_SLICE_TERMS)));
+    static const size_t slice_terms = (size_t)std::max(256L, std::min(3072L, ab_int("g1_msm_slice_terms", (long)G1_MSM_SLICE_TERMS)));
     const size_t h = (n + 1) / 2;
     unsigned S = (unsigned)((h + slice_terms - 1) / slice_terms);
     S = S <= 1 ? 1 : (S + 3) & ~3u;
@@ -192,15 +192,13 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     }
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     if (n) {
-        hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, (int)n, w.d_digits);
+        hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, (int)n);
         hipLaunchKernelGGL(k_plain_terms, dim3((unsigned)((2 * h + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar, (int)(2 * h));
     }
     MsmDesc d{};
     d.mult = w.d_mult;
     d.pflag = w.d_pflag;
     d.scalars = w.d_scalars;
-    d.digits_t = n ? w.d_digits : nullptr;
-    d.nsc = (int)n;
     d.term_point = w.d_term_point;  // output 1's list starts at entry max_terms = h: term_point[i] = i serves both
     d.term_scalar = w.d_term_scalar;
     d.sorted = w.d_sorted;

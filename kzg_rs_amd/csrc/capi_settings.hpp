@@ -43,7 +43,6 @@ struct Workspace {
     unsigned long long* d_ktime = nullptr;
     bool ktime_valid = false;   // [0, 4) were written (the challenge took its throughput form)
     bool kstamps_valid = false; // [4, 10) belong to the group in flight
-    uint8_t* d_digits = nullptr;  // the split scalars' digit bytes, digit-major [32][scalars of the launch] (msm.hpp k_glv_split)
     G1Jac29Mem* d_jtmp = nullptr;  // 2^64 P of every decoded point on its way to the affine table (k_mult_to_affine29)
     bool mult_affine = false;      // format of d_mult as the last decode left it
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
@@ -76,16 +75,20 @@ struct SmallReq {
     KzgRet rc = KZG_OK;  // a failure of the launch that carried the request (every request of that launch gets it)
     std::string msg;
     std::atomic<bool> taken{false}, done{false};  // taken: written under the queue's lock; done: the leader's LAST access to the request
+    std::atomic<int> lane{-1};                    // the lane whose launch carries the request (its owner then sleeps on that lane's word)
 };
+constexpr size_t SMALL_LANES_MAX = 16;
 struct SmallLane {
     KzgSettings* h = nullptr;  // a private lane (settings_lane) on one device of the handle
     bool busy = false;
+    std::atomic<uint32_t> word{0};  // the futex word the callers of this lane's launch sleep on
     std::vector<uint8_t> c, z, y, p, okerr;  // the gathered tuples of a launch
 };
 struct SmallQueue {
     std::mutex mu;
     std::deque<SmallReq*> q;        // waiting requests, oldest first
-    std::vector<SmallLane*> lanes;  // made on demand, up to max_lanes
+    SmallLane* lanes[SMALL_LANES_MAX] = {};  // made on demand, up to max_lanes (a slot, once set, never changes: read without the lock by who knows its index)
+    size_t n_lanes = 0;
     size_t max_lanes = 2;
     bool lane_two_streams = false;  // option small_streams=2: chain C of the one-proof path behind chain B, two streams per lane (A/B measurement)
     // The lanes' streams are made at the device's highest priority (option small_priority=0: normal).  Not for the priority
@@ -95,7 +98,7 @@ struct SmallQueue {
     // took 2.9 ms each instead of 1.7 (1.84 with 16 queues, 1.75 with priority lanes: profiles/r5_small_call_queues.txt).
     int lane_priority = 1;
     long linger_us = 250, linger_gap_us = 40;  // options small_linger_us / small_linger_gap_us (capi_coalesce.hpp small_submit); 0: never wait
-    std::atomic<uint32_t> epoch{0};    // the futex word every waiter sleeps on
+    std::atomic<uint32_t> epoch{0};    // the futex word the callers whose request is still in the queue sleep on
     std::atomic<uint64_t> arrivals{0};
     uint64_t last_done_us = 0;         // when the last launch finished, and how many calls it carried
     size_t last_done_items = 0;
@@ -241,7 +244,7 @@ static KzgRet run_program2(const DevProgram2& dp, const Fp* d_in, const uint32_t
 }
 // which form runs a launch of `instances` checks: option pairing=1 | 2 forces the one-wave / the latency program (A/B, cross-check)
 static bool pairing_latency_form(size_t instances) {
-    static const int forced = (int)opt_int("pairing", 0);
+    static const int forced = (int)ab_int("pairing", 0);
     return forced == 2 || (forced != 1 && instances <= LATENCY_PAIRING_MAX);
 }
 static KzgRet run_verify(const KzgSettings* s, const Fp* d_in, Fp* d_out, int instances, hipStream_t st);
@@ -283,11 +286,11 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
     }
     if (opt_flag("coalesce", true)) {  // (a peer of a multi-device handle loses it again in multi_build: only the handle a caller holds has one)
         s->small = new SmallQueue();
-        s->small->max_lanes = (size_t)std::max(1L, std::min(8L, opt_int("small_lanes", 2)));
-        s->small->lane_two_streams = opt_int("small_streams", 3) == 2;
-        s->small->lane_priority = opt_int("small_priority", 1) ? 1 : 0;
+        s->small->max_lanes = (size_t)std::max(1L, std::min((long)SMALL_LANES_MAX, opt_int("small_lanes", 2)));
+        s->small->lane_two_streams = ab_int("small_streams", 3) == 2;
+        s->small->lane_priority = ab_int("small_priority", 1) ? 1 : 0;
         s->small->linger_us = std::max(0L, std::min(2000L, opt_int("small_linger_us", 250)));
-        s->small->linger_gap_us = std::max(1L, std::min(1000L, opt_int("small_linger_gap_us", 40)));
+        s->small->linger_gap_us = std::max(1L, std::min(1000L, ab_int("small_linger_gap_us", 40)));
     }
     *out = s;
     return KZG_OK;
@@ -598,7 +601,7 @@ extern "C" KzgRet kzg_settings_from_tau_g2_devices(KzgSettings** out, const uint
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
                     w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_send, w.d_mult, w.d_jtmp, w.d_ktime, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
-                    w.d_records, w.d_hstage[0], w.d_hstage[1], w.d_msm_save, w.d_sha_mid, w.d_digits};
+                    w.d_records, w.d_hstage[0], w.d_hstage[1], w.d_msm_save, w.d_sha_mid};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w.h_buf) (void)hipHostFree(w.h_buf);

@@ -33,7 +33,7 @@ static KzgRet launch_evaluate(const KzgSettings* s, const void* d_blobs, const F
     // faster (14.5 against 15.3 ms per 262 144 blobs), but beside the other launch groups' kernels three workgroups hold
     // 117 KB of a CU's 160 KB of LDS and the MSM window blocks (36-46 KB each) queue behind them: 4.74-4.82 M blobs/s with
     // three, 4.91-4.97 M with two (profiles/r4_ab_evaluate.txt).  Option eval_lds_pad=<bytes> overrides (measurement).
-    static const long pad_opt = opt_int("eval_lds_pad", -1);
+    static const long pad_opt = ab_int("eval_lds_pad", -1);
     const size_t lds_pad = pad_opt >= 0 ? (size_t)std::min(120L * 1024, pad_opt) : alone ? 0 : 16384;
     // (the attribute is a per-kernel maximum that dyn_lds_ensure only raises: concurrent launches with different paddings cannot
     // fail each other; a launch whose request could not be raised goes without its padding - slower placement, same result)
@@ -139,7 +139,6 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, int stage) {
         HIPCHK(hipMalloc(&w.d_mult, MULT_ENTRY_BYTES * std::max((size_t)MSM_CHUNKS * np, (size_t)MSM_CHUNKS_LATENCY * std::min(np, (size_t)(2 * LATENCY_MAX_BLOBS + 1)))));
         HIPCHK(hipMalloc(&w.d_ab, sizeof(G1Jac) * 2 * capB));
         HIPCHK(hipMalloc(&w.d_ktime, 128));
-        HIPCHK(hipMalloc(&w.d_digits, 32 * nsc));
         if (msm_affine_enabled()) HIPCHK(hipMalloc(&w.d_jtmp, sizeof(G1Jac29Mem) * np));
         HIPCHK(hipMalloc(&w.d_parts, sizeof(G1Jac) * 2 * capB * MAX_WORLD));
         HIPCHK(hipMalloc(&w.d_send, sizeof(G1Jac) * 2 * MAX_WORLD));
@@ -180,7 +179,7 @@ static KzgRet ws_reserve(const KzgSettings* s, size_t T, size_t B, int stage) {
 // batch dimension alone fills the chip (msm.hpp MsmDesc::chunks_per_block); option msm_cpb = 1 | 2 | 4 overrides.
 static int msm_chunks_per_block(size_t B) {
     static const int forced = [] {
-        const int v = (int)opt_int("msm_cpb", 0);
+        const int v = (int)ab_int("msm_cpb", 0);
         return (v == 1 || v == 2 || v == 4) ? v : 0;
     }();
     if (forced) return forced;
@@ -223,13 +222,11 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     d.nterms[1] = (int)(2 * n + 1);
     d.max_terms = mt;
     d.stride = 2 * T + 1;
-    d.digits_t = w.d_digits;
-    d.nsc = (int)(B * (2 * n + 1));
     d.ktime = w.kstamps_valid ? w.d_ktime + 8 : nullptr;
     d.chunks = w.chunks;
     d.chunks_per_block = w.chunks == MSM_CHUNKS ? msm_chunks_per_block(B) : 1;
     // option msm_xcd=0: A/B measurement of the XCD placement (msm.hpp MSM_FLAG_XCD; profiles/r3_ab_msm.txt: +2 % throughput)
-    static const int msm_flags = opt_flag("msm_xcd", true) ? MSM_FLAG_XCD : 0;
+    static const int msm_flags = ab_flag("msm_xcd", true) ? MSM_FLAG_XCD : 0;
     d.flags = msm_flags;
     const unsigned slots = d.chunks / d.chunks_per_block, W = MSM_WINDOWS / d.chunks;
     // one large batch: slice the terms of an output over several workgroups until the launch has ~1000 of them
@@ -239,7 +236,7 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     // a small launch (the latency layout: one batch, 64 blocks) is bound by its fullest bucket - ~18 of 2 049 terms, 15 us
     // a Jacobian addition at lone-wave speed: four slices quarter that chain for one more short fold
     static const unsigned latency_slices = [] {  // option msm_latency_slices = 1 | 2 | 4 | 8 (A/B measurement)
-        const unsigned v = (unsigned)opt_int("msm_latency_slices", 0);
+        const unsigned v = (unsigned)ab_int("msm_latency_slices", 0);
         return v == 1 || v == 2 || v == 4 || v == 8 ? v : 4u;
     }();
     if (d.chunks != MSM_CHUNKS && S == 1 && n >= 256 && B <= 4) S = latency_slices;
@@ -257,7 +254,7 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
     d.window_sums = S > 1 ? w.d_window_sl : w.d_window;
     HIPCHK(hipEventRecord(s->ev[2], s->s1));
     const int nsc = (int)(B * (2 * n + 1));
-    hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc, w.d_digits);
+    hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, nsc);
     const unsigned gz = (unsigned)(2 * B * S);
     KzgRet rc_save = msm_save_reserve(s, W, slots, gz);
     if (rc_save != KZG_OK) return rc_save;
@@ -266,7 +263,7 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
         else msm_window_launch<Curve29Aff, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
     } else if (fp29_enabled()) {
         // the latency layout's few workgroups run their reduction trees with four lanes per addition (option msm_tree_quads=0: A/B)
-        static const bool tree_quads = opt_flag("msm_tree_quads", true);
+        static const bool tree_quads = ab_flag("msm_tree_quads", true);
         if (tree_quads && d.chunks != MSM_CHUNKS && B <= 4) {
             if (lds_sort) msm_window_launch<Curve29Quads, true>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
             else msm_window_launch<Curve29Quads, false>(d, W, slots, gz, w.d_msm_save, w.cap_msm_save, s->s1);
@@ -281,7 +278,7 @@ static KzgRet run_msm(const KzgSettings* s, size_t n, size_t B) {
 #endif
     // the latency layout (one window per chunk) of a few batches: every output is the plain sum of its slots x slices window
     // sums - one workgroup per output, four lanes per addition (option msm_sum_quads=0: the fold + combine kernels, A/B)
-    static const bool sum_quads = opt_flag("msm_sum_quads", true);
+    static const bool sum_quads = ab_flag("msm_sum_quads", true);
     if (sum_quads && W == 1 && fp29_enabled() && slots * S >= 2 && slots * S <= (unsigned)SUMQ_MAX_POINTS && 2 * B < 64) {
         HIPCHK(DYN_LDS(k_msm_sum_quads, SUMQ_LDS_BYTES));
         hipLaunchKernelGGL(k_msm_sum_quads, dim3((unsigned)(2 * B)), dim3(256), SUMQ_LDS_BYTES, s->s1, d.window_sums, w.d_ab, (int)(slots * S));
@@ -306,7 +303,7 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
     Workspace& w = s->ws;
     const int np = (int)(2 * T + 1);
     unsigned blocks = (unsigned)((2 * T + 63) / 64);
-    static const bool no_latency_layout = !opt_flag("msm_latency_layout", true);
+    static const bool no_latency_layout = !ab_flag("msm_latency_layout", true);
 #if KZG_AB_VARIANTS
     static const bool proofs_16 = opt_int("proofs_chunks", 0) == 16;  // (A/B measurement: round 1's sixteen 16-bit chunks for the proof-tuple entries)
 #else
@@ -334,7 +331,7 @@ static KzgRet launch_decode(const KzgSettings* s, const void* d_commitments, con
         hipLaunchKernelGGL(k_set_generator_multiples<G1Jac29Mem>, dim3(1), dim3(64), 0, s->s2, w.d_points, w.d_pflag, mult,
                            (const G1Jac29Mem*)s->d_gen_mult + gen_off, n2, np, w.chunks);
         // the latency layouts: eight lanes per point, one wavefront of 8 points per CU (option decode_quads=0: one lane, A/B)
-        static const bool dec_quads = opt_flag("decode_quads", true);
+        static const bool dec_quads = ab_flag("decode_quads", true);
         // (while every workgroup can have a CU to itself, and not beside the challenge chain: there the decode hides behind the
         // chain anyway and has only half the CUs)
         if (dec_quads && w.chunks != MSM_CHUNKS && !behind_sha && (2 * T + DECQ_POINTS_PER_BLOCK - 1) / DECQ_POINTS_PER_BLOCK <= (size_t)s->n_cus) {
@@ -393,7 +390,7 @@ static void select_streams(const KzgSettings* s, size_t T) {
     if (small && !s->s_half_tried) {
         s->s_half_tried = true;
         hipDeviceProp_t prop;
-        if (opt_flag("cu_mask", true) && hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount >= 64) {
+        if (ab_flag("cu_mask", true) && hipGetDeviceProperties(&prop, s->device) == hipSuccess && prop.multiProcessorCount >= 64) {
             const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
             std::vector<uint32_t> lo(words, 0), hi(words, 0);
             for (int i = 0; i < ncu; i++) ((i < ncu / 2) ? lo : hi)[i / 32] |= 1u << (i % 32);

@@ -285,12 +285,12 @@ __global__ void k_jac_to_jac29(const G1Jac* __restrict__ in, G1Jac29Mem* __restr
 
 // in place: canonical k (< r) -> k1 (limbs 0..3) | k2 (limbs 4..7) with k = k1 + k2 * x^2.
 // Barrett with M = floor(2^383 / x^2): the quotient estimate is low by at most 1 for k < 2^255.
-// digits_t (optional): the 32 digit bytes of every split scalar once more, DIGIT-major - digits_t[b * count + i] = byte b of
-// scalar i.  A (window, chunk) workgroup of k_msm_window sorts its terms by ONE byte of each scalar: from the scalar array that
-// is a 1-byte load at a 32-byte stride (a 32-byte sector of HBM / L2 traffic per byte, repeated by the 32 workgroups that read
-// the same scalar - the window kernel moved 11.8x its algorithmic bytes, profiles/r4_pmc.json); from here consecutive terms
-// are consecutive bytes.
-__global__ __launch_bounds__(256) void k_glv_split(Fr* __restrict__ scalars, int count, uint8_t* __restrict__ digits_t = nullptr) {
+// (Round 5 tried a DIGIT-major copy of the split scalars - digits_t[b * count + i] = byte b of scalar i - so that the window
+// kernel's sort reads consecutive bytes for consecutive terms instead of one byte per 32-byte scalar: the window kernel's HBM
+// bytes went from 1.182 to 1.169 GB per launch group and its time and SQ_WAIT_ANY share did not move - those byte reads were L2
+// hits, the kernel's traffic is its table rows (4 x 128 B per term, 0.40 GB per group, read ~1.6x) and the bucket sums between
+// the passes (0.20 GB).  Not kept.  profiles/r5_pmc.json vs r4_pmc.json.)
+__global__ __launch_bounds__(256) void k_glv_split(Fr* __restrict__ scalars, int count) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     Fr k = scalars[i];
@@ -342,12 +342,6 @@ __global__ __launch_bounds__(256) void k_glv_split(Fr* __restrict__ scalars, int
         out.l[4 + j] = addc(q[j], 0u, carry);
     }
     scalars[i] = out;
-    if (digits_t) {
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-#pragma unroll
-            for (int k = 0; k < 4; k++) digits_t[(size_t)(4 * j + k) * count + i] = (uint8_t)(out.l[j] >> (8 * k));
-    }
 }
 
 // ---------------------------------------------------------------- bucket accumulation + reduction
@@ -376,8 +370,6 @@ struct MsmDesc {
     int z0;                       // logical blockIdx.z of this launch's first z-layer (a grid too large for the save area
                                   // is launched in pieces)
     int flags;                    // MSM_FLAG_*
-    const uint8_t* digits_t;      // (optional) the scalars' digit bytes, digit-major: [32][nsc] (k_glv_split)
-    int nsc;                      // scalars in that array
     unsigned long long* ktime;    // (optional) the window kernel's execution interval (field.hpp kstamp_in / kstamp_out)
     int chunks_per_block;         // 1: a block per (window, chunk) - most parallel, lowest latency;  4: a block per window
                                   // sums the four chunks' terms into ONE bucket set - a quarter of the reductions and
@@ -903,15 +895,12 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     if (tid == 0) n_long = 0;
     __syncthreads();
     const uint8_t* sb = reinterpret_cast<const uint8_t*>(d.scalars);
-    const uint8_t* const dt = d.digits_t;  // (uniform) digit-major copy of the same bytes, when the caller made one
-    auto digit_of = [&](uint32_t scalar_index, int byte) -> uint32_t {
-        return dt ? dt[(size_t)byte * (size_t)d.nsc + scalar_index] : sb[(size_t)scalar_index * 32 + byte];
-    };
+
     // 1. counting sort by digit of the cpb * nt (chunk, term) pairs; entry = chunk << 27 | point index (32 chunks at most, 2^27 points)
     for (int c = 0; c < cpb; c++) {
         const int byte = W * (j0 + c) + w;
         for (int t = tid; t < nt; t += 256) {
-            uint32_t dig = d.pflag[tp[t]] ? 0u : digit_of(tsc[t], byte);
+            uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
             atomicAdd(&cnt[dig], 1u);
         }
     }
@@ -928,7 +917,7 @@ __global__ __launch_bounds__(256, CV::QUADS ? 1 : KZG_MSM_OCC) void k_msm_window
     for (int c = 0; c < cpb; c++) {
         const int byte = W * (j0 + c) + w;
         for (int t = tid; t < nt; t += 256) {
-            uint32_t dig = d.pflag[tp[t]] ? 0u : digit_of(tsc[t], byte);
+            uint32_t dig = d.pflag[tp[t]] ? 0u : sb[(size_t)tsc[t] * 32 + byte];
             uint32_t pos = atomicAdd(&cur[dig], 1u);
             if constexpr (LDSSORT) lst[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << MSM_ENTRY_CHUNK_SHIFT;
             else sorted_global[off[dig] + pos] = tp[t] | (uint32_t)(j0 + c) << MSM_ENTRY_CHUNK_SHIFT;

@@ -22,6 +22,7 @@ extern "C" {
     pub fn kzg_settings_from_tau_g2_devices(out: *mut *mut RawSettings, tau_g2: *const u8, devices: *const c_int, n_devices: usize) -> c_int;
     pub fn kzg_settings_devices(s: *const RawSettings, n_devices: *mut usize, devices_out: *mut c_int, cap: usize, exchange: *mut c_int) -> c_int;
     pub fn kzg_settings_free(s: *mut RawSettings);
+    pub fn kzg_settings_note(s: *const RawSettings) -> *const c_char;
     pub fn kzg_settings_root_of_unity(s: *const RawSettings, i: usize, out: *mut u8) -> c_int;
     pub fn kzg_settings_g1_point(s: *const RawSettings, i: usize, out: *mut u8) -> c_int;
     pub fn kzg_settings_g2_point(s: *const RawSettings, i: usize, out: *mut u8) -> c_int;
@@ -47,12 +48,27 @@ pub fn last_error() -> String {
 
 /// `KzgRet` -> `Result`: KZG_OK is "the boolean is valid" (`Ok(true)` / `Ok(false)`), everything else one of the
 /// reference's `Err(KzgError::...)` (include/kzg_rs_amd.h, "Conventions").
+/// What a successful constructor wants its caller to know about the handle ("" = nothing): fewer than 8 HIP hardware queues,
+/// how a multi-device handle exchanges its partial sums and what its self-test found.
+pub fn settings_note(h: &Handle) -> String {
+    unsafe {
+        let p = kzg_settings_note(h.0);
+        if p.is_null() {
+            return String::new();
+        }
+        CStr::from_ptr(p).to_string_lossy().to_string()
+    }
+}
+
 pub fn check(rc: c_int) -> Result<(), KzgError> {
     KzgError::from_ret(rc, last_error)
 }
 
-/// Owner of one `KzgSettings*` of the library.  The library serialises calls on a handle internally and the handle is
-/// immutable after creation, so sharing it between threads is sound.
+/// Owner of one `KzgSettings*` of the library.  The handle is immutable after creation and the library serves it to any number
+/// of threads at once - the small calls of concurrent callers are coalesced into shared launches on pooled lanes, each caller
+/// with its own verdict (csrc/capi_coalesce.hpp), large calls take the handle's own lock - so sharing it between threads is
+/// sound AND scales: one `static` settings value for a thread pool of `verify_kzg_proof` callers is the intended use, as with the
+/// reference's `&'static` slices (src/trusted_setup.rs:44-50,80-92).
 pub struct Handle(pub *mut RawSettings);
 unsafe impl Send for Handle {}
 unsafe impl Sync for Handle {}

@@ -105,7 +105,7 @@ def test_batch_challenges_is_host_code_and_matches_the_oracle():
 def test_loading_the_library_leaves_the_environment_alone():
     """Rounds 1-3 set GPU_MAX_HW_QUEUES from a load-time constructor; the library now reads its environment (KZG_DEVICES,
     KZG_OPTIONS) and writes nothing: the host sets GPU_MAX_HW_QUEUES=8 itself, and a constructor that sees
-    fewer says so through kzg_last_error() (GPU test: test_gpu_parity.py::test_constructor_notes_too_few_hardware_queues)."""
+    fewer says so in the handle's note, kzg_settings_note() (GPU test: test_gpu_parity.py::test_constructor_notes_too_few_hardware_queues)."""
     import subprocess
     import sys
     from kzg_rs_amd import api, build

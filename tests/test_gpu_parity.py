@@ -599,7 +599,8 @@ def test_pairing_forms_in_child_process(form):
         "got = api.verify_blob_kzg_proof_batches_device(d_b.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, B, st2)\n"
         "res.append(got == [b not in (3, 17, 39) for b in range(B)])\n"
         "print('RESULT', all(res), len(res))\n" % (O.ROOT, os.path.join(O.ROOT, "tests")))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_OPTIONS="pairing=" + form), capture_output=True, text=True, timeout=900)
+    # (forcing a form is an A/B switch: it exists in the A/B build of the library, the product picks by launch size)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_OPTIONS="pairing=" + form, KZG_LIB_OVERRIDE=api.LIB_AB_PATH), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "RESULT True 16" in out.stdout, out.stdout[-2000:]
 
