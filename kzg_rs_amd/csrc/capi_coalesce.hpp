@@ -208,12 +208,7 @@ static KzgRet small_lane_make(SmallLane& L, const SmallQueue& Q, const KzgSettin
 // lead launches meanwhile - its own request's, or one that only carries older requests.
 static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
     SmallQueue& Q = *s->small;
-    {
-        std::lock_guard<std::mutex> lk(Q.mu);
-        Q.q.push_back(&r);
-        Q.requests++;
-    }
-    Q.arrivals.fetch_add(1, std::memory_order_relaxed);
+    bool queued = false;
     for (;;) {
         const int my_lane = r.lane.load(std::memory_order_acquire);
         std::atomic<uint32_t>& word = my_lane >= 0 ? Q.lanes[my_lane]->word : Q.epoch;  // where this caller sleeps: its launch's lane, or the queue
@@ -221,8 +216,17 @@ static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
         if (r.done.load(std::memory_order_acquire)) break;
         int li = -1;
         std::unique_lock<std::mutex> lk(Q.mu, std::defer_lock);
+        // (ONE visit to the queue's lock for a caller that ends up a follower: it queues its request and looks for a lane in the
+        // same critical section, and once its request has been taken it never touches the lock again - 256 threads on one
+        // mutex, two visits per call, cost more host time than everything else in the call)
         if (!r.taken.load(std::memory_order_relaxed)) {
             lk.lock();
+            if (!queued) {
+                Q.q.push_back(&r);
+                Q.requests++;
+                queued = true;
+                Q.arrivals.fetch_add(1, std::memory_order_relaxed);
+            }
             if (!r.taken.load(std::memory_order_relaxed)) li = small_take_lane(Q);
             if (li < 0) lk.unlock();
         }

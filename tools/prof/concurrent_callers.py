@@ -39,12 +39,24 @@ exp1[6 * 3 + 2] = 0
 raw_blobs = blobs.tobytes()
 out = {"hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "runs": []}
 print("GPU_MAX_HW_QUEUES=%s" % os.environ.get("GPU_MAX_HW_QUEUES"))
+def cpu_stat():
+    out = {}
+    try:
+        for ln in open("/sys/fs/cgroup/cpu.stat"):
+            k, v = ln.split()
+            out[k] = int(v)
+    except Exception:
+        pass
+    return out
+
+
 for lanes in [int(x) for x in args.lanes.split(",")]:
     with api.options(small_lanes=lanes):
         st = api.KzgSettings.from_tau_g2(tau_g2)
     for kind in args.kinds.split(","):
         for T in [int(x) for x in args.threads.split(",")]:
             st.small_queue_stats(reset=True)
+            c0 = cpu_stat()
             if kind == "proof":
                 r = st.concurrent_callers("proof", T, args.seconds, b"".join(cs), b"".join(ps), bytes(exp_p), z=b"".join(zs), y=b"".join(ys))
                 per = 1
@@ -54,12 +66,18 @@ for lanes in [int(x) for x in args.lanes.split(",")]:
             else:
                 r = st.concurrent_callers("blobs", T, args.seconds, b"".join(bc), b"".join(bp), bytes(exp1), blobs=raw_blobs, per_call=1)
                 per = 1
+            c1 = cpu_stat()
+            cores = (c1.get("usage_usec", 0) - c0.get("usage_usec", 0)) / 1e6 / max(r["seconds"], 1e-9)
+            sysc = (c1.get("system_usec", 0) - c0.get("system_usec", 0)) / 1e6 / max(r["seconds"], 1e-9)
+            thr = c1.get("nr_throttled", 0) - c0.get("nr_throttled", 0)
             q = st.small_queue_stats()
+            r.update(host_cores=round(cores, 2), host_cores_system=round(sysc, 2), throttled_periods=thr)
             r.update(kind=kind, threads=T, lanes=lanes, launches=q["launches"], items_per_launch=q["items"] / max(1, q["launches"]), max_items=q["max_items"],
                      items_per_s=r["calls_per_s"] * per)
             out["runs"].append(r)
-            print("lanes %d  %-6s T=%3d: %8.0f calls/s (%8.0f items/s)  mean %6.2f ms  max %6.1f ms  wrong %d   launches %5d  items/launch %6.1f (max %d)" % (
-                lanes, kind, T, r["calls_per_s"], r["items_per_s"], r["mean_ms"], r["max_ms"], r["wrong"], q["launches"], r["items_per_launch"], q["max_items"]), flush=True)
+            print("lanes %d  %-6s T=%3d: %8.0f calls/s (%8.0f items/s)  mean %6.2f ms  max %6.1f ms  wrong %d   launches %5d  items/launch %6.1f (max %d)  host %.1f cores (%.1f system) throttled %d" % (
+                lanes, kind, T, r["calls_per_s"], r["items_per_s"], r["mean_ms"], r["max_ms"], r["wrong"], q["launches"], r["items_per_launch"], q["max_items"],
+                cores, sysc, thr), flush=True)
     st.close()
 if args.json:
     json.dump(out, open(args.json, "w"), indent=1)
