@@ -44,7 +44,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 BYTES_PER_BLOB = 131072
-# algorithmic bytes per unit, per kernel (DESIGN.md 5 / SURVEY.md 8d)
+# algorithmic bytes per unit, per kernel (DESIGN.md 4 / SURVEY.md 8d)
 ALG_BYTES = {
     "k_blob_challenge": BYTES_PER_BLOB + 48 + 32,   # blob + commitment read, z written       (per blob)
     "k_blob_evaluate": BYTES_PER_BLOB + 32 + 32,    # blob + z read, y written                (per blob)
@@ -1000,7 +1000,7 @@ def main():
                                      "(residency: the kernel shares the chip).  cycles_per_inst_standalone = standalone_ms x the measured shader clock x 1 024 SIMDs / "
                                      "SQ_INSTS_VALU (profiles/%s), to hold against issue_ceiling_cycles_per_inst (microbenchmarks: 4.2 for v_mad_u64_u32 / carry-chain "
                                      "code, 3.9 for SHA-256)" % (stamp_cnt, F, pmc_file),
-                     "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 5)"},
+                     "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 4)"},
         "path": {"algorithmic_bytes_per_blob": PATH_ALG_BYTES, "algorithmic_GBps": round(path_gbps, 2), "frac": round(path_gbps / HBM_PEAK_GBS, 6),
                  "hbm_traffic_ratio": path_ratio,
                  "valu_mix_ceiling_cycles_per_inst": round(mix_ceiling, 3) if mix_ceiling else None,

@@ -68,7 +68,7 @@ def build(force=False, verbose=False, variants=(0, 1)):
 # __device_stub__ symbols) must be defined in the cached code object, else the device pass runs again.
 # `--force` (and any cold build) runs every step.
 HOST_ONLY = ("capi_host_util.hpp", "capi_pieces.hpp", "capi_prover.hpp", "capi_settings.hpp", "capi_verify.hpp",
-             "capi_multi.hpp", "capi_coalesce.hpp", "capi_pipeline.hpp", "host_only.hpp", "kzg_capi.hip")
+             "capi_multi.hpp", "capi_coalesce.hpp", "small_queue.hpp", "dyn_lds.hpp", "capi_pipeline.hpp", "host_only.hpp", "kzg_capi.hip")
 LLVM_BIN = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
 
 

@@ -29,9 +29,10 @@
 // z = tau (the pairing's G2 point is the identity: only for who knows the setup's secret, i.e. test rigs) is flagged per item;
 // its owner decides it through the general path under the handle's own lock, as before.
 
-constexpr size_t SMALL_MAX_TUPLES = PROOFS_CHUNK;  // proof tuples per launch
-constexpr size_t SMALL_MAX_BLOBS = 256;            // blobs per launch (= the range of the one-pairing-per-blob form)
+constexpr size_t SMALL_MAX_TUPLES = PROOFS_CHUNK;  // proof tuples per launch (SmallQueue::cap_proofs)
+constexpr size_t SMALL_MAX_BLOBS = 256;            // blobs per launch (= the range of the one-pairing-per-blob form; SmallQueue::cap_blobs)
 
+static_assert(SMALL_MAX_TUPLES == 1024 && SMALL_MAX_BLOBS == 256, "SmallQueue::cap_proofs / cap_blobs (small_queue.hpp) are these");
 static void small_free(KzgSettings* s) {
     if (!s->small) return;
     for (size_t i = 0; i < s->small->n_lanes; i++) {
@@ -141,55 +142,6 @@ static KzgRet small_run_blobs(SmallLane& L, std::vector<SmallReq*>& batch, size_
     return KZG_OK;
 }
 
-// a lane for a new leader: a free one, or a new one while the handle has fewer than max_lanes (the slot is taken under the
-// lock, the lane itself - two streams, a dozen events - is made by the leader outside it); -1: all busy
-static int small_take_lane(SmallQueue& Q) {
-    for (size_t i = 0; i < Q.n_lanes; i++)
-        if (!Q.lanes[i]->busy) {
-            Q.lanes[i]->busy = true;
-            return (int)i;
-        }
-    if (Q.n_lanes < Q.max_lanes && Q.n_lanes < SMALL_LANES_MAX) {
-        SmallLane* L = new SmallLane();
-        L->busy = true;
-        Q.lanes[Q.n_lanes] = L;
-        return (int)Q.n_lanes++;
-    }
-    return -1;
-}
-
-// Waiting and waking.  Every waiter of a handle sleeps on ONE 32-bit word (a futex): a state change - a launch is done, a lane
-// is free - bumps the word and wakes all of them with one system call; a request's `done` flag is read without the lock.  (The
-// first form had a condition variable per request, and a leader woke its 255 followers one system call at a time under the
-// queue's lock: 0.5-1 ms of the 2 ms a launch takes.)
-#include <linux/futex.h>
-#include <sys/syscall.h>
-#include <unistd.h>
-static void small_sleep(std::atomic<uint32_t>& word, uint32_t seen) {
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&word), FUTEX_WAIT_PRIVATE, (unsigned long)seen, nullptr, nullptr, 0UL);
-}
-static void small_wake(std::atomic<uint32_t>& word, int how_many) {
-    word.fetch_add(1, std::memory_order_release);
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t*>(&word), FUTEX_WAKE_PRIVATE, (unsigned long)how_many, nullptr, nullptr, 0UL);
-}
-static void small_wake_all(std::atomic<uint32_t>& word) { small_wake(word, 0x7fffffff); }
-// Everybody asleep on `from` goes to sleep on `to` instead, without waking (FUTEX_CMP_REQUEUE): the callers a leader has just
-// taken into its launch move from the queue's word to the lane's, so that the launch's completion wakes exactly them - with one
-// word for everybody every completion woke the callers of the OTHER launch in flight as well, 256 threads of which half went
-// straight back to sleep (10 host cores at 256 threads; the cgroups of this project's boxes give a job 16).  `from` is bumped
-// first: a caller that was about to sleep on it (it read the old value) does not, and finds its lane on the way round.
-// Returns false when the word moved under us (then the caller wakes everybody instead: they sort themselves out).
-static bool small_requeue_all(std::atomic<uint32_t>& from, std::atomic<uint32_t>& to) {
-    const uint32_t now = from.fetch_add(1, std::memory_order_acq_rel) + 1;
-    // (uaddr, op, nr_wake = 0, nr_requeue in the timeout slot, uaddr2, the value uaddr must still hold)
-    const long rc = syscall(SYS_futex, reinterpret_cast<uint32_t*>(&from), FUTEX_CMP_REQUEUE_PRIVATE, 0UL, (unsigned long)0x7fffffff, reinterpret_cast<uint32_t*>(&to),
-                            (unsigned long)now);
-    return rc >= 0;
-}
-static uint64_t small_now_us() {
-    return (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
 // a new lane of the queue: sized once for the largest launch (1 024 tuples, 256 blobs: ~60 MB of device memory) - a workspace
 // that grows with the launches would free and allocate device memory in the middle of the traffic, and hipFree waits for the
 // whole device (measured: 100-200 ms stalls of every caller while the lanes grew)
@@ -204,97 +156,12 @@ static KzgRet small_lane_make(SmallLane& L, const SmallQueue& Q, const KzgSettin
     return ws_reserve(L.h, SMALL_MAX_BLOBS, 1, STAGE_BLOBS);
 }
 
-// Submit a request and return when it is done (r.rc; the per-item results where the request points).  The calling thread may
-// lead launches meanwhile - its own request's, or one that only carries older requests.
+// Submit a request and return when it is done (small_queue.hpp small_submit_core); the launch a leader runs on its lane:
 static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
     SmallQueue& Q = *s->small;
-    bool queued = false;
-    for (;;) {
-        const int my_lane = r.lane.load(std::memory_order_acquire);
-        std::atomic<uint32_t>& word = my_lane >= 0 ? Q.lanes[my_lane]->word : Q.epoch;  // where this caller sleeps: its launch's lane, or the queue
-        const uint32_t seen = word.load(std::memory_order_acquire);
-        if (r.done.load(std::memory_order_acquire)) break;
-        int li = -1;
-        std::unique_lock<std::mutex> lk(Q.mu, std::defer_lock);
-        // (ONE visit to the queue's lock for a caller that ends up a follower: it queues its request and looks for a lane in the
-        // same critical section, and once its request has been taken it never touches the lock again - 256 threads on one
-        // mutex, two visits per call, cost more host time than everything else in the call)
-        if (!r.taken.load(std::memory_order_relaxed)) {
-            lk.lock();
-            if (!queued) {
-                Q.q.push_back(&r);
-                Q.requests++;
-                queued = true;
-                Q.arrivals.fetch_add(1, std::memory_order_relaxed);
-            }
-            if (!r.taken.load(std::memory_order_relaxed)) li = small_take_lane(Q);
-            if (li < 0) lk.unlock();
-        }
-        if (li < 0) {
-            if (r.hash && r.hash->unclaimed()) hostpool::help(*r.hash);  // nothing to lead: hash the own blobs instead of sleeping
-            else small_sleep(word, seen);
-            continue;
-        }
-        // ---- leader (holds the lock and lane li)
-        SmallLane& L = *Q.lanes[(size_t)li];
-        // The callers of a launch that has just finished come back within ~100 us of each other.  A leader that takes the lane
-        // the moment it is free would leave with the first of them and the rest would wait a whole launch for the next lane;
-        // so while requests keep arriving (no gap of linger_gap_us) it waits, linger_us at most - but only right after a launch
-        // that carried several calls: a handle with one caller at a time never waits.  Measured, 64 threads of verify_kzg_proof:
-        // 6-16 k calls/s without (launches of 6-12), 27 k with a fixed 150 us.
-        if (Q.linger_us > 0 && Q.last_done_items >= 2 && small_now_us() - Q.last_done_us < 400) {
-            lk.unlock();
-            const uint64_t t0 = small_now_us();
-            uint64_t last_change = t0, seen_arrivals = Q.arrivals.load(std::memory_order_relaxed);
-            for (;;) {
-                std::this_thread::yield();
-                const uint64_t now = small_now_us(), a = Q.arrivals.load(std::memory_order_relaxed);
-                if (a != seen_arrivals) {
-                    seen_arrivals = a;
-                    last_change = now;
-                }
-                if (now - last_change >= (uint64_t)Q.linger_gap_us || now - t0 >= (uint64_t)Q.linger_us) break;
-            }
-            lk.lock();
-        }
-        // everything queued of the oldest request's kind, in order, up to the launch's capacity (our own request may have left
-        // with another leader meanwhile: then this launch only carries others)
-        std::vector<SmallReq*> batch;
-        size_t m = 0;
-        SmallReq::Kind kind = SmallReq::PROOFS;
-        if (!Q.q.empty()) {
-            batch.reserve(Q.q.size());  // (nothing below may throw between taking requests off the queue and completing them)
-            kind = Q.q.front()->kind;
-            const size_t cap = kind == SmallReq::PROOFS ? SMALL_MAX_TUPLES : SMALL_MAX_BLOBS;
-            for (auto it = Q.q.begin(); it != Q.q.end();) {
-                SmallReq* x = *it;
-                if (x->kind == kind && m + x->n <= cap) {
-                    x->lane.store(li, std::memory_order_release);
-                    x->taken.store(true, std::memory_order_relaxed);
-                    m += x->n;
-                    batch.push_back(x);
-                    it = Q.q.erase(it);
-                    if (m == cap) break;
-                } else ++it;
-            }
-        }
-        if (batch.empty()) {  // (everything left while this thread lingered)
-            L.busy = false;
-            lk.unlock();
-            continue;
-        }
-        Q.launches++;
-        Q.items += m;
-        Q.max_items = std::max<uint64_t>(Q.max_items, m);
-        const bool more = !Q.q.empty();
-        const size_t shard = (size_t)li % shard_count(s);
-        // the callers of this launch: from the queue's word to the lane's (everybody asleep on the queue's word is in the launch
-        // when the queue is empty now; with requests of the other kind, or beyond the launch's capacity, left in the queue -
-        // another lane may be free for them - everybody is woken and finds its place)
-        if (more || !small_requeue_all(Q.epoch, L.word)) small_wake_all(Q.epoch);
-        lk.unlock();
+    auto run = [&](int li, SmallLane& L, std::vector<SmallReq*>& batch, size_t m, SmallReq::Kind kind, std::string& msg) -> KzgRet {
+        const size_t shard = (size_t)li % shard_count(s);  // the lanes of a multi-device handle are dealt to its devices in turn
         KzgRet rc = KZG_OK;
-        std::string msg;
         const KzgSettings* const home = shard_of(s, shard);
         if (hipSetDevice(home->device) != hipSuccess) {
             (void)hipGetLastError();
@@ -302,9 +169,14 @@ static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
             msg = "HIP: hipSetDevice";
         }
         if (rc == KZG_OK && !L.h) {
-            rc = small_lane_make(L, Q, home);
+            try {
+                rc = small_lane_make(L, Q, home);
+                if (rc != KZG_OK) msg = g_err;
+            } catch (const std::bad_alloc&) {
+                rc = KZG_MALLOC;
+                msg = "host memory of a lane";
+            }
             if (rc != KZG_OK) {
-                msg = g_err;
                 if (L.h) kzg_settings_free(L.h);
                 L.h = nullptr;
             }
@@ -318,28 +190,17 @@ static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
                 msg = "host buffers of the launch";
             }
             if (rc != KZG_OK) proof_drain(L.h);  // nothing of the launch stays in flight behind an error
+            else memcpy(s->timings, L.h->timings, sizeof s->timings);  // kzg_last_timings: the last launch's intervals (last writer wins)
         }
         if (shard != 0) (void)hipSetDevice(s->device);
         // no pool worker may still read a caller's blobs once its call has returned (an error path may not have come by the join)
         for (SmallReq* x : batch)
             if (x->hash) hostpool::finish(*x->hash);
-        lk.lock();
-        if (rc == KZG_OK && L.h) memcpy(s->timings, L.h->timings, sizeof s->timings);  // kzg_last_timings: the last launch's intervals
-        L.busy = false;
-        Q.last_done_us = small_now_us();
-        Q.last_done_items = batch.size();
-        const bool waiting = !Q.q.empty();
-        lk.unlock();
-        for (SmallReq* x : batch) {
-            x->rc = rc;
-            if (rc != KZG_OK) x->msg = msg;
-            x->done.store(true, std::memory_order_release);  // (the owner may return, and its request die, from here on)
-        }
-        small_wake_all(L.word);                // the launch's callers
-        if (waiting) small_wake(Q.epoch, 1);   // the lane is free again: ONE of the callers still in the queue leads (it takes the others along)
-    }
-    if (r.rc != KZG_OK) g_err = r.msg;
-    return r.rc;
+        return rc;
+    };
+    const KzgRet rc = small_submit_core(Q, r, run);
+    if (rc != KZG_OK) g_err = r.msg;
+    return rc;
 }
 
 static bool small_enabled(const KzgSettings* s) {

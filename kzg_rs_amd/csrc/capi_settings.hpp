@@ -57,53 +57,7 @@ struct Workspace {
     size_t h_cap = 0;
 };
 
-// ---------------------------------------------------------------- the small-call queue of a handle (capi_coalesce.hpp)
-// One request = the small call of one host thread: n (commitment, z, y, proof) tuples, or n host blobs with their commitments
-// and proofs; every item gets its own pairing and the request gets its own results - what the entry point makes of them
-// (one verdict, a conjunction, a verdict per item) is the submitter's business.
-struct SmallReq {
-    enum Kind { PROOFS = 0, BLOBS = 1 };
-    Kind kind = PROOFS;
-    size_t n = 0;
-    const uint8_t *c = nullptr, *p = nullptr;  // n x 48 bytes each
-    const uint8_t *z = nullptr, *y = nullptr;  // PROOFS: n x 32 big-endian bytes each
-    const uint8_t* blobs = nullptr;            // BLOBS: n x 131072 bytes
-    hostpool::JobRef hash;                     // BLOBS: the challenges (the submitter's buffer behind hash->z_le), claimed blob by blob by whoever has time
-    // results.  PROOFS: per item.  BLOBS: [0] only - the conjunction over the request's blobs, any parse failure among them, any z = tau
-    bool* ok = nullptr;
-    uint8_t *err = nullptr, *general = nullptr;
-    KzgRet rc = KZG_OK;  // a failure of the launch that carried the request (every request of that launch gets it)
-    std::string msg;
-    std::atomic<bool> taken{false}, done{false};  // taken: written under the queue's lock; done: the leader's LAST access to the request
-    std::atomic<int> lane{-1};                    // the lane whose launch carries the request (its owner then sleeps on that lane's word)
-};
-constexpr size_t SMALL_LANES_MAX = 16;
-struct SmallLane {
-    KzgSettings* h = nullptr;  // a private lane (settings_lane) on one device of the handle
-    bool busy = false;
-    std::atomic<uint32_t> word{0};  // the futex word the callers of this lane's launch sleep on
-    std::vector<uint8_t> c, z, y, p, okerr;  // the gathered tuples of a launch
-};
-struct SmallQueue {
-    std::mutex mu;
-    std::deque<SmallReq*> q;        // waiting requests, oldest first
-    SmallLane* lanes[SMALL_LANES_MAX] = {};  // made on demand, up to max_lanes (a slot, once set, never changes: read without the lock by who knows its index)
-    size_t n_lanes = 0;
-    size_t max_lanes = 2;
-    bool lane_two_streams = false;  // option small_streams=2: chain C of the one-proof path behind chain B, two streams per lane (A/B measurement)
-    // The lanes' streams are made at the device's highest priority (option small_priority=0: normal).  Not for the priority
-    // itself: the HIP runtime keeps a separate pool of hardware queues per priority, so the lanes' streams do not share queues
-    // with each other's or with the launch-group pipeline's normal-priority streams.  Streams that share a hardware queue run
-    // one behind the other: with normal-priority lanes and GPU_MAX_HW_QUEUES=8, two threads calling verify_kzg_proof at once
-    // took 2.9 ms each instead of 1.7 (1.84 with 16 queues, 1.75 with priority lanes: profiles/r5_small_call_queues.txt).
-    int lane_priority = 1;
-    long linger_us = 250, linger_gap_us = 40;  // options small_linger_us / small_linger_gap_us (capi_coalesce.hpp small_submit); 0: never wait
-    std::atomic<uint32_t> epoch{0};    // the futex word the callers whose request is still in the queue sleep on
-    std::atomic<uint64_t> arrivals{0};
-    uint64_t last_done_us = 0;         // when the last launch finished, and how many calls it carried
-    size_t last_done_items = 0;
-    uint64_t launches = 0, requests = 0, items = 0, max_items = 0;  // since the last kzg_debug_small_queue_stats(reset)
-};
+#include "small_queue.hpp"
 
 struct KzgSettings {
     int device = 0;

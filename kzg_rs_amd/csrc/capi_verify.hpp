@@ -1479,7 +1479,7 @@ extern "C" KzgRet kzg_verify_kzg_proofs(bool* ok_out, uint8_t* err_out, const ui
 }
 
 extern "C" KzgRet kzg_verify_kzg_proof(bool* ok, const uint8_t commitment[48], const uint8_t z[32], const uint8_t y[32],
-                                       const uint8_t proof[48], const KzgSettings* s) {
+                                       const uint8_t proof[48], const KzgSettings* s) try {
     // src/kzg_proof.rs:353-397.  One proof at a time takes the reference's own equation (proof_single_locked); option
     // proof_path=msm sends it through the batch form with the single scalar r^0 = 1 instead (round 3's path; A/B, cross-check):
     // e(pi, [tau]G2) == e(C - [y]G + [z]pi, G2)  <=>  e(pi, [tau - z]G2) == e(C - [y]G, G2)
@@ -1509,6 +1509,8 @@ extern "C" KzgRet kzg_verify_kzg_proof(bool* ok, const uint8_t commitment[48], c
         if (!general) return KZG_OK;
     }
     return kzg_verify_kzg_proof_batch(ok, commitment, z, y, proof, 1, s);
+} catch (const std::bad_alloc&) {
+    return fail(KZG_MALLOC, "host buffers of the call");  // (the queue's request list; nothing is thrown across the C ABI)
 }
 
 // KzgProof::verify_kzg_proof_batch (src/kzg_proof.rs:399-444) over byte inputs: n (commitment, z, y, proof) tuples checked

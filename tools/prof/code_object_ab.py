@@ -1,7 +1,7 @@
 """Product library (default kernel forms only) against the A/B build (the same + the alternative forms): what stripping the
 variants from the shipped code object changes.  Each library in a child process:
   - size of the .so and of its gfx950 code object
-  - verify_kzg_proof (one proof at a time): 96 calls, min / median / max / spread (a lone wavefront's time
+  - verify_kzg_proof (one proof at a time): 96 calls, min / median / max / spread (docs/lab_notebook.md 9: a lone wavefront's time
     depends on where the dispatcher put it; both paths: default and KZG_OPTIONS=proof_path=msm, round 3's)
   - one verify_blob_kzg_proof_batch of 1 024 device-resident blobs: 32 calls, min / median / max
     python3 tools/prof/code_object_ab.py            (through gpurun, from the repo root)"""
