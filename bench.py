@@ -629,12 +629,15 @@ def main():
         run_groups(W)
     K = args.steps
     warm_sum5, warm_cnt = 0.0, 0
+    other_stamps, other_stamp_cnt = {}, 0   # in-kernel stamps of the launch groups OUTSIDE the timed region: warm-up, stand-alone, self-check
     for h in handles:
         t, c = h.timing_totals(reset=True)  # the warm-up groups do not count (kept apart for the profiler cross-check below)
         warm_sum5 += t[5]
         warm_cnt += c
         h.shader_clock(reset=True)
-        h.kernel_stamp_totals(reset=True)
+        ws, wc, _ = h.kernel_stamp_totals(reset=True)
+        other_stamps = {k: other_stamps.get(k, 0.0) + v for k, v in ws.items()}
+        other_stamp_cnt += wc
     elapsed, _ = timed(lambda: run_groups(K))
     clk_cycles = clk_ticks = 0.0
     for h in handles:  # the clock the SIMDs ran at during the timed region (every wave of the challenge kernel stamps it)
@@ -745,7 +748,9 @@ def main():
             torch.cuda.synchronize()
             solo_res = api.verify_blob_kzg_proof_batches_device(v[0].data_ptr(), v[1].data_ptr(), v[2].data_ptr(), n, G, solo)
         st_tm = solo.last_timings()
-        solo_stamps = solo.kernel_stamp_totals()[2]   # the same group's in-kernel stamps (ms)
+        ss, sc_, solo_stamps = solo.kernel_stamp_totals()   # the in-kernel stamps (ms) of the handle's groups, and of its last one
+        other_stamps = {k: other_stamps.get(k, 0.0) + v for k, v in ss.items()}
+        other_stamp_cnt += sc_
         standalone = {"k_blob_challenge": st_tm[5], "k_blob_evaluate": st_tm[4], "k_g1_decode_multiples": st_tm[6], "k_msm": st_tm[2],
                       "k_slp_run(pairing)": st_tm[3], "whole_group": st_tm[0]}
         if not all(r is True for r in solo_res):
@@ -786,6 +791,7 @@ def main():
         torch.cuda.synchronize()
         for h in handles:  # (the single-batch legs above ran on this handle too: only the control's launches are counted below)
             h.timing_totals(reset=True)
+            h.kernel_stamp_totals(reset=True)
         res = api.verify_blob_kzg_proof_batch_groups_device([tuple(t.data_ptr() for t in variants[vi]) for vi in order], n, G, settings, in_flight=F)
         for t, i, old in saved:
             t[i] = old
@@ -807,6 +813,9 @@ def main():
             t, c = h.timing_totals(reset=True)
             sc_sums = [a + b for a, b in zip(sc_sums, t)]
             sc_cnt += c
+            ks, kc, _ = h.kernel_stamp_totals(reset=True)
+            other_stamps = {k: other_stamps.get(k, 0.0) + v for k, v in ks.items()}
+            other_stamp_cnt += kc
         if world == 1:
             # one proof at a time (src/kzg_proof.rs:353-397, the revm precompile's call): median of 32 calls
             pc, pz, py, pp, _ = synth.make_valid_proofs(1, seed=5, settings=settings)
@@ -930,8 +939,13 @@ def main():
         pk = prof.get(PMCN[kname], {})
         insts = pk.get("SQ_INSTS_VALU")
         scale = units / pmc["blobs_per_launch"] if pmc else 1.0
+        n_all = stamp_cnt + other_stamp_cnt
+        all_ms = (stamp_sum.get(kname, 0.0) + other_stamps.get(kname, 0.0)) / n_all if n_all else None
         row = {"kernel": kname, "units_per_launch": units, "algorithmic_bytes_per_launch": ALG[kname] * units,
                "standalone_ms": round(sa, 4) if sa else None, "in_flight_ms": round(fl, 4) if fl else None,
+               # every launch of this size in the process (warm-up, timed, stand-alone and self-check groups): the population behind the
+               # kernel's launches of this grid in a rocprofv3 kernel trace of this command (profiles/<round>_kernel_trace_by_grid.json)
+               "all_launches_ms": round(all_ms, 4) if all_ms else None, "launches": n_all,
                "achieved_standalone_GBps": round(ALG[kname] * units / sa / 1e6, 2) if sa else None,
                "frac_standalone": round(ALG[kname] * units / sa / 1e6 / HBM_PEAK_GBS, 6) if sa else None,
                "achieved_in_flight_GBps": round(ALG[kname] * units / fl / 1e6, 2) if fl else None,
@@ -945,6 +959,21 @@ def main():
             mix_num += insts * CEIL[kname]
             mix_den += insts
         kernel_rows.append(row)
+    for kname, pname, sa_ms in (("k_msm_reduce", "kzg::k_msm_reduce<false>", None), ("k_slp_run(pairing)", PMC_NAME["k_slp_run(pairing)"], (standalone or {}).get("k_slp_run(pairing)"))):
+        pk = prof.get(pname, {})
+        scale = units / pmc["blobs_per_launch"] if pmc else 1.0
+        ms = sa_ms or pk.get("ms_single_stream")
+        insts = pk.get("SQ_INSTS_VALU")
+        kernel_rows.append({"kernel": kname, "units_per_launch": units, "algorithmic_bytes_per_launch": 0, "standalone_ms": round(ms, 4) if ms else None,
+                            "standalone_ms_source": "HIP events on a single-stream handle, this run" if sa_ms else "kernel-trace duration in profiles/%s (not stamped)" % pmc_file,
+                            "in_flight_ms": None, "valu_wave_insts_per_launch": round(insts * scale) if insts else None,
+                            "cycles_per_inst_standalone": round(ms * 1e-3 * clock_hz * 1024 / (insts * scale), 3) if ms and insts else None,
+                            "issue_ceiling_cycles_per_inst": 4.2,
+                            "note": "reads the bucket sums k_msm_window wrote (no input bytes of its own): latency chain of ~28 point additions per window slot"
+                            if kname == "k_msm_reduce" else "one wavefront per pairing instance, LDS-resident straight-line program: dependency-depth bound"})
+        if insts:
+            mix_num += insts * 4.2
+            mix_den += insts
     mix_ceiling = mix_num / mix_den if mix_den else None
     path_gbps = PATH_ALG_BYTES * n * G * K / elapsed / 1e9   # per GPU
     out = {
@@ -1023,6 +1052,20 @@ def main():
         "concurrent_callers": concurrent,
         "configs": configs,
     }
+    if configs:   # cycles per VALU instruction of the two config kernels: this run's time x the measured clock / the instruction counts of the committed PMC profile
+        try:
+            cp = json.load(open(os.path.join(ROOT, "profiles", "r5_config_pmc.json")))["kernels"]
+            for leg, kn, ms_key in (("config3", "kzg::k_blob_evaluate_t<true>", "ms"), ("config4", "kzg::k_msm_window<kzg::Curve29Aff, true>", None)):
+                insts = cp[kn]["SQ_INSTS_VALU"]
+                ms = configs[leg]["ms"] if ms_key else cp[kn]["ms_single_stream"]
+                configs[leg]["roofline"].update({
+                    "valu_wave_insts": round(insts), "valu_cycles_per_inst": round(ms * 1e-3 * clock_hz * 1024 / insts, 3), "issue_ceiling_cycles_per_inst": 4.2,
+                    "valu_source": "profiles/r5_config_pmc.json SQ_INSTS_VALU of the same launch size; %s; shader clock %s" % (
+                        "this run's ms" if ms_key else "the window kernel's own duration in that profile (%.2f ms: ms_msm above also holds split, reduction, folds, combine)" % ms,
+                        "%.0f MHz measured in this run's timed region" % shader_mhz if shader_mhz else "2 400 MHz nominal"),
+                    "hbm_traffic_bytes": cp[kn].get("hbm_bytes_corrected"), "sq_wait_any_frac": round(cp[kn]["SQ_WAIT_ANY"] / cp[kn]["SQ_WAVE_CYCLES"], 3)})
+        except Exception:
+            pass
     if world > 1:
         g = max(pipe.stats["groups"], 1)  # warm-up groups included; per-step averages of THIS rank's host time
         out["multi_gpu"] = {"ranks": world, "backend": backend_name, "rccl_ranks": world if backend_name == "nccl" else 0,

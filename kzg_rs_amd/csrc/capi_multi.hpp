@@ -666,6 +666,8 @@ static KzgRet multi_exchange_selftest(KzgSettings* s, bool& equal, std::string& 
     m->exchange = saved_exchange;
     (void)hipSetDevice(s->device);
     if (rc != KZG_OK) return rc;
+    // (A/B build only, for the test of the rejection path: one bit of what ncclAllGather delivered is flipped)
+    if (ab_int("multi_selftest_corrupt", 0) && cap[0][1].size() > 5) cap[0][1][5] ^= 1;
     const bool same0 = cap[0][0] == cap[0][1] && !cap[0][0].empty(), same1 = cap[1][0] == cap[1][1] && !cap[1][0].empty();
     bool nontrivial = false;
     for (uint8_t b : cap[0][0]) nontrivial |= b != 0;

@@ -196,6 +196,39 @@ def test_in_process_rccl_exchange_world_of_one():
     assert r.returncode == 0 and "rccl-exchange-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+_REJECT_CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+import golden_data as G
+from kzg_rs_amd import api
+st = api.KzgSettings.load_trusted_setup_file(devices=[0])
+devs, ex = st.devices()
+print("NOTE", st.note())
+assert ex == "host" and "DIFFER" in st.note() and "RCCL REJECTED" in st.note(), (ex, st.note())
+blobs, cs, ps = [list(x) for x in zip(*G.valid_blob_tuples())]
+assert api.KzgProof.verify_blob_kzg_proof_batch([api.Blob(b) for b in blobs], [api.Bytes48(c) for c in cs], [api.Bytes48(x) for x in ps], st) is True
+st.close()
+try:
+    with api.options(multi_exchange="rccl"):
+        api.KzgSettings.load_trusted_setup_file(devices=[0])
+    print("constructed")
+except api.KzgError as e:
+    print("REFUSED", e.kind, "RCCL REJECTED" in e.msg)
+"""
+
+
+def test_exchange_self_test_rejects_a_collective_that_delivers_other_bytes():
+    """The rejection path of the exchange self-test: with one bit of the all-gathered buffer flipped (KZG_OPTIONS
+    multi_selftest_corrupt=1, a hook of the A/B build) the handle says so - on stderr and in its note - and carries its partial
+    sums through host memory, verifying correctly; with multi_exchange=rccl forced the same handle does not construct."""
+    from kzg_rs_amd import api
+    e = dict(os.environ, KZG_OPTIONS="multi_force=1;multi_min_blobs=2;multi_min_chunk=2;multi_selftest_blobs=16;multi_selftest_corrupt=1",
+             KZG_LIB_OVERRIDE=api.LIB_AB_PATH)
+    r = subprocess.run([sys.executable, "-c", _REJECT_CHILD % {"root": ROOT, "here": HERE}], env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "REFUSED InternalError True" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "kzg_rs_amd: exchange self-test" in r.stderr and "pinned host memory" in r.stderr, r.stderr[-2000:]
+
+
 def test_env_selected_devices_for_an_unchanged_caller():
     """KZG_DEVICES in the environment turns the reference-shaped constructor's handle into a multi-device one."""
     code = (

@@ -452,6 +452,35 @@ def test_g1_msm(settings, n):
     assert got == O.g1_msm(b"".join(pts), b"".join(sc), n)
 
 
+@pytest.mark.parametrize("n", [3071, 6144, 6145, 12289, 24577, 196609, 393216, 400001])
+def test_g1_msm_slice_boundaries(settings, n):
+    """kzg_g1_msm deals its terms to the window kernel's two outputs in slices of at most 3 072 terms and folds the slices' window
+    sums by trees of 64 (csrc/capi_pieces.hpp): sizes on either side of every boundary of that shape - one slice per output (6 144),
+    the first sliced size (6 145: 4 slices of 769 / 768), a slice count that is not a power of two, the first size with two fold
+    levels (196 609: 72 window-sum layers padded to 128), exactly two full groups of 64 (393 216) and a ragged one above it.
+    Points: 257 distinct multiples of the generator tiled over the terms (one of them the identity, one pair repeated), random
+    scalars up to 2^255; by linearity the sum equals the oracle's 257-term MSM over each point's scalars summed mod r."""
+    import ctypes as C
+    import numpy as np
+    D = 257
+    rng = random.Random(7000 + n)
+    base = _gen_multiples([rng.randrange(1, R) for _ in range(D)])
+    base[5] = G1_INF
+    base[9] = base[8]
+    sc = np.random.Generator(np.random.PCG64(n)).integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc[:, 0] &= 0x7F
+    sc[n // 2] = 0                       # a zero scalar in the middle
+    sc[n - 1] = np.frombuffer((R - 1).to_bytes(32, "big"), dtype=np.uint8)
+    pts = (b"".join(base) * (n // D + 1))[: 48 * n]
+    out = C.create_string_buffer(48)
+    api._chk(api.lib().kzg_g1_msm(out, pts, sc.ctypes.data_as(C.c_char_p), n, settings._h))
+    sums = [0] * D
+    for i in range(n):
+        sums[i % D] += int.from_bytes(sc[i].tobytes(), "big")
+    want = O.g1_msm(b"".join(base), b"".join((v % R).to_bytes(32, "big") for v in sums), D)
+    assert out.raw == want
+
+
 def test_g1_msm_cancellation(settings):
     """s*P + (r - s)*P = O and all-equal digits: bucket collisions, P + (-P), identity result."""
     rng = random.Random(5)

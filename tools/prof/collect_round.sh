@@ -16,6 +16,8 @@ rm -rf gpurun_out/${tag}_stats; mkdir -p gpurun_out/${tag}_stats
 # duration in the line and its AverageNs in the stats then describe the same run
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_stats -o run --output-format csv -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_stats.log 2>&1
 grep '^{' gpurun_out/${tag}_stats.log | tail -1 > gpurun_out/${tag}_bench_profiled.json
+# the same trace split by launch size: --stats averages a kernel over launches of every size the process makes
+python3 tools/prof/trace_by_grid.py gpurun_out/${tag}_stats/run_kernel_trace.csv > gpurun_out/${tag}_kernel_trace_by_grid.json
 i=0
 # SKIP_PMC=1: only the stats pass and the unprofiled line (the PMC json under profiles/ already describes this code)
 [ "${SKIP_PMC:-0}" = "1" ] || for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS"; do
