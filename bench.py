@@ -1088,18 +1088,17 @@ def main():
 
 
 def run_single_process_child(devices, n, timeout=300):
-    """The one-process leg in child processes (a failure or a hang there costs that leg, not the line): with the exchange the
-    handle's own self-test selects (csrc/capi_multi.hpp multi_exchange_selftest: host memory vs ncclAllGather compared bit for
-    bit at construction; `exchange` and `exchange_note` of the leg say which one won and why), then with each exchange forced
-    (KZG_OPTIONS multi_exchange=host | rccl) - on a list of distinct devices the RCCL one is the north star's collective over xGMI."""
+    """The one-process leg in child processes (a failure or a hang there costs that leg, not the line): first with the exchange
+    the handle's own self-test selects (csrc/capi_multi.hpp multi_exchange_selftest: host memory vs ncclAllGather compared bit for
+    bit at construction; `exchange` and `exchange_note` of the leg say which one won and why), then with the OTHER exchange
+    forced (KZG_OPTIONS multi_exchange=host | rccl) - on a list of distinct devices the RCCL one is the north star's collective
+    over xGMI."""
     import subprocess
     out = {}
-    for name, opts in (("selected_exchange", None), ("host_exchange", "multi_exchange=host"), ("rccl_exchange", "multi_exchange=rccl")):
+    distinct = len(set(devices.split(","))) == len(devices.split(","))
+
+    def child(opts):
         env = dict(os.environ)
-        if opts and opts.endswith("rccl"):
-            if len(set(devices.split(","))) != len(devices.split(",")):
-                out[name] = {"skipped": "the device list names a device twice: ncclCommInitAll needs distinct devices"}
-                continue
         if opts:
             env["KZG_OPTIONS"] = ";".join(x for x in (env.get("KZG_OPTIONS"), opts) if x)
         try:
@@ -1107,12 +1106,19 @@ def run_single_process_child(devices, n, timeout=300):
                                capture_output=True, text=True, timeout=timeout, env=env)
             for line in reversed(r.stdout.strip().splitlines()):
                 if line.startswith("{"):
-                    out[name] = json.loads(line)
-                    break
-            else:
-                out[name] = {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-600:])}
+                    return json.loads(line)
+            return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-600:])}
         except Exception as e:  # timeout included
-            out[name] = {"error": repr(e)[:600]}
+            return {"error": repr(e)[:600]}
+
+    out["selected_exchange"] = child(None)
+    picked = out["selected_exchange"].get("exchange")
+    if picked == "rccl":
+        out["host_exchange"] = child("multi_exchange=host")
+        out["rccl_exchange"] = {"same_as": "selected_exchange"}
+    else:
+        out["host_exchange"] = {"same_as": "selected_exchange"} if picked == "host" else child("multi_exchange=host")
+        out["rccl_exchange"] = child("multi_exchange=rccl") if distinct else {"skipped": "the device list names a device twice: ncclCommInitAll needs distinct devices"}
     return out
 
 

@@ -178,7 +178,8 @@ def test_bench_script_bare_command_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["multi_gpu"]["ranks"] == 2
     assert d["self_check"]["passed"] is True
-    sp = d["multi_gpu"]["single_process"]["host_exchange"]
+    sp = d["multi_gpu"]["single_process"]["selected_exchange"]  # (the shared-GPU rig names device 0 twice: host memory is what the self-test can select)
+    assert d["multi_gpu"]["single_process"]["host_exchange"] == {"same_as": "selected_exchange"}
     assert sp["batch"] == 512 and sp["devices"] == [0, 0] and sp["exchange"] == "host", sp
     assert sp["sharded_batch"]["ok"] is True and sp["sharded_batch"]["corrupted_proof_on_last_device"] is False, sp
     assert sp["sharded_stream"]["results_as_expected"] is True and sp["sharded_stream"]["in_flight"] == 4, sp
