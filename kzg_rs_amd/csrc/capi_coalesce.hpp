@@ -199,7 +199,7 @@ static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
         return rc;
     };
     const KzgRet rc = small_submit_core(Q, r, run);
-    if (rc != KZG_OK) g_err = r.msg;
+    if (rc != KZG_OK) g_err = r.msg;  // (thread-local: the message of the launch that carried this caller's request)
     return rc;
 }
 

@@ -5,6 +5,8 @@
 #pragma once
 #include <linux/futex.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <string.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -35,7 +37,7 @@ struct SmallReq {
     bool* ok = nullptr;
     uint8_t *err = nullptr, *general = nullptr;
     KzgRet rc = KZG_OK;  // a failure of the launch that carried the request (every request of that launch gets it)
-    std::string msg;
+    char msg[192] = {0};  // (a fixed buffer: completing a request must not allocate - a leader that threw half-way through would leave callers asleep)
     std::atomic<bool> taken{false}, done{false};  // taken: written under the queue's lock; done: the leader's LAST access to the request
     std::atomic<int> lane{-1};                    // the lane whose launch carries the request (its owner then sleeps on that lane's word)
 };
@@ -107,7 +109,8 @@ static int small_take_lane(SmallQueue& Q) {
             return (int)i;
         }
     if (Q.n_lanes < Q.max_lanes && Q.n_lanes < SMALL_LANES_MAX) {
-        SmallLane* L = new SmallLane();
+        SmallLane* L = new (std::nothrow) SmallLane();  // (no memory for a lane: as if every lane were busy)
+        if (!L) return -1;
         L->busy = true;
         Q.lanes[Q.n_lanes] = L;
         return (int)Q.n_lanes++;
@@ -192,7 +195,7 @@ static KzgRet small_submit_core(SmallQueue& Q, SmallReq& r, Run&& run) {
                 small_wake(Q.epoch, 1);
                 if (!was_taken) {
                     r.rc = KZG_MALLOC;
-                    r.msg = "host buffers of the launch";
+                    snprintf(r.msg, sizeof r.msg, "%s", "host buffers of the launch");
                     return r.rc;
                 }
                 continue;  // (another leader carries our request: wait for it)
@@ -226,12 +229,14 @@ static KzgRet small_submit_core(SmallQueue& Q, SmallReq& r, Run&& run) {
         if (more || !small_requeue_all(Q.epoch, L.word)) small_wake_all(Q.epoch);
         lk.unlock();
         KzgRet rc = KZG_OK;
-        std::string msg;
+        char msg_buf[sizeof r.msg] = {0};
         try {
+            std::string msg;
             rc = run(li, L, batch, m, kind, msg);
-        } catch (const std::bad_alloc&) {
+            snprintf(msg_buf, sizeof msg_buf, "%s", msg.c_str());
+        } catch (...) {  // (whatever the launch threw: its callers are completed, with an error)
             rc = KZG_MALLOC;
-            msg = "host buffers of the launch";
+            snprintf(msg_buf, sizeof msg_buf, "%s", "host buffers of the launch");
         }
         lk.lock();
         L.busy = false;
@@ -241,7 +246,7 @@ static KzgRet small_submit_core(SmallQueue& Q, SmallReq& r, Run&& run) {
         lk.unlock();
         for (SmallReq* x : batch) {
             x->rc = rc;
-            if (rc != KZG_OK) x->msg = msg;
+            if (rc != KZG_OK) memcpy(x->msg, msg_buf, sizeof x->msg);
             x->done.store(true, std::memory_order_release);  // (the owner may return, and its request die, from here on)
         }
         small_wake_all(L.word);                // the launch's callers

@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
             const KzgRet rc = small_submit_core(Q, r, run);
             if (blobs) hostpool::finish(*r.hash);
             if (rc != KZG_OK) {
-                CHECK(rc == KZG_ERROR && r.msg == "injected failure");
+                CHECK(rc == KZG_ERROR && strcmp(r.msg, "injected failure") == 0);
                 error_calls++;
             } else if (blobs) {
                 uint8_t acc = 0;
