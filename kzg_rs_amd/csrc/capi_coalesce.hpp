@@ -249,7 +249,7 @@ extern "C" KzgRet kzg_debug_small_queue_stats(const KzgSettings* s, uint64_t out
     if (!s || !out) return fail(KZG_BADARGS, "null argument");
     memset(out, 0, 5 * sizeof(uint64_t));
     if (!s->small) return KZG_OK;
-    std::lock_guard<std::mutex> lk(s->small->mu);
+    std::lock_guard<SmallSpinLock> lk(s->small->mu);
     out[0] = s->small->launches;
     out[1] = s->small->requests;
     out[2] = s->small->items;

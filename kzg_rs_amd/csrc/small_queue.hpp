@@ -48,8 +48,29 @@ struct SmallLane {
     std::atomic<uint32_t> word{0};  // the futex word the callers of this lane's launch sleep on
     std::vector<uint8_t> c, z, y, p, okerr;  // the gathered tuples of a launch
 };
+// The queue's lock: held for a push, a look at the lanes, the taking of a batch - tens of nanoseconds to a few microseconds - by up
+// to hundreds of threads that arrive within ~100 us of each other when a launch completes.  A pthread mutex sends every
+// contended acquirer through futex_wait / futex_wake (a context switch each); this one spins on the flag (test-and-test-and-set,
+// `pause`), yields the core after a while, and never sleeps in the kernel.  Lockable: works with std::unique_lock / lock_guard.
+struct SmallSpinLock {
+    std::atomic<bool> held{false};
+    void lock() {
+        for (unsigned spins = 0;; spins++) {
+            if (!held.load(std::memory_order_relaxed) && !held.exchange(true, std::memory_order_acquire)) return;
+            if (spins < 256) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            } else {
+                std::this_thread::yield();
+            }
+        }
+    }
+    bool try_lock() { return !held.load(std::memory_order_relaxed) && !held.exchange(true, std::memory_order_acquire); }
+    void unlock() { held.store(false, std::memory_order_release); }
+};
 struct SmallQueue {
-    std::mutex mu;
+    SmallSpinLock mu;
     std::deque<SmallReq*> q;        // waiting requests, oldest first
     SmallLane* lanes[SMALL_LANES_MAX] = {};  // made on demand, up to max_lanes (a slot, once set, never changes: read without the lock by who knows its index)
     size_t n_lanes = 0;
@@ -133,7 +154,7 @@ static KzgRet small_submit_core(SmallQueue& Q, SmallReq& r, Run&& run) {
         const uint32_t seen = word.load(std::memory_order_acquire);
         if (r.done.load(std::memory_order_acquire)) break;
         int li = -1;
-        std::unique_lock<std::mutex> lk(Q.mu, std::defer_lock);
+        std::unique_lock<SmallSpinLock> lk(Q.mu, std::defer_lock);
         // (ONE visit to the queue's lock for a caller that ends up a follower: it queues its request and looks for a lane in the
         // same critical section, and once its request has been taken it never touches the lock again - 256 threads on one
         // mutex, two visits per call, cost more host time than everything else in the call)
@@ -226,8 +247,8 @@ static KzgRet small_submit_core(SmallQueue& Q, SmallReq& r, Run&& run) {
         // the callers of this launch: from the queue's word to the lane's (everybody asleep on the queue's word is in the launch
         // when the queue is empty now; with requests of the other kind, or beyond the launch's capacity, left in the queue -
         // another lane may be free for them - everybody is woken and finds its place)
-        if (more || !small_requeue_all(Q.epoch, L.word)) small_wake_all(Q.epoch);
         lk.unlock();
+        if (more || !small_requeue_all(Q.epoch, L.word)) small_wake_all(Q.epoch);  // (outside the lock: moving 200 sleepers takes the kernel a while)
         KzgRet rc = KZG_OK;
         char msg_buf[sizeof r.msg] = {0};
         try {
