@@ -354,6 +354,45 @@ def _group_tensors(torch, blobs, cs, ps, lo, hi):
     return d_b, d_c, d_p
 
 
+def test_small_calls_of_many_threads_spread_over_the_devices_of_the_handle(env):
+    """The small-call queue of a MULTI-device handle (csrc/capi_coalesce.hpp: 2 lanes per device, lane i on shard i mod D): 24
+    threads of verify_kzg_proof and of 6-blob verify_blob_kzg_proof_batch calls on the handle over [0, 0, 0] - six lanes, two on
+    every logical shard - through the in-library harness that checks every answer; the mainnet vectors as the inputs, true and
+    false and Err cases among them."""
+    api, O, G = env["api"], env["O"], env["G"]
+    ost = env["ost"]
+    st3 = api.KzgSettings.load_trusted_setup_file(devices=[0, 0, 0])   # (default options: batches below 256 blobs are small calls, not sharded ones)
+
+    def well_sized(c):
+        try:
+            return all(len(bytes.fromhex(c[k])) == w for k, w in (("commitment", 48), ("z", 32), ("y", 32), ("proof", 48)))
+        except ValueError:
+            return False
+
+    cases = [c for c in G.vectors()["verify_kzg_proof"] if well_sized(c)]   # 114 of the 122 vectors (the others fail from_slice in the caller)
+    want = [c["output"] for c in cases]
+    assert want.count(True) >= 5 and want.count(False) >= 5 and want.count(None) >= 5
+    exp = bytes(2 if w is None else int(w) for w in want)
+    c_, z_, y_, p_ = (b"".join(bytes.fromhex(c[k]) for c in cases) for k in ("commitment", "z", "y", "proof"))
+    st3.small_queue_stats(reset=True)
+    r = st3.concurrent_callers("proof", 24, 1.5, c_, p_, exp, z=z_, y=y_)
+    q = st3.small_queue_stats()
+    assert r["wrong"] == 0 and r["calls"] > 500, r
+    assert 3 <= q["lanes"] <= 6 and q["launches"] < q["requests"], q   # lanes on more than one shard; calls shared launches
+    tuples = G.valid_blob_tuples()
+    blobs = b"".join(t[0] for t in tuples[:6]) * 2
+    cs = b"".join(t[1] for t in tuples[:6]) * 2
+    ps = bytearray(b"".join(t[2] for t in tuples[:6]) * 2)
+    ps[48 * 8: 48 * 9] = tuples[1][2] if tuples[1][2] != tuples[2][2] else tuples[3][2]   # call 1: blob 2 gets another blob's proof
+    wantb = [O.verify_blob_kzg_proof_batch([blobs[131072 * i: 131072 * (i + 1)] for i in range(6 * k, 6 * k + 6)],
+                                           [cs[48 * i: 48 * i + 48] for i in range(6 * k, 6 * k + 6)],
+                                           [bytes(ps[48 * i: 48 * i + 48]) for i in range(6 * k, 6 * k + 6)], ost) for k in range(2)]
+    assert wantb == [True, False]
+    rb = st3.concurrent_callers("blobs", 12, 1.5, cs, bytes(ps), bytes(int(w) for w in wantb), blobs=blobs, per_call=6)
+    assert rb["wrong"] == 0 and rb["calls"] > 100, rb
+    st3.close()
+
+
 def test_launch_groups_routed_to_the_devices_of_the_handle(env):
     """kzg_verify_blob_kzg_proof_batch_groups_device and _batches_device on a handle over [0, 0, 0]: every launch group goes
     to a shard on the device that owns its memory (here: the three logical shards in turn - 7 groups = 3 + 2 + 2, an uneven
