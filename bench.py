@@ -306,9 +306,8 @@ def config_legs(settings, torch, dev, no_cpu=False):
     t4 = sorted(ms4[1:])[len(ms4[1:]) // 2]
     d4 = sorted(dec4[1:])[len(dec4[1:]) // 2]
     hterms = (n4 + 1) // 2
-    S = 1
-    while (hterms + S - 1) // S > 2048:
-        S *= 2
+    S = (hterms + 3071) // 3072               # csrc/capi_pieces.hpp kzg_g1_msm: slices of at most 3 072 terms, their number a multiple of 4
+    S = 1 if S <= 1 else (S + 3) & ~3
     out["config4"] = {"workload": "G1 msm_variable_base, 2^20 trusted-setup points (4 096 Lagrange points x 256) x random Fr scalars (BASELINE.json configs[3])",
                       "entry_point": "kzg_g1_msm", "pairs": n4, "ms_msm": round(t4, 4), "ms_decode_and_tables": round(d4, 4), "ms_msm_all_runs": [round(x, 4) for x in ms4],
                       "ms_call_wall": round(sorted(wall4[1:])[1], 3), "pairs_per_s": round(n4 / t4 * 1e3, 1), "ns_per_term": round(t4 * 1e6 / n4, 3),
@@ -318,7 +317,8 @@ def config_legs(settings, torch, dev, no_cpu=False):
                       "buckets_in_lds": "the sorted (bucket -> table entry) lists: 4 x %d entries = %.1f KB per workgroup; the 256 bucket accumulators of a workgroup "
                                         "are registers, one bucket per lane" % ((hterms + S - 1) // S, 4 * 4 * ((hterms + S - 1) // S + 1) / 1024),
                       "checked": {"passed": ok4, "what": how},
-                      "timing": "HIP events on the library's stream: ms_msm = GLV split + window kernel + bucket reduction + slice folds + window combine; "
+                      "timing": "HIP events on the library's stream: ms_msm = GLV split + window kernel (bucket sums of every (window, slice) workgroup) + fold of the slices bucket by bucket + "
+                                "reduction of the 8 windows' 256 buckets and the Horner chain over the windows with four lanes per point addition; "
                                 "ms_decode_and_tables = decompression + subgroup test + affine table rows of all 2^20 points (one pass + one inversion pass); "
                                 "ms_call_wall adds the host's scalar reduction, 84 MB of PCIe and the workspace; median of 3 runs after one warm-up"}
     return out

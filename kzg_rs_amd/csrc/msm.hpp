@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(256, SAFE ? 1 : 2) void k_msm_reduce(const uint32_t
 // number of slots - made a 2^20-term sum SLOWER, 10.5 ms against 8.5: four launches of long workgroups have four tails, and the
 // reduction's 198-VGPR wavefronts take SIMD slots from the window kernel.  profiles/r5_config4_experiments.txt.)
 template <class CV, bool LDSSORT>
-inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, uint32_t* save, size_t save_bytes, hipStream_t st) {
+inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, uint32_t* save, size_t save_bytes, hipStream_t st, bool with_reduce = true) {
     const size_t layer = (size_t)gx * gy * (256 * (msm_two_pass<CV>() ? MSM_SAVE2_WORDS : CV::WORDS) + 1) * 4;  // (+ 1: the window's flag)
     unsigned per = (unsigned)std::min<size_t>(gz, std::max<size_t>(1, save_bytes / layer));
     d.save = save;
@@ -1298,6 +1298,7 @@ inline void msm_window_launch(MsmDesc d, unsigned gx, unsigned gy, unsigned gz, 
         const size_t list_bytes = (msm_two_pass<CV>() && LDSSORT) ? 4 * ((size_t)d.chunks_per_block * ((size_t)(d.max_terms + d.slices - 1) / d.slices + 1) + 4) : 0;
         hipLaunchKernelGGL((k_msm_window<CV, LDSSORT>), dim3(gx, gy, nz), dim3(256), CV::QUADS ? MSM_QUADS_LDS_BYTES : list_bytes, st, d);
         if constexpr (msm_two_pass<CV>()) {
+            if (!with_reduce) continue;  // (the caller takes the bucket sums of the whole grid from the save area: msm_large_tail)
             const int nslots = (int)(gx * gy * nz);
             uint32_t* const flags = save + (size_t)per * gx * gy * 256 * MSM_SAVE2_WORDS;  // behind the points of a full piece
             hipLaunchKernelGGL(k_msm_reduce<false>, dim3((unsigned)((nslots + 7) / 8)), dim3(256), 0, st, (const uint32_t*)save, flags, d.window_sums, (int)gx,
@@ -1415,6 +1416,178 @@ __global__ __launch_bounds__(64) void k_msm_combine_quad(const G1Jac* __restrict
         Fp* dst = r == 0 ? &out[o].x : r == 1 ? &out[o].y : &out[o].z;
         *dst = c;
     }
+}
+
+// ---- the tail of ONE LARGE sum (kzg_g1_msm from ~50 000 terms on: Z = 2 S layers of (window, slice) workgroups, Z in the
+// hundreds at 2^20 terms).  k_msm_reduce is a chain of ~28 point additions per slot whatever the number of slots (1.0 ms,
+// one lane per addition at ~35 us each), the fold of the Z window sums six more, the Horner chain 63: 1.55 ms behind a 7 ms
+// window kernel.  Here the SLICES are folded first, bucket by bucket - B[w][b] = sum_z B[z][w][b]: Z - 1 additions per
+// bucket, all 256 W buckets at once: work, not latency - and only W slots are reduced, with four lanes per addition:
+//   k_msm_bucket_fold      thread (w, b, g) adds the layers [g per, (g + 1) per) of its bucket one after the other
+//                          (SAFE = false: a same-x pair only flags the workgroup, SAFE = true redoes flagged workgroups with
+//                          the complete formula - the two passes of k_msm_reduce)
+//   k_msm_bucket_sum_quads one wavefront per (w, b): the tree over its gp partial sums, sixteen quads
+//   k_msm_reduce_quads     one workgroup per window: sum_b b B_b as 16 sum_hi hi R_hi + sum_lo lo C_lo (the scheme of
+//                          k_msm_window's latency form), 64 quads
+// then k_msm_combine_quad.  Points travel as the save area's 48-word records (X | Y | Z, radix 2^29, 16 words each).
+__device__ __forceinline__ G1Jac29 save2_load(const uint32_t* p) {
+    const uint4* const i4 = reinterpret_cast<const uint4*>(p);
+    G1Jac29 pnt;
+    Fp29* const c[3] = {&pnt.x, &pnt.y, &pnt.z};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const uint4 a = i4[4 * j], bb = i4[4 * j + 1], cc = i4[4 * j + 2], dd = i4[4 * j + 3];
+        c[j]->l[0] = a.x; c[j]->l[1] = a.y; c[j]->l[2] = a.z; c[j]->l[3] = a.w;
+        c[j]->l[4] = bb.x; c[j]->l[5] = bb.y; c[j]->l[6] = bb.z; c[j]->l[7] = bb.w;
+        c[j]->l[8] = cc.x; c[j]->l[9] = cc.y; c[j]->l[10] = cc.z; c[j]->l[11] = cc.w;
+        c[j]->l[12] = dd.x; c[j]->l[13] = dd.y;
+    }
+    return pnt;
+}
+__device__ __forceinline__ void save2_store(uint32_t* p, const G1Jac29& v) {
+    sumq_store(p, v.x);
+    sumq_store(p + 16, v.y);
+    sumq_store(p + 32, v.z);
+}
+constexpr int MSM_FOLD_MAX_GROUPS = 128;
+// save: [Z][W][256] bucket sums (the window kernel's slots, gy = 1, one piece); part: [W][256][gp] partial sums, the groups
+// beyond `groups` identities; flags: one word per workgroup, zeroed by the caller.  Grid W gp x 256 threads.
+template <bool SAFE>
+__global__ __launch_bounds__(256) void k_msm_bucket_fold(const uint32_t* __restrict__ save, uint32_t* __restrict__ part, uint32_t* __restrict__ flags, int W,
+                                                         int Z, int per, int groups, int gp) {
+    const int w = blockIdx.x % W, g = blockIdx.x / W, b = threadIdx.x;
+    if constexpr (SAFE) {
+        if (!flags[blockIdx.x]) return;
+    }
+    uint32_t* const dst = part + (((size_t)w * 256 + b) * gp + g) * MSM_SAVE2_WORDS;
+    if (g >= groups) {
+        save2_store(dst, g1j29_identity());
+        return;
+    }
+    const int z0 = g * per, z1 = min(Z, z0 + per);
+    bool bad = false;
+    G1Jac29 acc = save2_load(save + (((size_t)z0 * W + w) * 256 + b) * MSM_SAVE2_WORDS);
+#pragma unroll 1
+    for (int z = z0 + 1; z < z1; z++) acc = g1j29_add_fast<SAFE>(acc, save2_load(save + (((size_t)z * W + w) * 256 + b) * MSM_SAVE2_WORDS), bad);
+    save2_store(dst, acc);
+    if constexpr (!SAFE) {
+        if (__any((int)bad) && (threadIdx.x & 63) == 0) flags[blockIdx.x] = 1u;  // (every writer stores the same word)
+    }
+}
+// out[p] = the sum of part[p][0 .. gp), gp a power of two <= MSM_FOLD_MAX_GROUPS; dynamic LDS: gp points + 16 quad scratches
+constexpr size_t msm_bucket_sum_lds_bytes(int gp) { return 4 * ((size_t)gp * SUMQ_POINT_WORDS + 16 * SUMQ_SCRATCH_WORDS); }
+__global__ __launch_bounds__(64) void k_msm_bucket_sum_quads(const uint32_t* __restrict__ part, uint32_t* __restrict__ out, int gp) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t bsum_lds[];
+    uint32_t* const pts = bsum_lds;
+    const int tid = threadIdx.x, q = tid >> 2, r = tid & 3;
+    uint32_t* const scr = bsum_lds + gp * SUMQ_POINT_WORDS + q * SUMQ_SCRATCH_WORDS;
+    const uint4* const src = reinterpret_cast<const uint4*>(part + (size_t)blockIdx.x * gp * SUMQ_POINT_WORDS);
+    for (int i = tid; i < gp * (SUMQ_POINT_WORDS / 4); i += 64) reinterpret_cast<uint4*>(pts)[i] = src[i];
+    __syncthreads();
+#pragma unroll 1
+    for (int half = gp >> 1; half >= 1; half >>= 1) {
+#pragma unroll 1
+        for (int k = q; k < half; k += 16)
+            g1j29_add_quad<SumqLayout16>(pts + k * SUMQ_POINT_WORDS, pts + (k + half) * SUMQ_POINT_WORDS, pts + k * SUMQ_POINT_WORDS, scr, r, tid);
+        __syncthreads();
+    }
+    if (tid < SUMQ_POINT_WORDS / 4) reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * SUMQ_POINT_WORDS)[tid] = reinterpret_cast<const uint4*>(pts)[tid];
+}
+// window_sums[w] = sum_b b B[w][b] from buckets[w][256] (48-word records); one 256-thread workgroup (64 quads) per window.
+// Row trees in place, the bucket sums fetched again for the column trees, then the two weighted 16-element sums by a suffix
+// scan (from one vector into the other: a level reads slots that their owners rewrite) and a tree, four doublings, one
+// addition: ~22 quad additions in a row.
+constexpr size_t MSM_REDQ_LDS_BYTES = 4 * ((size_t)(256 + 64) * SUMQ_POINT_WORDS + 64 * SUMQ_SCRATCH_WORDS);
+__global__ __launch_bounds__(256) void k_msm_reduce_quads(const uint32_t* __restrict__ buckets, G1Jac* __restrict__ window_sums) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t redq_lds[];
+    constexpr int PW = SUMQ_POINT_WORDS, P4 = SUMQ_POINT_WORDS / 4;
+    const int tid = threadIdx.x, q = tid >> 2, r = tid & 3, lane = tid & 63;
+    uint32_t* const pts = redq_lds;
+    uint32_t* rc_cur = redq_lds + 256 * PW;
+    uint32_t* rc_nxt = rc_cur + 32 * PW;
+    uint32_t* const scr = redq_lds + (256 + 64) * PW + q * SUMQ_SCRATCH_WORDS;
+    const uint4* const src = reinterpret_cast<const uint4*>(buckets + (size_t)blockIdx.x * 256 * PW);
+    for (int i = tid; i < 256 * P4; i += 256) reinterpret_cast<uint4*>(pts)[i] = src[i];
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 1; s < 16; s <<= 1) {  // rows: R_hi ends in slot 16 hi
+        const int ops = 128 / s, per_row = 8 / s;
+#pragma unroll 1
+        for (int k = q; k < ops; k += 64) {
+            const int dst = 16 * (k / per_row) + 2 * s * (k % per_row);
+            g1j29_add_quad<SumqLayout16>(pts + dst * PW, pts + (dst + s) * PW, pts + dst * PW, scr, r, lane);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 16 * P4; i += 256) reinterpret_cast<uint4*>(rc_cur)[i] = reinterpret_cast<const uint4*>(pts)[(16 * (i / P4)) * P4 + i % P4];
+    __syncthreads();
+    for (int i = tid; i < 256 * P4; i += 256) reinterpret_cast<uint4*>(pts)[i] = src[i];
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 1; s < 16; s <<= 1) {  // columns: C_lo ends in slot lo
+        const int ops = 128 / s;
+#pragma unroll 1
+        for (int k = q; k < ops; k += 64) {
+            const int dst = 16 * (2 * s * (k >> 4)) + (k & 15);
+            g1j29_add_quad<SumqLayout16>(pts + dst * PW, pts + (dst + 16 * s) * PW, pts + dst * PW, scr, r, lane);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 16 * P4; i += 256) reinterpret_cast<uint4*>(rc_cur)[16 * P4 + i] = reinterpret_cast<const uint4*>(pts)[i];
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 1; s < 16; s <<= 1) {  // suffix scans of R (slots 0..15) and C (16..31): V_k <- sum_{j >= k} V_j
+        if (q < 32) {
+            if ((q & 15) + s < 16) g1j29_add_quad<SumqLayout16>(rc_cur + q * PW, rc_cur + (q + s) * PW, rc_nxt + q * PW, scr, r, lane);
+            else if (r < 3) sumq_store(rc_nxt + q * PW + 16 * r, sumq_load(rc_cur + q * PW + 16 * r));
+        }
+        __syncthreads();
+        uint32_t* const t = rc_cur;
+        rc_cur = rc_nxt;
+        rc_nxt = t;
+    }
+    if (tid < 2) save2_store(rc_cur + 16 * tid * PW, g1j29_identity());  // sum_{k >= 1} S_k = sum_j j V_j: S_0 stays out
+    __syncthreads();
+#pragma unroll 1
+    for (int s = 8; s >= 1; s >>= 1) {
+        if (q < 32 && (q & 15) < s) g1j29_add_quad<SumqLayout16>(rc_cur + q * PW, rc_cur + (q + s) * PW, rc_cur + q * PW, scr, r, lane);
+        __syncthreads();
+    }
+    if (tid >= 4) return;  // (one quad: its LDS instructions execute in order)
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) g1j29_dbl_quad<SumqLayout16>(rc_cur, rc_cur, scr, r);
+    g1j29_add_quad<SumqLayout16>(rc_cur, rc_cur + 16 * PW, rc_cur, scr, r, lane);
+    if (r < 3) {
+        const Fp c = fp29_to_std(sumq_load(rc_cur + 16 * r));
+        G1Jac& o = window_sums[blockIdx.x];
+        *(r == 0 ? &o.x : r == 1 ? &o.y : &o.z) = c;
+    }
+}
+// Host side of the tail: `save` holds the bucket sums of all Z layers (msm_window_launch(..., with_reduce = false) in ONE
+// piece); tmp: msm_large_tail_bytes(W, gp) of device memory; leaves window_sums[0 .. W).
+constexpr size_t msm_large_tail_bytes(unsigned W, int gp) { return 4 * ((size_t)W * 256 * ((size_t)gp + 1) * MSM_SAVE2_WORDS + (size_t)W * MSM_FOLD_MAX_GROUPS); }
+inline int msm_large_tail_groups(unsigned Z, int per, int* gp_out) {
+    const int groups = (int)((Z + per - 1) / per);
+    int gp = 2;
+    while (gp < groups) gp <<= 1;
+    *gp_out = gp;
+    return groups;
+}
+inline hipError_t msm_large_tail(const uint32_t* save, unsigned W, unsigned Z, int per, uint32_t* tmp, G1Jac* window_sums, hipStream_t st) {
+    int gp;
+    const int groups = msm_large_tail_groups(Z, per, &gp);
+    uint32_t* const flags = tmp;                                   // [W gp]
+    uint32_t* const part = tmp + (size_t)W * MSM_FOLD_MAX_GROUPS;  // [W][256][gp] records
+    uint32_t* const buckets = part + (size_t)W * 256 * gp * MSM_SAVE2_WORDS;  // [W][256] records
+    hipError_t e = hipMemsetAsync(flags, 0, 4 * (size_t)W * gp, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_msm_bucket_fold<false>, dim3(W * gp), dim3(256), 0, st, save, part, flags, (int)W, (int)Z, per, groups, gp);
+    hipLaunchKernelGGL(k_msm_bucket_fold<true>, dim3(W * gp), dim3(256), 0, st, save, part, flags, (int)W, (int)Z, per, groups, gp);
+    if ((e = DYN_LDS(k_msm_bucket_sum_quads, msm_bucket_sum_lds_bytes(MSM_FOLD_MAX_GROUPS))) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_msm_bucket_sum_quads, dim3(W * 256), dim3(64), msm_bucket_sum_lds_bytes(gp), st, (const uint32_t*)part, buckets, gp);
+    if ((e = DYN_LDS(k_msm_reduce_quads, MSM_REDQ_LDS_BYTES)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_msm_reduce_quads, dim3(W), dim3(256), MSM_REDQ_LDS_BYTES, st, (const uint32_t*)buckets, window_sums);
+    return hipGetLastError();
 }
 
 // The same sum with ONE LANE per output, for launches with many outputs (a launch group of batches): the Horner chain

@@ -481,6 +481,87 @@ def test_g1_msm_slice_boundaries(settings, n):
     assert out.raw == want
 
 
+def _tiled_msm(settings, base, sc_rows):
+    """kzg_g1_msm over the points of `base` tiled over len(sc_rows) terms, and what the oracle says by linearity."""
+    import ctypes as C
+    import numpy as np
+    D, n = len(base), len(sc_rows)
+    pts = (b"".join(base) * (n // D + 1))[: 48 * n]
+    sc = np.ascontiguousarray(sc_rows, dtype=np.uint8)
+    out = C.create_string_buffer(48)
+    api._chk(api.lib().kzg_g1_msm(out, pts, sc.ctypes.data_as(C.c_char_p), n, settings._h))
+    sums = [0] * D
+    for i in range(n):
+        sums[i % D] += int.from_bytes(sc[i].tobytes(), "big")
+    return out.raw, O.g1_msm(b"".join(base), b"".join((v % R).to_bytes(32, "big") for v in sums), D)
+
+
+def test_g1_msm_large_sum_tail_special_cases(settings):
+    """From 16 (window, slice) layers on (n > 24 576) kzg_g1_msm folds the slices BUCKET BY BUCKET (k_msm_bucket_fold: the
+    fast pass flags a same-x pair, the safe pass redoes the flagged workgroups), sums the partial sums with four lanes per
+    addition and reduces 8 slots with quads (csrc/msm.hpp msm_large_tail).  Inputs built to meet every ending of those
+    additions: ONE point under one scalar (equal bucket sums in every slice: P + P all through the fold, every other bucket
+    empty), P and -P in turn (the identity as a partial sum and as the result), two points under two byte patterns (equal
+    partial sums meeting in the quads' trees and in the row / column scans), and a run with only the LAST slices populated
+    (identities first in every chain)."""
+    import numpy as np
+    rng = random.Random(99)
+    m = _gen_multiples([rng.randrange(1, R)])[0]
+    neg = O.g1_mul(m, (R - 1).to_bytes(32, "big"))
+    q = _gen_multiples([rng.randrange(1, R)])[0]
+    n = 49_153
+    one = np.zeros((n, 32), dtype=np.uint8)
+    one[:, 31] = 1
+    got, want = _tiled_msm(settings, [m], one)
+    assert got == want
+    k = np.zeros((n, 32), dtype=np.uint8)
+    k[:] = np.frombuffer(bytes([0x11] * 31 + [0x21]), dtype=np.uint8)
+    k[:, 0] &= 0x0F
+    got, want = _tiled_msm(settings, [m], k)
+    assert got == want
+    got, want = _tiled_msm(settings, [m, neg], k[: n - 1])   # an even count: every pair cancels
+    assert got == want == G1_INF
+    got, want = _tiled_msm(settings, [m, neg], k)            # one term left over
+    assert got == want
+    two = np.zeros((n, 32), dtype=np.uint8)
+    two[0::2] = np.frombuffer(bytes([0x00] * 16 + [0x35] * 16), dtype=np.uint8)
+    two[1::2] = np.frombuffer(bytes([0x00] * 16 + [0x53] * 16), dtype=np.uint8)
+    got, want = _tiled_msm(settings, [m, q, q, m], two)
+    assert got == want
+    tail_only = np.zeros((n, 32), dtype=np.uint8)
+    tail_only[n - 700:] = np.random.Generator(np.random.PCG64(5)).integers(0, 256, size=(700, 32), dtype=np.uint8)
+    tail_only[:, 0] &= 0x3F
+    got, want = _tiled_msm(settings, [m, q, G1_INF], tail_only)
+    assert got == want
+
+
+def test_g1_msm_large_sum_tail_against_the_slot_reduction():
+    """The same 2^17-term sums through both tails in the A/B build - the bucket-first fold + quads (default) and the per-slot
+    reduction + fold trees of the window sums (g1_msm_large_tail=0) - and through two fold shapes: byte for byte."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, ctypes as C, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from kzg_rs_amd import api\n"
+        "s = api.KzgSettings.load_trusted_setup_file()\n"
+        "n = 1 << 17\n"
+        "g = api.g1_mul_generator([(3 + 7 * i).to_bytes(32, 'big') for i in range(509)], s)\n"
+        "pts = (b''.join(g) * (n // 509 + 1))[:48 * n]\n"
+        "sc = np.random.Generator(np.random.PCG64(17)).integers(0, 256, size=(n, 32), dtype=np.uint8)\n"
+        "sc[:, 0] &= 0x3F\n"
+        "out = C.create_string_buffer(48)\n"
+        "api._chk(api.lib().kzg_g1_msm(out, pts, sc.ctypes.data_as(C.c_char_p), n, s._h))\n"
+        "print('SUM', out.raw.hex())\n" % O.ROOT)
+    sums = []
+    for opts in ("", "g1_msm_large_tail=0", "g1_msm_fold_per=2", "g1_msm_fold_per=13"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_OPTIONS=opts, KZG_LIB_OVERRIDE=api.LIB_AB_PATH),
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (opts, out.stdout[-2000:], out.stderr[-2000:])
+        sums.append([l for l in out.stdout.splitlines() if l.startswith("SUM")][0])
+    assert len(set(sums)) == 1, sums
+
+
 def test_g1_msm_cancellation(settings):
     """s*P + (r - s)*P = O and all-equal digits: bucket collisions, P + (-P), identity result."""
     rng = random.Random(5)
