@@ -38,7 +38,7 @@ i=0
     i=$((i+1))
     out=gpurun_out/${tag}_config_pmc_$i
     rm -rf $out; mkdir -p $out
-    KZG_OPTIONS="single_stream=1;g1_msm_overlap=0" rocprofv3 --pmc $ctrs --kernel-trace -d $out -o run --output-format csv -- python3 tools/prof/config_legs.py --no-cpu > $out.log 2>&1
+    KZG_OPTIONS="single_stream=1" rocprofv3 --pmc $ctrs --kernel-trace -d $out -o run --output-format csv -- python3 tools/prof/config_legs.py --no-cpu > $out.log 2>&1
 done
 [ "${SKIP_PMC:-0}" = "1" ] || python3 tools/prof/pmc_to_json.py gpurun_out/${tag}_config_pmc 0 > gpurun_out/${tag}_config_pmc.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err

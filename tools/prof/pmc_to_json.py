@@ -49,9 +49,9 @@ for name, o in kern.items():
         o["hbm_bytes_corrected"] = round(2 * o["FETCH_SIZE"] * 1024 + o["WRITE_SIZE"] * 1024)
 if group == 0:  # the config legs (tools/prof/config_legs.py): no launch group, the kernels' largest dispatches of that process
     print(json.dumps({
-        "method": "rocprofv3 --pmc, one counter set per run, KZG_OPTIONS=single_stream=1;g1_msm_overlap=0, python3 tools/prof/config_legs.py: values are "
+        "method": "rocprofv3 --pmc, one counter set per run, KZG_OPTIONS=single_stream=1, python3 tools/prof/config_legs.py: values are "
                   "per launch of the kernel (its largest dispatch in the process: k_blob_evaluate over 16 384 blobs = BASELINE configs[2]; k_msm_window, "
-                  "k_msm_reduce, k_g1_decode_multiples29, k_mult_to_affine29 over 2^20 terms = BASELINE configs[3]). FETCH_SIZE / WRITE_SIZE in KB as "
+                  "k_msm_bucket_fold, k_msm_bucket_sum_quads, k_msm_reduce_quads, k_g1_decode_multiples29, k_mult_to_affine29 over 2^20 terms = BASELINE configs[3]). FETCH_SIZE / WRITE_SIZE in KB as "
                   "reported; hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section).",
         "config3_blobs": 16384, "config4_pairs": 1 << 20, "kernels": kern}, indent=1))
     sys.exit(0)
