@@ -308,7 +308,15 @@ extern "C" KzgRet kzg_debug_concurrent_callers(double out[5], int kind, size_t t
         }
     };
     std::vector<std::thread> pool;
-    for (size_t t = 0; t < threads; t++) pool.emplace_back(body, t);
+    try {
+        pool.reserve(threads);
+        for (size_t t = 0; t < threads; t++) pool.emplace_back(body, t);
+    } catch (...) {  // (no more threads to be had: the ones made leave at once - a joinable thread must not meet its destructor)
+        stop.store(true);
+        go.store(true, std::memory_order_release);
+        for (auto& th : pool) th.join();
+        return fail(KZG_ERROR, "kzg_debug_concurrent_callers: could not start the threads");
+    }
     const auto t0 = std::chrono::steady_clock::now();
     go.store(true, std::memory_order_release);
     std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
