@@ -245,6 +245,7 @@ static KzgRet settings_common(KzgSettings** out, const uint8_t tau_g2[96]) {
         s->small->lane_priority = ab_int("small_priority", 1) ? 1 : 0;
         s->small->linger_us = std::max(0L, std::min(2000L, opt_int("small_linger_us", 250)));
         s->small->linger_gap_us = std::max(1L, std::min(1000L, ab_int("small_linger_gap_us", 40)));
+        s->small->cap_proofs = (size_t)std::max(1L, std::min(1024L, ab_int("small_cap_proofs", 1024)));  // (A/B: fewer tuples per launch; a request larger than the cap would never leave)
     }
     *out = s;
     return KZG_OK;
