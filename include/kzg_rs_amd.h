@@ -303,7 +303,8 @@ KzgRet kzg_g1_decompress(uint8_t *status_out, uint8_t *xy_out, const uint8_t *po
 /* G1Projective::msm_variable_base (call sites src/kzg_proof.rs:419,429,430): out = sum scalars[i] * points[i];
  * points: n * 48 bytes compressed, must lie in G1 (checked: the MSM uses the GLV endomorphism); scalars: n * 32 bytes
  * big-endian (reduced mod r),
- * out: 48 bytes compressed.  Host pointers. */
+ * out: 48 bytes compressed.  Host pointers.  n <= 2^26 (KZG_BADARGS above).  BASELINE config 4: 2^20 terms in 7.8 ms + 24.5 ms of
+ * decompression, subgroup tests and table rows for the 2^20 points. */
 KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t *points48, const uint8_t *scalars, size_t n, const KzgSettings *s);
 /* out48[i] = compress(scalars[i] * G1::generator()); scalars n * 32 bytes big-endian (reduced mod r).
  * Prover-side helper used to build synthetic (commitment, proof) pairs under a
