@@ -180,6 +180,9 @@ def concurrent_callers(settings, blobs, cs, ps, synth, qc, qz, qy, qp, no_cpu=Fa
                 "throttled_ms": round((after.get("throttled_usec", 0) - before.get("throttled_usec", 0)) / 1e3, 1)}
 
     out = {"handle": "one shared KzgSettings handle; small-call queue of csrc/capi_coalesce.hpp", "seconds_per_point": seconds, "host_cores": ncores,
+           "callers": "T std::threads inside the library (kzg_debug_concurrent_callers), closed loop: each calls the public entry point again as soon as its answer is "
+                      "back and checked; the threads wait for the start asleep and make their first call at their own moment within 2.5 ms (independent callers do not "
+                      "arrive in lock-step; released together they would travel as one cohort with the second lane idle: 86-90 k instead of 94-108 k calls/s at T = 256)",
            "host_cpu_quota_cores": quota,
            "verify_kzg_proof": [], "verify_blob_kzg_proof_batch_6_host_blobs": []}
     settings.concurrent_callers("proof", 8, 0.3, c_, p_, bytes(exp), z=z_, y=b"".join(ys))  # lanes and their workspaces
