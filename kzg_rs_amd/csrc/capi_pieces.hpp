@@ -189,8 +189,9 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     if ((rc = msm_save_reserve(s, W, 1, gz)) != KZG_OK) return rc;
     // From 16 layers on (and while the save area holds them all: ~4 M terms) the tail of a LARGE sum: the slices folded bucket
     // by bucket, then W slots reduced with four lanes per addition (msm.hpp msm_large_tail) - 0.8 ms instead of 1.55 at 2^20
-    // terms.  fold_per = the layers one thread adds in a row (more: fewer partial sums for the quads, a longer chain).
-    static const int fold_per_opt = (int)std::max(2L, std::min(64L, ab_int("g1_msm_fold_per", 6)));
+    // terms.  fold_per = the layers one thread adds in a row (more: fewer partial sums for the quads, a longer chain; measured at
+    // 344 layers: 6 -> 0.166 + 0.160 ms, 11 -> 0.188 + 0.111, 16 -> 0.264 + 0.115, 22 -> 0.358 + 0.077 for fold + sum).
+    static const int fold_per_opt = (int)std::max(2L, std::min(64L, ab_int("g1_msm_fold_per", 11)));
     const int fold_per = std::max(fold_per_opt, (int)((gz + MSM_FOLD_MAX_GROUPS - 1) / MSM_FOLD_MAX_GROUPS));
     int fold_gp = 0;
     (void)msm_large_tail_groups(gz, fold_per, &fold_gp);

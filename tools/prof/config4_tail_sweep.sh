@@ -1,7 +1,14 @@
-set -x
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "g1_msm" 2>&1 | tail -3
-timeout 600 python -m pytest tests/test_gpu_baseline_sizes.py -x -q -k "config4 or msm" 2>&1 | tail -3
-echo "== product default"; python tools/prof/config_legs.py --no-cpu 2>&1 | tail -1
-for o in "g1_msm_large_tail=0" "g1_msm_fold_per=4" "g1_msm_fold_per=6" "g1_msm_fold_per=8" "g1_msm_fold_per=11" "g1_msm_fold_per=3"; do
-  echo "== $o"; KZG_LIB_OVERRIDE=$PWD/kzg_rs_amd/libkzg_rs_amd_ab.so KZG_OPTIONS="$o" python tools/prof/config_legs.py --no-cpu 2>&1 | tail -1
+# A/B: the large-sum tail of kzg_g1_msm (msm.hpp msm_large_tail) - layers one thread folds in a row (g1_msm_fold_per) - with the kernels' own times
+export TMPDIR=/tmp
+for o in "g1_msm_fold_per=6" "g1_msm_fold_per=11" "g1_msm_fold_per=16" "g1_msm_fold_per=22" "g1_msm_fold_per=43"; do
+  echo "== $o"
+  rm -rf /tmp/c4s
+  KZG_LIB_OVERRIDE=$PWD/kzg_rs_amd/libkzg_rs_amd_ab.so KZG_OPTIONS="$o" rocprofv3 --kernel-trace --stats -d /tmp/c4s -o run --output-format csv -- python3 tools/prof/config_legs.py --no-cpu 2>/dev/null | grep -o '"ms_msm": [0-9.]*, "ms_decode_and_tables": [0-9.]*, "ms_msm_all_runs": \[[^]]*\]'
+  python3 - <<'P'
+import csv,glob
+f=glob.glob("/tmp/c4s/**/*kernel_stats.csv",recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    n=r["Name"]
+    if any(k in n for k in ("bucket_fold<false","bucket_sum","reduce_quads","combine_quad")): print("   %-50s %s calls  avg %.1f us" % (n.split("(")[0][-50:], r["Calls"], float(r["AverageNs"])/1e3))
+P
 done
