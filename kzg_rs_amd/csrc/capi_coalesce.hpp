@@ -190,7 +190,11 @@ static KzgRet small_submit(const KzgSettings* s, SmallReq& r) {
                 msg = "host buffers of the launch";
             }
             if (rc != KZG_OK) proof_drain(L.h);  // nothing of the launch stays in flight behind an error
-            else memcpy(s->timings, L.h->timings, sizeof s->timings);  // kzg_last_timings: the last launch's intervals (last writer wins)
+            else {  // kzg_last_timings: the last launch's intervals - under the handle's lock like every other writer and the reader;
+                    // a diagnostic: when a large call holds the lock (or the other lane's leader is writing) this launch's are skipped
+                std::unique_lock<std::mutex> tl(s->mu, std::try_to_lock);
+                if (tl.owns_lock()) memcpy(s->timings, L.h->timings, sizeof s->timings);
+            }
         }
         if (shard != 0) (void)hipSetDevice(s->device);
         // no pool worker may still read a caller's blobs once its call has returned (an error path may not have come by the join)
