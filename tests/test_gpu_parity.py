@@ -562,6 +562,15 @@ def test_g1_msm_large_sum_tail_against_the_slot_reduction():
     assert len(set(sums)) == 1, sums
 
 
+def test_g1_msm_randomised_large_sums():
+    """10 s of tools/fuzz_g1_msm.py: random sizes in the large-sum tail's range, points with repeats / negatives / the identity,
+    scalar patterns that collide in the buckets, every sum against the oracle by linearity."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(O.ROOT, "tools", "fuzz_g1_msm.py"), "10", "20261003"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "no mismatch" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
 def test_g1_msm_cancellation(settings):
     """s*P + (r - s)*P = O and all-equal digits: bucket collisions, P + (-P), identity result."""
     rng = random.Random(5)
