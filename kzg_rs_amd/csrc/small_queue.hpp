@@ -139,6 +139,12 @@ static int small_take_lane(SmallQueue& Q) {
     return -1;
 }
 
+// (tests/host/small_queue_main.cpp defines this to stall a caller between its read of r.lane and its read of the word it will
+// sleep on - the window in which a leader can take the request)
+#ifndef SMALL_QUEUE_TEST_HOOK_BETWEEN_LOADS
+#define SMALL_QUEUE_TEST_HOOK_BETWEEN_LOADS() ((void)0)
+#endif
+
 // Submit a request and return when it is done (r.rc, r.msg; the per-item results where the request points).  The calling thread
 // may lead launches meanwhile - its own request's, or one that only carries older requests.
 //   run(lane index, lane, batch, items, kind, msg) -> KzgRet : the launch itself, called WITHOUT the queue's lock by the leader that
@@ -151,8 +157,15 @@ static KzgRet small_submit_core(SmallQueue& Q, SmallReq& r, Run&& run) {
     for (;;) {
         const int my_lane = r.lane.load(std::memory_order_acquire);
         std::atomic<uint32_t>& word = my_lane >= 0 ? Q.lanes[my_lane]->word : Q.epoch;  // where this caller sleeps: its launch's lane, or the queue
+        SMALL_QUEUE_TEST_HOOK_BETWEEN_LOADS();
         const uint32_t seen = word.load(std::memory_order_acquire);
         if (r.done.load(std::memory_order_acquire)) break;
+        // A leader may have taken the request between the two loads above: it stores r.lane, THEN bumps the queue's word and
+        // moves that word's sleepers to its lane's.  A `seen` read after that bump would let this caller sleep on the queue's
+        // word at its current value while the launch's completion only wakes the lane's word - asleep until unrelated traffic
+        // happens by, for ever on a handle that goes idle.  The lane store is ordered before the bump, so a post-bump `seen`
+        // implies the new lane is visible here: go round and sleep on the right word.
+        if (r.lane.load(std::memory_order_acquire) != my_lane) continue;
         int li = -1;
         std::unique_lock<SmallSpinLock> lk(Q.mu, std::defer_lock);
         // (ONE visit to the queue's lock for a caller that ends up a follower: it queues its request and looks for a lane in the

@@ -7,6 +7,12 @@
 //   * requests really travel together (fewer launches than requests), never beyond a launch's capacity, never two launches on
 //     one lane at a time, never more lanes than allowed;
 //   * the blob callers' challenge hashes (the persistent pool of host_only.hpp) are complete when the launch reads them.
+// argv[4] > 0: every fourth pass of a caller through the submit loop stalls that many microseconds between reading its request's
+// lane and reading the futex word it is about to sleep on (SMALL_QUEUE_TEST_HOOK_BETWEEN_LOADS) - the window in which a leader can
+// take the request and move the queue's sleepers; a caller that then slept on the queue's word would never be woken once traffic
+// stops (round-5 advisor finding).  argv[5]: watchdog seconds.  argv[6] = 1: the callers meet at a barrier before every call,
+// so the queue goes IDLE after every burst of T calls and a caller left asleep on the wrong word stays asleep (continuous
+// traffic would wake it by accident).  Without the re-read of r.lane in small_submit_core this mode hangs within a few bursts.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,9 +22,17 @@
 #include <thread>
 #include <vector>
 
+static std::atomic<long> hook_delay_us{0};
+static std::atomic<unsigned> hook_calls{0};
+static void hook_between_loads();
+#define SMALL_QUEUE_TEST_HOOK_BETWEEN_LOADS() hook_between_loads()
 #define KZG_HOST_FE_PER_BLOB 64  // small "blobs" (2 KiB): the hashing pool's code paths without 128 KiB per request
 #include "small_queue.hpp"
 
+static void hook_between_loads() {
+    const long d = hook_delay_us.load(std::memory_order_relaxed);
+    if (d > 0 && (hook_calls.fetch_add(1, std::memory_order_relaxed) & 3) == 0) std::this_thread::sleep_for(std::chrono::microseconds(d));
+}
 static std::atomic<int> failures{0};
 #define CHECK(x)                                                      \
     do {                                                              \
@@ -30,6 +44,19 @@ static std::atomic<int> failures{0};
 
 int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 64, CALLS = argc > 2 ? atoi(argv[2]) : 200, LANES = argc > 3 ? atoi(argv[3]) : 2;
+    hook_delay_us = argc > 4 ? atol(argv[4]) : 0;
+    const int WATCHDOG_S = argc > 5 ? atoi(argv[5]) : 120;
+    const bool BURSTS = argc > 6 && atoi(argv[6]) != 0;
+    std::atomic<unsigned> bar_count{0}, bar_gen{0};
+    auto barrier = [&] {
+        const unsigned g = bar_gen.load(std::memory_order_acquire);
+        if (bar_count.fetch_add(1, std::memory_order_acq_rel) + 1 == (unsigned)T) {
+            bar_count.store(0, std::memory_order_relaxed);
+            bar_gen.fetch_add(1, std::memory_order_release);
+        } else {
+            while (bar_gen.load(std::memory_order_acquire) == g) std::this_thread::yield();
+        }
+    };
     const size_t BLOB = (size_t)32 * KZG_HOST_FE_PER_BLOB;
     SmallQueue Q;
     Q.max_lanes = (size_t)LANES;
@@ -40,9 +67,9 @@ int main(int argc, char** argv) {
     std::atomic<uint64_t> launches{0}, carried{0}, failed_launches{0};
     std::atomic<bool> finished{false};
     std::thread watchdog([&] {
-        for (int i = 0; i < 1200 && !finished; i++) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        for (int i = 0; i < 10 * WATCHDOG_S && !finished; i++) std::this_thread::sleep_for(std::chrono::milliseconds(100));
         if (!finished) {
-            fprintf(stderr, "WATCHDOG: callers still waiting after 120 s - a lost wake-up\n");
+            fprintf(stderr, "WATCHDOG: callers still waiting after %d s - a lost wake-up\n", WATCHDOG_S);
             abort();
         }
     });
@@ -92,6 +119,7 @@ int main(int argc, char** argv) {
     auto caller = [&](int t) {
         std::mt19937_64 rng(1234 + t);
         for (int k = 0; k < CALLS; k++) {
+            if (BURSTS) barrier();
             const bool blobs = t % 8 == 0;
             const size_t n = blobs ? 1 + rng() % 4 : 1 + rng() % 5;
             std::vector<uint8_t> c(48 * n), p(48 * n), z(32 * n), y(32 * n), bl(blobs ? BLOB * n : 0), zle(32 * n);
@@ -135,7 +163,7 @@ int main(int argc, char** argv) {
                 }
             }
             done_calls++;
-            if ((rng() & 7) == 0) std::this_thread::sleep_for(std::chrono::microseconds(rng() % 300));  // (not a pure closed loop)
+            if (!BURSTS && (rng() & 7) == 0) std::this_thread::sleep_for(std::chrono::microseconds(rng() % 300));  // (not a pure closed loop)
         }
     };
     std::vector<std::thread> ths;

@@ -22,13 +22,17 @@ def _build(tag, flags):
 
 
 @pytest.mark.parametrize("tag,flags,runs", [
-    ("tsan", ["-fsanitize=thread"], [(48, 60, 2), (96, 25, 3), (3, 150, 2)]),
+    # (threads, calls, lanes[, stall us between a caller's read of its lane and of its futex word, watchdog s, bursts])
+    # the last two: bursts of T calls with an idle queue between them and the stall injected - the lost wake-up of the round-5
+    # advisor finding (a follower asleep on the queue's word after its request left with a leader) hangs this within a few
+    # bursts when small_submit_core does not re-read r.lane (checked by hand against the unfixed loop: 3 hangs of 3 runs)
+    ("tsan", ["-fsanitize=thread"], [(48, 60, 2), (96, 25, 3), (3, 150, 2), (5, 200, 1, 300, 60, 1), (6, 150, 2, 200, 60, 1)]),
     ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], [(64, 80, 2), (200, 20, 1)]),
 ])
 def test_small_queue_under_sanitizers(tag, flags, runs):
     exe = _build(tag, flags)
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1")
-    for threads, calls, lanes in runs:
-        out = subprocess.run([exe, str(threads), str(calls), str(lanes)], capture_output=True, text=True, timeout=600, env=env)
-        assert out.returncode == 0, (threads, calls, lanes, out.stdout[-1500:], out.stderr[-3000:])
+    for run in runs:
+        out = subprocess.run([exe] + [str(x) for x in run], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, (run, out.stdout[-1500:], out.stderr[-3000:])
         assert "failures 0" in out.stdout and "WARNING: ThreadSanitizer" not in out.stderr, (out.stdout[-500:], out.stderr[-3000:])
