@@ -43,21 +43,7 @@ sys.path.insert(0, ROOT)
 # ROCm gives a process 4 hardware queues by default; the pipeline uses 2 streams per in-flight group
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-BYTES_PER_BLOB = 131072
-# algorithmic bytes per unit, per kernel (DESIGN.md 4 / SURVEY.md 8d)
-ALG_BYTES = {
-    "k_blob_challenge": BYTES_PER_BLOB + 48 + 32,   # blob + commitment read, z written       (per blob)
-    "k_blob_evaluate": BYTES_PER_BLOB + 32 + 32,    # blob + z read, y written                (per blob)
-    "k_g1_decode_multiples": 2 * (48 + 96 + 4 + 4 * 128 + 192),  # two points per blob: compressed in; affine, flag, 4 affine table rows, 2^64 P out
-    "k_msm": 3 * 128,                               # three (point, scalar) terms per blob, 96 + 32 B each
-    "k_slp_run(pairing)": 0,
-}
-PMC_NAME = {"k_blob_challenge": "kzg::k_blob_challenge_t<4>", "k_blob_evaluate": "kzg::k_blob_evaluate_t<true>",
-            "k_g1_decode_multiples": "kzg::k_g1_decode_multiples29<4, true>", "k_msm": "kzg::k_msm_window<kzg::Curve29Aff, true>",
-            "k_slp_run(pairing)": "kzg::k_slp_run<false>"}
-PMC_FILES = ("r5_pmc.json", "r4_pmc.json", "r3_pmc.json")  # newest first; the first that exists is used (kernel names must match PMC_NAME)
-PATH_ALG_BYTES = BYTES_PER_BLOB + 48 + 48 + 64   # full verify, per blob: blob + commitment + proof read, z and y written
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
+from kzg_rs_amd.benchline import BYTES_PER_BLOB, HBM_PEAK_GBS  # noqa: E402  (per-kernel algorithmic bytes, PMC names and the line's assembly live there)
 
 
 def cpu_baseline(blobs, cs, ps, tau_g2, max_blobs):
@@ -253,8 +239,19 @@ def config_legs(settings, torch, dev, no_cpu=False):
     d_z = torch.from_numpy(z_le).to(dev)
     d_y = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
+    # The leg's input was just written by memory-bound fill kernels (2 GiB).  For some tens of milliseconds after such a burst the
+    # chip runs this VALU-bound kernel 15-30 % slower (0.93 -> 1.20 ms, decaying over ~20 calls), and after 20 ms of idleness not at
+    # all (0.911-0.924 ms, 12 calls, spread 1.4 %): profiles/r6_config3_regimes.json.  It is the state of the chip, not the launch:
+    # the time per blob is the same at 4.0, 5.0 and 5.33 rounds of resident wavefronts (12 288 / 15 360 / 16 384 blobs: 54.7 / 54.6 /
+    # 54.0 ns), so there is no quantisation tail for a persistent grid to remove.  Both regimes are reported: `ms` after a settle,
+    # `ms_after_memory_burst` right behind the fills.
+    burst = []
+    for _ in range(4):
+        api.evaluate_polynomials_device(d_y.data_ptr(), d_blobs.data_ptr(), d_z.data_ptr(), n, settings)
+        burst.append(settings.last_timings()[4])
+    time.sleep(0.05)
     ms3 = []
-    for _ in range(6):
+    for _ in range(8):
         api.evaluate_polynomials_device(d_y.data_ptr(), d_blobs.data_ptr(), d_z.data_ptr(), n, settings)
         ms3.append(settings.last_timings()[4])
     y = d_y.cpu().numpy().reshape(n, 32)
@@ -265,33 +262,49 @@ def config_legs(settings, torch, dev, no_cpu=False):
     alg3 = BYTES_PER_BLOB + 64
     out["config3"] = {"workload": "evaluate_polynomial_in_evaluation_form only, %d device-resident blobs (BASELINE.json configs[2])" % n,
                       "entry_point": "kzg_evaluate_polynomials_device", "blobs": n, "ms": round(t3, 4), "ms_all_runs": [round(x, 4) for x in ms3],
+                      "spread": round((max(ms3[1:]) - min(ms3[1:])) / t3, 4),
+                      "ms_after_memory_burst": [round(x, 4) for x in burst],
                       "blobs_per_s": round(n / t3 * 1e3, 1),
                       "roofline": {"bound": "valu-issue", "algorithmic_bytes_per_blob": alg3, "achieved": round(alg3 * n / t3 / 1e6, 2), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(alg3 * n / t3 / 1e6 / HBM_PEAK_GBS, 6)},
                       "checked": {"passed": ok3, "what": "%d blobs evaluated at a root of unity return their own element; the two identical halves agree bit for bit"
                                                          % len(roots)},
-                      "timing": "HIP events on the library's stream around k_eval_powers + k_blob_evaluate + k_eval_finish; median of 5 runs after one warm-up"}
+                      "timing": "HIP events on the library's stream around k_eval_powers + k_blob_evaluate + k_eval_finish; ms = median of 7 back-to-back calls after one "
+                                "warm-up, started 50 ms after the input fills; ms_after_memory_burst = the 4 calls right behind the fills (see profiles/r6_config3_regimes.json)"}
     del d_blobs, d_z, d_y
     torch.cuda.empty_cache()
     # ---- config 4
     ts = open(os.path.join(ROOT, "kzg_rs_amd", "data", "trusted_setup.txt")).read().split("\n")
-    base = b"".join(bytes.fromhex(ts[2 + i]) for i in range(4096))
+    brp = lambda i: int(format(i, "012b")[::-1], 2)
+    base = b"".join(bytes.fromhex(ts[2 + brp(i)]) for i in range(4096))   # g1_points as the handle keeps them (bit-reversal permuted, build.rs:79)
     reps = 256
     n4 = 4096 * reps
     sc = np.random.Generator(np.random.PCG64(4)).integers(0, 256, size=(n4, 32), dtype=np.uint8)
-    sc[:, 0] &= 0x7F   # some scalars land in [r, 2^255): the entry point reduces them mod r like Scalar::from_raw
-    pts = base * reps
+    sc[:, 0] &= 0x7F   # some scalars land in [r, 2^255): the entry points reduce them mod r like Scalar::from_raw
     L = api.lib()
     o48 = C.create_string_buffer(48)
-    ms4, dec4, wall4 = [], [], []
-    for _ in range(4):
+    bench_settings = settings
+    settings = api.KzgSettings.load_trusted_setup_file()   # the mainnet setup (the benchmark's own handle is the known-tau test setup: no G1 section)
+    # (a) the setup form: the handle's own points, no per-call decode (kzg_g1_msm_setup)
+    ms4, wall4 = [], []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        api._chk(L.kzg_g1_msm_setup(o48, sc.ctypes.data_as(C.c_char_p), n4, settings._h))
+        wall4.append((time.perf_counter() - t0) * 1e3)
+        ms4.append(settings.last_timings()[2])
+    dec_setup = settings.last_timings()[6]
+    got = o48.raw
+    # (b) arbitrary points: the same 2^20 pairs as compressed bytes (kzg_g1_msm decodes, subgroup-tests and tabulates them per call)
+    pts = base * reps
+    msA, decA, wallA = [], [], []
+    for _ in range(3):
         t0 = time.perf_counter()
         api._chk(L.kzg_g1_msm(o48, pts, sc.ctypes.data_as(C.c_char_p), n4, settings._h))
-        wall4.append((time.perf_counter() - t0) * 1e3)
+        wallA.append((time.perf_counter() - t0) * 1e3)
         tm = settings.last_timings()
-        ms4.append(tm[2])
-        dec4.append(tm[6])
-    got = o48.raw
+        msA.append(tm[2])
+        decA.append(tm[6])
+    same_forms = o48.raw == got
     # sum of each point's 256 scalars mod r, in Python integers (256 x 4096 additions of 32-byte numbers)
     sums = [0] * 4096
     as_int = [int.from_bytes(sc[i].tobytes(), "big") for i in range(n4)]
@@ -299,41 +312,36 @@ def config_legs(settings, torch, dev, no_cpu=False):
         sums[i & 4095] += v
     small = b"".join((v % R).to_bytes(32, "big") for v in sums)
     api._chk(L.kzg_g1_msm(o48, base, small, 4096, settings._h))
-    ok4 = o48.raw == got
-    how = "equals the 4 096-term MSM over the distinct points with each point's 256 scalars summed mod r (same entry point, one-slice shape)"
+    ok4 = o48.raw == got and same_forms
+    how = ("kzg_g1_msm_setup = kzg_g1_msm over the same points as compressed bytes = the 4 096-term MSM over the distinct points with each point's 256 scalars summed mod r")
     if not no_cpu:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
         ok4 = ok4 and O.g1_msm(base, small, 4096) == got
-        how += " and the CPU oracle's 4 096-term MSM"
+        how += " = the CPU oracle's 4 096-term MSM"
+    settings.close()
+    settings = bench_settings
     t4 = sorted(ms4[1:])[len(ms4[1:]) // 2]
-    d4 = sorted(dec4[1:])[len(dec4[1:]) // 2]
-    hterms = (n4 + 1) // 2
-    S = (hterms + 3071) // 3072               # csrc/capi_pieces.hpp kzg_g1_msm: slices of at most 3 072 terms, their number a multiple of 4
-    S = 1 if S <= 1 else (S + 3) & ~3
-    out["config4"] = {"workload": "G1 msm_variable_base, 2^20 trusted-setup points (4 096 Lagrange points x 256) x random Fr scalars (BASELINE.json configs[3])",
-                      "entry_point": "kzg_g1_msm", "pairs": n4, "ms_msm": round(t4, 4), "ms_decode_and_tables": round(d4, 4), "ms_msm_all_runs": [round(x, 4) for x in ms4],
-                      "ms_call_wall": round(sorted(wall4[1:])[1], 3), "pairs_per_s": round(n4 / t4 * 1e3, 1), "ns_per_term": round(t4 * 1e6 / n4, 3),
-                      "roofline": {"bound": "valu-issue", "algorithmic_bytes_per_pair": 128, "achieved": round(128 * n4 / t4 / 1e6, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(128 * n4 / t4 / 1e6 / HBM_PEAK_GBS, 6)},
-                      "window_bits": 8, "windows": 32, "glv_chunks": 4, "slices_per_output": S, "workgroups": 8 * 2 * S,
-                      "buckets_in_lds": "the sorted (bucket -> table entry) lists: 4 x %d entries = %.1f KB per workgroup; the 256 bucket accumulators of a workgroup "
-                                        "are registers, one bucket per lane" % ((hterms + S - 1) // S, 4 * 4 * ((hterms + S - 1) // S + 1) / 1024),
+    w4 = sorted(wall4[1:])[len(wall4[1:]) // 2]
+    tA = sorted(msA[1:])[0]
+    out["config4"] = {"workload": "G1 msm_variable_base, 2^20 trusted-setup points (the handle's 4 096 Lagrange points, term i -> point i mod 4 096) x random Fr scalars "
+                                  "(BASELINE.json configs[3])",
+                      "entry_point": "kzg_g1_msm_setup", "pairs": n4, "ms_msm": round(t4, 4), "ms_decode_and_tables": round(dec_setup, 4), "ms_msm_all_runs": [round(x, 4) for x in ms4],
+                      "ms_call_wall": round(w4, 3), "ms_call_wall_all_runs": [round(x, 3) for x in wall4], "pairs_per_s": round(n4 / t4 * 1e3, 1), "ns_per_term": round(t4 * 1e6 / n4, 3),
+                      "roofline": {"bound": "valu-issue", "algorithmic_bytes_per_pair": 32, "achieved": round(32 * n4 / t4 / 1e6, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(32 * n4 / t4 / 1e6 / HBM_PEAK_GBS, 6),
+                                   "note": "algorithmic bytes = the scalars (32 B per term): the points are the handle's, resident as table rows (16 MB)"},
+                      "form": "fixed base (csrc/msm_fixed.hpp): 16 signed 16-bit windows, 16 bucket additions per term into ONE set of 2^15 buckets; entries partitioned in HBM by "
+                              "the bucket's high 7 bits (counting sort, 4 B per entry), each workgroup sorts <= 12 288 entries of one partition by the low 8 bits in LDS (48 KB) and "
+                              "accumulates one bucket per lane in registers (mixed additions of 128-B affine rows 2^(16 v) P_j)",
+                      "arbitrary_points": {"entry_point": "kzg_g1_msm", "ms_msm": round(tA, 4), "ms_decode_and_tables": round(sorted(decA[1:])[0], 4), "ms_call_wall": round(sorted(wallA[1:])[0], 3),
+                                           "what": "the same pairs with the points as 2^20 x 48 compressed bytes: decompression + subgroup test + table rows per call, then GLV + 8-bit "
+                                                   "windows (32 bucket additions per term) on the verification path's window kernel"},
                       "checked": {"passed": ok4, "what": how},
-                      "timing": "HIP events on the library's stream: ms_msm = GLV split + window kernel (bucket sums of every (window, slice) workgroup) + fold of the slices bucket by bucket + "
-                                "reduction of the 8 windows' 256 buckets and the Horner chain over the windows with four lanes per point addition; "
-                                "ms_decode_and_tables = decompression + subgroup test + affine table rows of all 2^20 points (one pass + one inversion pass); "
-                                "ms_call_wall adds the host's scalar reduction, 84 MB of PCIe and the workspace; median of 3 runs after one warm-up"}
+                      "timing": "HIP events on the library's stream: ms_msm = digits + partition (count, plan, scatter) + bucket accumulation + fold of the workgroups' bucket sums + "
+                                "the two 256-bucket reductions + join; ms_call_wall = the whole call from pageable host scalars (32 MB of PCIe, reduction mod r on the device); "
+                                "median of 5 runs after one warm-up"}
     return out
-
-
-def load_pmc():
-    for name in PMC_FILES:
-        try:
-            return name, json.load(open(os.path.join(ROOT, "profiles", name)))
-        except Exception:
-            continue
-    return None, None
 
 
 def spawn_ranks(n):
@@ -499,6 +507,11 @@ def main():
     ap.add_argument("--no-self-check", action="store_true", help="skip the poisoned control group and the stand-alone group (profiling runs)")
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2] / configs[3] legs (evaluation only; 2^20-term MSM)")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the concurrent_callers block (T threads on one shared handle)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="run the one-process-per-GPU path (PipelinedVerifier: kzg_shard_* phases + torch.distributed exchanges) even in a world of ONE rank - "
+                         "what the default run's configs.config5_shard leg does in a child process, so that the 1-GPU figure of the sharded shape comes from the "
+                         "same code path --gpus N runs")
+    ap.add_argument("--no-shard-leg", action="store_true", help="skip configs.config5_shard (BASELINE configs[4]'s shard shape on one GPU, in a child process)")
     ap.add_argument("--precall-single", action="store_true",
                     help="measurement: one 1 024-blob call on the handle BEFORE the warm-up (it creates the handle's CU-masked stream pair, "
                          "two more users of the 8 hardware queues the pipeline's lanes share)")
@@ -533,14 +546,23 @@ def main():
     dev = torch.device("cuda", local_rank)
     coll_dev = "cpu" if share else dev  # where the collectives' tensors live
     dist = None
-    if world > 1:
+    use_pipe = world > 1 or args.force_collectives   # the one-process-per-GPU path (also in a world of one when asked for)
+    if use_pipe:
+        import datetime
+
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         if share:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=120))
 
     from kzg_rs_amd import api, synth
     from kzg_rs_amd.distributed import HipBackend, PipelinedVerifier, verify_blob_kzg_proof_batch_sharded
@@ -551,7 +573,23 @@ def main():
     n = args.blobs or (1024 if workload == "configs1" else 32768)
     G = max(1, args.group or (256 if workload == "configs1" else 8))
     F = max(1, args.inflight)
-    blobs, cs, ps, settings = synth.make_valid_batch(n, seed=1000 + rank, chunk=1024)
+    # pre-flight: the variants (one per group in flight: G x n blobs each) against this GPU's free memory - a run that does not fit
+    # shrinks its launch group (and says so) instead of dying in an allocation
+    n_var = 1 if F <= 1 else (max(1, F - 2) + 3 if use_pipe else F + 1)   # = sum(depth) + 1 below: one variant per pipeline handle
+    free_b = torch.cuda.mem_get_info(dev)[0]
+    G_asked = G
+    def _need(g):
+        return n_var * g * n * (BYTES_PER_BLOB + 96) + n * (BYTES_PER_BLOB + 96) + (14 << 30)   # + the synthetic batch + workspaces, tables, pinned mirrors
+    while G > 1 and _need(G) > free_b:
+        G = max(1, G // 2)
+    preflight = {"free_hbm_GiB": round(free_b / 2**30, 1), "variants": n_var, "needed_GiB": round(_need(G) / 2**30, 1), "batches_per_step": G,
+                 "batches_per_step_asked": G_asked, "shrunk": G != G_asked}
+    n_src = min(n, 1024) if args.force_collectives and world == 1 else n   # (the shard leg of the default run: 1 024 valid blobs, tiled)
+    blobs, cs, ps, settings = synth.make_valid_batch(n_src, seed=1000 + rank, chunk=1024)
+    if n_src != n:
+        reps = (n + n_src - 1) // n_src
+        blobs = np.ascontiguousarray(np.tile(blobs, (reps, 1))[:n])
+        cs, ps = (cs * reps)[:n], (ps * reps)[:n]
     d_blobs = torch.from_numpy(blobs).to(dev)
     d_c = torch.frombuffer(bytearray(b"".join(cs)), dtype=torch.uint8).to(dev)
     d_p = torch.frombuffer(bytearray(b"".join(ps)), dtype=torch.uint8).to(dev)
@@ -561,12 +599,12 @@ def main():
     # ---- pipeline: depth (d1, d2, d3) groups between the phases; one handle (2 HIP streams + workspace) per group in flight
     if F <= 1:
         depth = (0, 0, 0)
-    elif world > 1:
+    elif use_pipe:
         depth = (max(1, F - 2), 1, 1)
     else:
         depth = (F - 1, 0, 1)
     n_handles = sum(depth) + 1
-    if world == 1:
+    if not use_pipe:
         # ONE GPU: the groups are kept in flight INSIDE the library (kzg_verify_blob_kzg_proof_batch_groups_device,
         # csrc/capi_pipeline.hpp: the same fixed-order pipeline behind one C call - the entry point a C / Rust caller with many
         # batches has); the handle grows its own per-group lanes
@@ -574,7 +612,7 @@ def main():
     else:
         handles = [settings] + [api.KzgSettings.from_tau_g2(synth.synthetic_setup()[1]) for _ in range(n_handles - 1)]
         backends = [backend0] + [HipBackend(h) for h in handles[1:]]
-        pipe = PipelinedVerifier(backends, dist, coll_dev, depth, equal_shards=True)
+        pipe = PipelinedVerifier(backends, dist, coll_dev, depth, equal_shards=True, force_collectives=args.force_collectives)
     # every batch is a different permutation of the rank's shard (different transcript and r), at its own HBM address:
     # one variant (G x n blobs = G x 128 MiB) per handle, so the groups in flight stream disjoint memory
     gen = torch.Generator(device="cpu").manual_seed(7 + rank)
@@ -674,7 +712,7 @@ def main():
 
         def seq_steps(k, tm=None):
             for _ in range(k):
-                if world == 1:
+                if not use_pipe:
                     ok = api.KzgProof.verify_blob_kzg_proof_batch_device(d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n, settings)
                 else:
                     ok = verify_blob_kzg_proof_batch_sharded((d_blobs.data_ptr(), d_c.data_ptr(), d_p.data_ptr(), n), n, backend0, dist, coll_dev, timings=tm)
@@ -688,11 +726,11 @@ def main():
         single = {"value": round(n * world * KS / seq_elapsed, 2), "unit": "blobs/s", "ms_per_step": round(seq_elapsed / KS * 1e3, 4),
                   "steps": KS, "what": "one verify_blob_kzg_proof_batch call of %d device-resident blobs at a time%s"
                                        % (n * world, "" if world == 1 else ", sharded by blob over %d ranks (transcript hashed once on rank 0)" % world),
-                  "stage_ms_rank0": {k[:-2] + "_ms": round(v / KS * 1e3, 4) for k, v in stage_s.items()} if world > 1 else None,
+                  "stage_ms_rank0": {k[:-2] + "_ms": round(v / KS * 1e3, 4) for k, v in stage_s.items()} if use_pipe else None,
                   "kernel_ms": {"k_blob_challenge": round(seq_tm[5], 4), "k_blob_evaluate": round(seq_tm[4], 4),
                                 "k_g1_decode_multiples": round(seq_tm[6], 4), "k_msm": round(seq_tm[2], 4),
                                 "k_slp_run(pairing)": round(seq_tm[3], 4)}}
-        if world == 1 and n <= 4096:
+        if not use_pipe and n <= 4096:
             import ctypes as C
 
             h_c, h_p = b"".join(cs), b"".join(ps)
@@ -729,6 +767,43 @@ def main():
                                             "(chunked copies on a copy stream overlapped with the previous chunk's verification); first_pass = the same "
                                             "call on never-touched pages" % (NB, n)}}
             del h_many
+            # ONE reference-shaped call with a LARGE Vec<Blob> (src/kzg_proof.rs:472-525; an unchanged caller does not restructure its blobs
+            # into launch groups): 8 192 and 32 768 blobs through kzg_verify_blob_kzg_proof_batch from pageable host memory, and
+            # device-resident through kzg_verify_blob_kzg_proof_batch_device - next to the 1 024-blob figures above
+            large = []
+            for nl in (8192, 32768):
+                rl = nl // n
+                hb = np.ascontiguousarray(np.broadcast_to(h_blobs, (rl,) + h_blobs.shape)).reshape(nl, -1)   # pageable, 1 / 4 GiB
+                hc_l, hp_l = h_c * rl, h_p * rl
+                tsl, kms = [], None
+                for _ in range(4):
+                    t0 = time.perf_counter()
+                    api._chk(api.lib().kzg_verify_blob_kzg_proof_batch(C.byref(ok), hb.ctypes.data_as(C.c_char_p), hc_l, hp_l, nl, settings._h))
+                    tsl.append(time.perf_counter() - t0)
+                    if not ok.value:
+                        raise SystemExit("verification of a valid synthetic batch returned false (large host call)")
+                host_ms = sorted(tsl[1:])[1] * 1e3
+                db = torch.from_numpy(hb).to(dev)
+                dc_l = torch.frombuffer(bytearray(hc_l), dtype=torch.uint8).to(dev)
+                dp_l = torch.frombuffer(bytearray(hp_l), dtype=torch.uint8).to(dev)
+                torch.cuda.synchronize()
+                tsd = []
+                for _ in range(4):
+                    t0 = time.perf_counter()
+                    okd = api.KzgProof.verify_blob_kzg_proof_batch_device(db.data_ptr(), dc_l.data_ptr(), dp_l.data_ptr(), nl, settings)
+                    tsd.append(time.perf_counter() - t0)
+                    if not okd:
+                        raise SystemExit("verification of a valid synthetic batch returned false (large device call)")
+                ltm = settings.last_timings()
+                dev_ms = sorted(tsd[1:])[1] * 1e3
+                large.append({"blobs": nl, "host_pageable": {"ms": round(host_ms, 3), "blobs_per_s": round(nl / host_ms * 1e3, 1), "pcie_GBps": round(nl * (BYTES_PER_BLOB + 96) / host_ms / 1e6, 2)},
+                              "device_resident": {"ms": round(dev_ms, 3), "blobs_per_s": round(nl / dev_ms * 1e3, 1),
+                                                  "kernel_ms": {"k_blob_challenge": round(ltm[5], 4), "k_blob_evaluate": round(ltm[4], 4), "k_g1_decode_multiples": round(ltm[6], 4),
+                                                                "k_msm": round(ltm[2], 4), "k_slp_run(pairing)": round(ltm[3], 4)}}})
+                del db, dc_l, dp_l, hb
+                torch.cuda.empty_cache()
+            end2end["large_calls"] = {"what": "ONE kzg_verify_blob_kzg_proof_batch call (one transcript, one r, one pairing) of a large Vec<Blob>: median of 3 calls after one "
+                                              "warm-up; the blobs are the 1 024 valid synthetic blobs repeated (a batch may hold a blob twice)", "calls": large}
     # ---- the kernels ALONE on the chip: one launch group on a single-stream handle, nothing else in flight.  With several
     # groups in flight a kernel's interval is its residency (how long it shared the chip), not its cost.
     standalone = None
@@ -865,6 +940,29 @@ def main():
             if not args.no_configs:
                 configs = config_legs(settings, torch, dev, no_cpu=args.no_cpu_baseline)
     backend_name = dist.get_backend() if dist else None
+    pipe_check = rank_stats = None
+    if pipe is not None:
+        # the negative control THROUGH THE PIPELINED PATH: one group of the timed shape with one proof swapped for another blob's in
+        # batch G // 2 - that batch false on every rank, every other batch true (src/kzg_proof.rs:436-444)
+        v0 = variants[0]
+        bad_b = G // 2
+        i = bad_b * n + n // 2
+        keep_p = v0[2][i].clone()
+        v0[2][i] = v0[2][(i + 1) % (n * G)] if not torch.equal(v0[2][i], v0[2][(i + 1) % (n * G)]) else v0[2][(i + 2) % (n * G)]
+        torch.cuda.synchronize()
+        res_bad = pipe.run([((v0[0].data_ptr(), v0[1].data_ptr(), v0[2].data_ptr(), n), G)])[0]
+        v0[2][i] = keep_p
+        torch.cuda.synchronize()
+        res_ok = pipe.run([((v0[0].data_ptr(), v0[1].data_ptr(), v0[2].data_ptr(), n), G)])[0]
+        pipe_check = {"poisoned_batch": bad_b, "how": "one proof of this rank's shard replaced by another blob's (a valid G1 point)",
+                      "results": [r for r in res_bad], "passed": list(res_bad) == [b != bad_b for b in range(G)] and all(r is True for r in res_ok)}
+        # every rank's host-side stage split (per step, warm-up groups included), gathered on rank 0
+        mine = dict(pipe.stats, rank=rank)
+        rank_stats = [None] * world
+        if world > 1:
+            dist.all_gather_object(rank_stats, mine)
+        else:
+            rank_stats = [mine]
     if dist:
         # every rank leaves its GPU before rank 0 reports (and, at N > 1, drives all of them from one process)
         del variants, d_blobs
@@ -875,110 +973,28 @@ def main():
         dist.destroy_process_group()
     if rank != 0:
         return
-    # The dominant kernel: the one that costs most when it has the chip to itself (stand-alone group above); without that
-    # measurement, the largest VALU instruction count in the newest committed PMC profile, then the largest live interval.
-    pmc_file, pmc = load_pmc()
-    prof = (pmc or {}).get("kernels", {})
-    knames = ("k_blob_challenge", "k_blob_evaluate", "k_g1_decode_multiples", "k_msm", "k_slp_run(pairing)")
-    if standalone:
-        dom = max(knames, key=lambda k: standalone[k])
-        dom_source = "largest stand-alone duration in this run (one launch group alone on a single-stream handle)"
-    elif all(PMC_NAME[k] in prof for k in ("k_blob_challenge", "k_blob_evaluate")):
-        dom = max(kernels, key=lambda k: prof.get(PMC_NAME[k], {}).get("SQ_INSTS_VALU", 0))
-        dom_source = "largest SQ_INSTS_VALU in profiles/" + pmc_file
-    else:
-        dom = max(kernels, key=kernels.get)
-        dom_source = "largest live interval (no matching PMC profile)"
-    units = n * G
-    stamped = dom == "k_blob_challenge" and kernels[dom] > 0   # the throughput-form challenge kernel stamps its own interval
-    launch_ms = kernels[dom] if stamped or not standalone else standalone[dom]
-    achieved = ALG_BYTES[dom] * units / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    sa_ms = standalone[dom] if standalone else None
-    sa_achieved = ALG_BYTES[dom] * units / (sa_ms * 1e-3) / 1e9 if sa_ms else None
-    # HBM traffic of that kernel and the VALU instruction counts of all kernels come from the PMC passes committed under
-    # profiles/ (tools/prof/collect_round.sh; rocprofv3 --pmc cannot run inside this process).  They are per launch of
-    # `blobs_per_launch` blobs there; if that differs from this run's launch size the figure is scaled and SAYS so.
-    traffic, traffic_source, valu, path_ratio = None, None, None, None
+    # ---- roofline / path / valu: assembled by kzg_rs_amd/benchline.py (a pure function of this measurement and the PMC profile under
+    # profiles/; its docstring states the dominance rule and what every column means; tests/test_benchline.py checks its arithmetic)
+    from kzg_rs_amd import benchline
+    from kzg_rs_amd import build as kbuild
+    pmc_file, pmc = benchline.load_pmc(ROOT)
     try:
-        pk = prof.get(PMC_NAME[dom])
-        if pk and "hbm_bytes_corrected" in pk:
-            same = pmc["blobs_per_launch"] == units
-            traffic = round(pk["hbm_bytes_corrected"] * units / pmc["blobs_per_launch"])
-            traffic_source = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 gfx950 correction, collected on a launch of "
-                              "%d blobs - %s" % (pmc_file, pmc["blobs_per_launch"], "the same launch size as this run, not re-measured by it" if same else
-                                                 "EXTRAPOLATED linearly to this run's %d blobs per launch" % units))
-        path = list(PMC_NAME.values()) + ["kzg::k_msm_combine", "kzg::k_msm_combine_lanes", "kzg::k_batch_scalars", "kzg::k_glv_split", "kzg::k_mult_to_affine29",
-                                           "kzg::k_eval_powers", "kzg::k_eval_finish", "kzg::k_msm_reduce<false>", "kzg::k_msm_reduce<true>"]
-        insts = sum(prof[k].get("SQ_INSTS_VALU", 0) for k in path if k in prof)
-        per_blob = insts / pmc["blobs_per_launch"]  # wave-instructions per blob, all kernels of the path
-        simds, clock = 1024, 2.4e9
-        valu = {"wave_insts_per_blob": round(per_blob), "insts_per_cycle_per_simd": round(per_blob * (n * G * K / elapsed) / (simds * clock), 4),
-                "cycles_per_inst": round((simds * clock) / (per_blob * (n * G * K / elapsed)), 3),
-                "shader_clock_mhz_measured": round(shader_mhz, 1) if shader_mhz else None,
-                "cycles_per_inst_at_measured_clock": round((simds * shader_mhz * 1e6) / (per_blob * (n * G * K / elapsed)), 3) if shader_mhz else None,
-                "ceiling_insts_per_cycle_per_simd": {"multiply_add_kernels (evaluate, decode, MSM window, MSM reduce)": 0.238, "sha256 (k_blob_challenge)": 0.256},
-                "note": "insts_per_cycle_per_simd / cycles_per_inst assume the nominal 2.4 GHz; shader_clock_mhz_measured is what the SIMDs ran at during "
-                        "the timed region (s_memtime / s_memrealtime stamped by every wave of k_blob_challenge) and cycles_per_inst_at_measured_clock "
-                        "the figure to hold against the ceilings.  VALU wave-instructions issued per SIMD cycle at the measured throughput (SQ_INSTS_VALU of every kernel of the path, profiles/"
-                        + pmc_file + ").  Ceilings per kernel class, from the builder's microbenchmarks: the multiply-add kernels are v_mad_u64_u32 / "
-                        "carry-chain code at 4.2 cycles per wave-instruction on a saturated SIMD = 0.238 (profiles/r1_issuebench_valu_issue_cost.txt; "
-                        "with the 2-4 wavefronts per SIMD their register budgets allow: 5.5 / 5.15 / 4.9 cycles, profiles/r3_depbench_mad_issue_vs_occupancy.txt); "
-                        "the SHA-256 kernel mixes 4.2-cycle rotates with 2.4-cycle logic at 3.9 cycles = 0.256 (profiles/r1_shabench_sha256_compress.txt)"}
-        path_bytes = sum(prof[k].get("hbm_bytes_corrected", 0) for k in path if k in prof)
-        path_ratio = round(path_bytes / (PATH_ALG_BYTES * pmc["blobs_per_launch"]), 3)
-    except Exception:
-        pass
-    # ---- every big kernel of the path: its cost alone on the chip, its residency in the timed region, its algorithmic bytes and
-    # how close its instruction stream runs to the issue ceiling of its instruction mix
-    CEIL = {"k_blob_challenge": 3.9, "k_blob_evaluate": 4.2, "k_g1_decode_multiples": 4.2, "k_msm_window": 4.2}   # cycles per wave-instruction, builder's microbenchmarks
-    ALG = {"k_blob_challenge": ALG_BYTES["k_blob_challenge"], "k_blob_evaluate": ALG_BYTES["k_blob_evaluate"],
-           "k_g1_decode_multiples": ALG_BYTES["k_g1_decode_multiples"], "k_msm_window": ALG_BYTES["k_msm"]}
-    PMCN = dict(PMC_NAME, k_msm_window=PMC_NAME["k_msm"])
-    kernel_rows, mix_num, mix_den = [], 0.0, 0.0
+        kkey = kbuild.kernel_key()
+    except BaseException:
+        kkey = None
+    n_chal = cnt + warm_cnt + solo_cnt + sc_cnt
+    measurement = {
+        "n": n, "G": G, "K": K, "F": F, "world": world, "elapsed_s": elapsed, "shader_mhz": shader_mhz,
+        "in_flight_ms": {k: v for k, v in in_flight.items() if v}, "stamp_cnt": stamp_cnt, "stamp_sum_ms": stamp_sum,
+        "other_stamp_sum_ms": other_stamps, "other_stamp_cnt": other_stamp_cnt,
+        "solo_stamps_ms": {k: v for k, v in (solo_stamps or {}).items() if v} or None,
+        "standalone_event_ms": standalone,
+        "challenge_event_population": {"all_launches_ms": (sums[5] + warm_sum5 + solo_sums[5] + sc_sums[5]) / n_chal if n_chal and kernels["k_blob_challenge"] > 0 else None,
+                                       "launches": n_chal if kernels["k_blob_challenge"] > 0 else None,
+                                       "incl_warmup_ms": (sums[5] + warm_sum5) / max(cnt + warm_cnt, 1) if kernels["k_blob_challenge"] > 0 else None},
+    }
+    blocks = benchline.assemble(measurement, pmc_file, pmc, kkey)
     clock_hz = (shader_mhz or 2400.0) * 1e6
-    for kname in ("k_blob_challenge", "k_blob_evaluate", "k_g1_decode_multiples", "k_msm_window"):
-        sa = (solo_stamps or {}).get(kname) or None
-        fl = in_flight.get(kname) or None
-        pk = prof.get(PMCN[kname], {})
-        insts = pk.get("SQ_INSTS_VALU")
-        scale = units / pmc["blobs_per_launch"] if pmc else 1.0
-        n_all = stamp_cnt + other_stamp_cnt
-        all_ms = (stamp_sum.get(kname, 0.0) + other_stamps.get(kname, 0.0)) / n_all if n_all else None
-        row = {"kernel": kname, "units_per_launch": units, "algorithmic_bytes_per_launch": ALG[kname] * units,
-               "standalone_ms": round(sa, 4) if sa else None, "in_flight_ms": round(fl, 4) if fl else None,
-               # every launch of this size in the process (warm-up, timed, stand-alone and self-check groups): the population behind the
-               # kernel's launches of this grid in a rocprofv3 kernel trace of this command (profiles/<round>_kernel_trace_by_grid.json)
-               "all_launches_ms": round(all_ms, 4) if all_ms else None, "launches": n_all,
-               "achieved_standalone_GBps": round(ALG[kname] * units / sa / 1e6, 2) if sa else None,
-               "frac_standalone": round(ALG[kname] * units / sa / 1e6 / HBM_PEAK_GBS, 6) if sa else None,
-               "achieved_in_flight_GBps": round(ALG[kname] * units / fl / 1e6, 2) if fl else None,
-               "frac_in_flight": round(ALG[kname] * units / fl / 1e6 / HBM_PEAK_GBS, 6) if fl else None,
-               "hbm_traffic_bytes": round(pk["hbm_bytes_corrected"] * scale) if "hbm_bytes_corrected" in pk else None,
-               "hbm_traffic_ratio": round(pk["hbm_bytes_corrected"] * scale / (ALG[kname] * units), 3) if "hbm_bytes_corrected" in pk else None,
-               "valu_wave_insts_per_launch": round(insts * scale) if insts else None,
-               "cycles_per_inst_standalone": round(sa * 1e-3 * clock_hz * 1024 / (insts * scale), 3) if sa and insts else None,
-               "issue_ceiling_cycles_per_inst": CEIL[kname]}
-        if insts:
-            mix_num += insts * CEIL[kname]
-            mix_den += insts
-        kernel_rows.append(row)
-    for kname, pname, sa_ms in (("k_msm_reduce", "kzg::k_msm_reduce<false>", None), ("k_slp_run(pairing)", PMC_NAME["k_slp_run(pairing)"], (standalone or {}).get("k_slp_run(pairing)"))):
-        pk = prof.get(pname, {})
-        scale = units / pmc["blobs_per_launch"] if pmc else 1.0
-        ms = sa_ms or pk.get("ms_single_stream")
-        insts = pk.get("SQ_INSTS_VALU")
-        kernel_rows.append({"kernel": kname, "units_per_launch": units, "algorithmic_bytes_per_launch": 0, "standalone_ms": round(ms, 4) if ms else None,
-                            "standalone_ms_source": "HIP events on a single-stream handle, this run" if sa_ms else "kernel-trace duration in profiles/%s (not stamped)" % pmc_file,
-                            "in_flight_ms": None, "valu_wave_insts_per_launch": round(insts * scale) if insts else None,
-                            "cycles_per_inst_standalone": round(ms * 1e-3 * clock_hz * 1024 / (insts * scale), 3) if ms and insts else None,
-                            "issue_ceiling_cycles_per_inst": 4.2,
-                            "note": "reads the bucket sums k_msm_window wrote (no input bytes of its own): latency chain of ~28 point additions per window slot"
-                            if kname == "k_msm_reduce" else "one wavefront per pairing instance, LDS-resident straight-line program: dependency-depth bound"})
-        if insts:
-            mix_num += insts * 4.2
-            mix_den += insts
-    mix_ceiling = mix_num / mix_den if mix_den else None
-    path_gbps = PATH_ALG_BYTES * n * G * K / elapsed / 1e9   # per GPU
     out = {
         "metric": "blobs/sec verify_blob_kzg_proof_batch",
         "value": round(n * world * G * K / elapsed, 2),
@@ -1000,51 +1016,14 @@ def main():
                    "blobs_per_gpu_per_batch": n, "batch": n * world, "batches_per_step": G, "blobs_per_step": n * world * G,
                    "parallelism": "shard-by-blob x%d" % world, "groups_in_flight": F,
                    "entry_point": "kzg_verify_blob_kzg_proof_batch_groups_device: ONE C call for all %d launch groups of the timed region, %d in flight "
-                                  "inside the library" % (K, F) if world == 1 else
-                                  "kzg_shard_*_launch/_wait phases driven by kzg_rs_amd.distributed.PipelinedVerifier, one process per GPU"},
-        # launch_ms / achieved / frac: the kernel's average duration over the launches of the timed region - what rocprofv3
-        # --kernel-trace --stats reports for this command (with %d groups in flight that is its RESIDENCY: it shares the chip);
-        # standalone_ms / frac_standalone: the same kernel with the chip to itself - its cost.
-        "roofline": {"bound": "valu-issue", "bound_note": "the bound that binds is VALU issue (wide-integer modular arithmetic and SHA-256: ~106 k wave-instructions per "
-                     "blob against 131 KB of input); achieved / peak / frac below are the HBM figures BASELINE.json's metric asks for, for the dominant kernel; "
-                     "kernels[] carries every big kernel with its cycles per instruction against the issue ceiling of its instruction mix",
-                     "kernel": dom, "kernel_chosen_by": dom_source, "units_per_launch": units, "launch_ms": round(launch_ms, 4),
-                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                     "standalone_ms": round(sa_ms, 4) if sa_ms else None,
-                     "achieved_standalone": round(sa_achieved, 3) if sa_achieved else None,
-                     "frac_standalone": round(sa_achieved / HBM_PEAK_GBS, 6) if sa_achieved else None,
-                     "traffic": traffic, "traffic_source": traffic_source,
-                     "algorithmic_bytes_per_launch": ALG_BYTES[dom] * units,
-                     "launch_ms_incl_warmup": round((sums[5] + warm_sum5) / max(cnt + warm_cnt, 1), 4) if stamped else None,
-                     # every launch of this kernel at this size in the process: warm-up + timed groups in flight, the stand-alone groups and
-                     # the groups of the self check - the population behind the kernel's AverageNs in a rocprofv3 --stats of this command
-                     "launch_ms_all_launches": round((sums[5] + warm_sum5 + solo_sums[5] + sc_sums[5]) / max(cnt + warm_cnt + solo_cnt + sc_cnt, 1), 4) if stamped else None,
-                     "launches": cnt + warm_cnt + solo_cnt + sc_cnt if stamped else None,
-                     "launch_ms_source": ("live: the kernel's own execution interval, stamped inside the kernel with s_memrealtime (first wavefront in, last "
-                                          "wavefront out) and averaged over the %d launch groups of the timed region, %d groups in flight (residency, not cost); "
-                                          "launch_ms_incl_warmup averages the %d warm-up groups in as well - the population rocprofv3 --kernel-trace --stats of "
-                                          "this same command averages into the kernel's AverageNs; standalone_ms: the same stamp from one launch group alone on "
-                                          "the chip" % (cnt, F, warm_cnt)) if stamped else
-                                         "live: HIP events around the kernel on a single-stream handle, one launch group alone on the chip",
-                     "kernels": kernel_rows,
-                     "kernels_note": "standalone_ms / in_flight_ms: the kernel's own interval, stamped inside the kernel with s_memrealtime (first wavefront in, last "
-                                     "out): one launch group alone on a single-stream handle | averaged over the %d launch groups of the timed region with %d in flight "
-                                     "(residency: the kernel shares the chip).  cycles_per_inst_standalone = standalone_ms x the measured shader clock x 1 024 SIMDs / "
-                                     "SQ_INSTS_VALU (profiles/%s), to hold against issue_ceiling_cycles_per_inst (microbenchmarks: 4.2 for v_mad_u64_u32 / carry-chain "
-                                     "code, 3.9 for SHA-256)" % (stamp_cnt, F, pmc_file),
-                     "note": "path is integer-ALU / latency bound, not HBM bound (DESIGN.md 4)"},
-        "path": {"algorithmic_bytes_per_blob": PATH_ALG_BYTES, "algorithmic_GBps": round(path_gbps, 2), "frac": round(path_gbps / HBM_PEAK_GBS, 6),
-                 "hbm_traffic_ratio": path_ratio,
-                 "valu_mix_ceiling_cycles_per_inst": round(mix_ceiling, 3) if mix_ceiling else None,
-                 "valu_frac_of_mix_ceiling": round(mix_ceiling / valu["cycles_per_inst_at_measured_clock"], 4)
-                 if mix_ceiling and valu and valu.get("cycles_per_inst_at_measured_clock") else None,
-                 "note": "whole path per GPU: 131 232 algorithmic bytes per blob x blobs/s; hbm_traffic_ratio = PMC HBM bytes of every kernel of the path / "
-                         "algorithmic bytes (profiles/%s; the blob is streamed twice: hash, then evaluate)" % pmc_file},
-        "valu": valu,
-        "kernel_ms_standalone": {k: round(v, 4) for k, v in standalone.items()} if standalone else None,
-        "kernel_ms_in_flight": dict({k: round(v, 4) for k, v in in_flight.items()},
-                                    note="in-kernel stamps (first wavefront in, last wavefront out), averaged over the timed region's launch groups, %d in "
-                                         "flight: residency beside the other groups, not cost - see kernel_ms_standalone / roofline.kernels" % F),
+                                  "inside the library" % (K, F) if not use_pipe else
+                                  "kzg_shard_*_launch/_wait phases driven by kzg_rs_amd.distributed.PipelinedVerifier, one process per GPU%s"
+                                  % (" (a world of ONE rank: --force-collectives)" if world == 1 else "")},
+        "roofline": blocks["roofline"],
+        "path": blocks["path"],
+        "valu": blocks["valu"],
+        "kernel_ms_standalone": blocks["kernel_ms_standalone"],
+        "kernel_ms_in_flight": blocks["kernel_ms_in_flight"],
         "self_check": self_check,
         "single_batch": single,
         "end_to_end": end2end,
@@ -1057,21 +1036,51 @@ def main():
     }
     if configs:   # cycles per VALU instruction of the two config kernels: this run's time x the measured clock / the instruction counts of the committed PMC profile
         try:
-            cp = json.load(open(os.path.join(ROOT, "profiles", "r5_config_pmc.json")))["kernels"]
-            for leg, kn, ms_key in (("config3", "kzg::k_blob_evaluate_t<true>", "ms"), ("config4", "kzg::k_msm_window<kzg::Curve29Aff, true>", None)):
+            cfile = "r6_config_pmc.json"
+            cj = json.load(open(os.path.join(ROOT, "profiles", cfile)))
+            cp = cj["kernels"]
+            fresh = kkey is not None and cj.get("kernel_key") == kkey
+            for leg, kn, ms_key in (("config3", "kzg::k_blob_evaluate_t<true>", "ms"), ("config4", "kzg::k_fb_window", None)):
+                if leg not in configs or kn not in cp:
+                    continue
+                if not fresh:
+                    configs[leg]["roofline"]["pmc_stale"] = "profiles/%s was collected on kernel key %s, this tree is %s: counters NOT used" % (cfile, cj.get("kernel_key"), kkey)
+                    continue
                 insts = cp[kn]["SQ_INSTS_VALU"]
                 ms = configs[leg]["ms"] if ms_key else cp[kn]["ms_single_stream"]
                 configs[leg]["roofline"].update({
                     "valu_wave_insts": round(insts), "valu_cycles_per_inst": round(ms * 1e-3 * clock_hz * 1024 / insts, 3), "issue_ceiling_cycles_per_inst": 4.2,
-                    "valu_source": "profiles/r5_config_pmc.json SQ_INSTS_VALU of the same launch size; %s; shader clock %s" % (
-                        "this run's ms" if ms_key else "the window kernel's own duration in that profile (%.2f ms: ms_msm above also holds split, reduction, folds, combine)" % ms,
+                    "valu_source": "profiles/%s (kernel key %s = this tree's) SQ_INSTS_VALU of the same launch size; %s; shader clock %s" % (
+                        cfile, kkey, "this run's ms" if ms_key else "the bucket kernel's own duration in that profile (%.2f ms: ms_msm above also holds the partition passes, folds and reductions)" % ms,
                         "%.0f MHz measured in this run's timed region" % shader_mhz if shader_mhz else "2 400 MHz nominal"),
                     "hbm_traffic_bytes": cp[kn].get("hbm_bytes_corrected"), "sq_wait_any_frac": round(cp[kn]["SQ_WAIT_ANY"] / cp[kn]["SQ_WAVE_CYCLES"], 3)})
         except Exception:
             pass
-    if world > 1:
+    out["preflight"] = preflight
+    if use_pipe:
         g = max(pipe.stats["groups"], 1)  # warm-up groups included; per-step averages of THIS rank's host time
+        bulk_once = G % world == 0
+        shard_1gpu = None
+        try:
+            shard_1gpu = json.load(open(os.path.join(ROOT, "profiles", "r6_config5_shard_1gpu.json")))
+        except Exception:
+            pass
         out["multi_gpu"] = {"ranks": world, "backend": backend_name, "rccl_ranks": world if backend_name == "nccl" else 0,
+                            "exchange_ran": {"exchange1": ("all_to_all_single of [src rank][%d batches][%d blobs] x 160 B records to the batch's owner, then all_gather of r "
+                                                           "(32 B per batch) + error flags" % (G // world, n)) if bulk_once else
+                                                          "all_gather of every rank's records (batches per step not divisible by the rank count)",
+                                             "exchange2": "all_gather of %d x 288 B partial sums (A_k, B_k), folded on every rank" % G,
+                                             "transport": "RCCL (torch.distributed backend nccl) on device buffers" if backend_name == "nccl" else
+                                                          "gloo on host buffers (test rig: ranks share one GPU)",
+                                             "world_of_one": world == 1},
+                            "per_rank_stage_ms_per_step": [{"rank": r_["rank"], "groups": r_["groups"], "r_hash_ms": round(r_["r_hash_s"] / max(r_["groups"], 1) * 1e3, 4),
+                                                            "exchange1_ms": round(r_["exchange1_s"] / max(r_["groups"], 1) * 1e3, 4),
+                                                            "exchange2_ms": round(r_["exchange2_s"] / max(r_["groups"], 1) * 1e3, 4)} for r_ in (rank_stats or []) if r_],
+                            "pipe_check": pipe_check,
+                            "efficiency_vs": {"value": round(world * shard_1gpu["value"], 2), "unit": "blobs/s", "one_gpu_value": shard_1gpu["value"],
+                                              "what": "N x the ONE-GPU figure of this same shard shape through this same code path (profiles/r6_config5_shard_1gpu.json: "
+                                                      "bench.py --workload config5 --force-collectives on one MI355X, %s) - the like-for-like base of a scaling curve; "
+                                                      "configs1's 1 024-blob batches at N = 1 are a different workload" % shard_1gpu.get("measured", "")} if shard_1gpu else None,
                             "transcript_hash": "once per batch: rank j hashes batches [jB/N, (j+1)B/N) of every step" if G % world == 0 else
                                                "every rank hashes every batch (batches per step not divisible by the rank count)",
                             "r_hash_ms_per_step": round(pipe.stats["r_hash_s"] / g * 1e3, 4),
@@ -1083,11 +1092,59 @@ def main():
         # ONE process over all the GPUs through a multi-device handle and the reference's call shape (the ranks have left the
         # GPUs by now).  A child process: a failure or a hang there costs this leg, not the line.
         sp = os.environ.get("KZG_BENCH_SINGLE_PROCESS", "1")
-        if sp != "0" and (not share or sp == "force"):  # (ranks sharing one GPU: only when a test asks for it - the list then names device 0 `world` times)
+        if world > 1 and sp != "0" and (not share or sp == "force"):  # (ranks sharing one GPU: only when a test asks for it - the list then names device 0 `world` times)
             out["multi_gpu"]["single_process"] = run_single_process_child(",".join("0" if share else str(i) for i in range(world)), n)
+    if world == 1 and not use_pipe and not args.no_configs and not args.no_shard_leg:
+        # BASELINE configs[4]'s SHARD SHAPE on this one GPU, through the code path --gpus N runs (a child process: this one gives
+        # its memory back first; a failure or a hang there costs the leg, not the line)
+        del variants, d_blobs
+        torch.cuda.empty_cache()
+        out.setdefault("configs", {})
+        if out["configs"] is None:
+            out["configs"] = {}
+        out["configs"]["config5_shard"] = run_shard_leg_child(args.steps, args.warmup)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(blobs, cs, ps, synth.synthetic_setup()[1], args.cpu_sample)
     print(json.dumps(out))
+
+
+def run_shard_leg_child(steps, warmup, timeout=420):
+    """configs.config5_shard: `bench.py --gpus 1 --workload config5 --force-collectives` in a child process - 8 batches x 32 768 blobs
+    per step on ONE GPU through PipelinedVerifier (kzg_shard_* phases, the records all-to-all, r as 32 bytes, the all-gather of
+    288-byte partial sums: a world of one rank over RCCL), i.e. the N = 1 point of the curve `--gpus N` draws."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", "config5", "--force-collectives", "--steps", str(steps), "--warmup", str(warmup),
+           "--no-latency", "--no-self-check", "--no-cpu-baseline", "--no-configs", "--no-concurrent"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+        wall = time.perf_counter() - t0
+        line = None
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                line = json.loads(ln)
+                break
+        if line is None:
+            return {"error": "rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-800:])}
+        mg = line.get("multi_gpu") or {}
+        rk = (mg.get("per_rank_stage_ms_per_step") or [{}])[0]
+        return {"workload": line["config"]["workload"], "entry_point": line["config"]["entry_point"], "value": line["value"], "unit": line["unit"],
+                "ms_per_step": line["ms_per_step"], "steps": line["steps"], "warmup": line["warmup"], "blobs_per_step": line["config"]["blobs_per_step"],
+                "batches_per_step": line["config"]["batches_per_step"], "blobs_per_gpu_per_batch": line["config"]["blobs_per_gpu_per_batch"],
+                "r_hash_s": round(rk.get("r_hash_ms", 0.0) / 1e3, 6), "exchange1_s": round(rk.get("exchange1_ms", 0.0) / 1e3, 6), "exchange2_s": round(rk.get("exchange2_ms", 0.0) / 1e3, 6),
+                "stage_note": "host seconds per step of the one rank: r_hash = SHA-256 of the step's 8 transcripts of 32 768 x 160 B (42 MB) on the host pool, overlapped with the "
+                              "GPU phases of the other groups in flight; exchange 1 / 2 = the collectives (a world of one: the transport is exercised, nothing crosses a link)",
+                "poisoned_batch_false": (mg.get("pipe_check") or {}).get("passed"), "pipe_check": mg.get("pipe_check"),
+                "exchange_ran": mg.get("exchange_ran"), "backend": mg.get("backend"), "preflight": line.get("preflight"),
+                "roofline": {k: line["roofline"].get(k) for k in ("kernel", "launch_ms", "frac", "frac_path", "frac_of_binding_bound")},
+                "child_wall_s": round(wall, 1),
+                "what": "BASELINE.json configs[4]'s shard shape on ONE GPU: 8 batches x 32 768 blobs per step = 262 144 blobs, the per-GPU work of every step at any N, "
+                        "through the one-process-per-GPU path (PipelinedVerifier with force_collectives, world of one rank)"}
+    except Exception as e:  # timeout included
+        return {"error": repr(e)[:800]}
 
 
 def run_single_process_child(devices, n, timeout=300):

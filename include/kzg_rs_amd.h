@@ -141,7 +141,9 @@ KzgRet kzg_verify_kzg_proofs(bool *ok_out, uint8_t *err_out, const uint8_t *comm
  * &[G1Affine] / &[Scalar]; across the C ABI they are n*48 compressed bytes and n*32 big-endian canonical bytes in
  * HOST memory, decoded on the device with the same checks as Bytes48/Bytes32 decoding (:17-43) - an undecodable
  * point or a non-canonical scalar is KZG_BADARGS.  n == 0 -> *ok = true (both sides are the identity).
- * 2 <= n <= 256 (KZG_OPTIONS small_batch_pairings_max): the same answer as the CONJUNCTION of n one-proof checks, one pairing
+ * DEFAULT FOR SMALL BATCHES - a different algorithm from the reference's, same answer: 2 <= n <= 256 (KZG_OPTIONS
+ * small_batch_pairings_max, default 256; small_batch_pairings_max=0 runs the reference's random linear combination :399-444 at
+ * every size) returns the CONJUNCTION of n one-proof checks, one pairing
  * per tuple on a CU of its own (1.7-2.6 ms against 2.9 ms for decode -> MSM -> pairing).  The combination is a probabilistic
  * test of exactly that conjunction: it holds whenever the conjunction does, and could hold without it only if the
  * hash-derived r were a root of a fixed non-zero polynomial of degree < n over Fr (probability < 2^-246). */
@@ -159,10 +161,11 @@ KzgRet kzg_verify_blob_kzg_proof(bool *ok, const uint8_t *blob, const uint8_t co
  * them hashed on up to 16 host threads beside the GPU's point decode - a chain is 2.8 ms on GPU lanes however few blobs
  * there are and 65 us on a SHA-NI core; larger host batches cross PCIe in slices with the chains running on the GPU behind
  * them, and device-resident input always hashes on the GPU.  Field and curve arithmetic is never done on the host.
- * The sizes a beacon node calls this with (the 6-9 blobs of a block; up to KZG_OPTIONS small_batch_pairings_max = 256 host
- * blobs): every blob gets its own pairing, side by side on CUs of their own, and *ok is the conjunction of the n
+ * DEFAULT FOR SMALL BATCHES - a different algorithm from the reference's, same answer: at the sizes a beacon node calls this
+ * with (the 6-9 blobs of a block; 2 <= n <= KZG_OPTIONS small_batch_pairings_max = 256 host blobs) every blob gets its own pairing, side by side on CUs of their own, and *ok is the conjunction of the n
  * verify_blob_kzg_proof verdicts - 1.8-3.2 ms instead of 3.0-3.7 ms; see kzg_verify_kzg_proof_batch for why that is the
- * same answer.  small_batch_pairings_max=0 keeps the combined form at every size. */
+ * same answer.  small_batch_pairings_max=0 keeps the reference's combined form (:399-444, one pairing per batch) at every size;
+ * tests/test_gpu_parity.py checks that the two forms agree on 2 000 seeded mixed batches. */
 KzgRet kzg_verify_blob_kzg_proof_batch(bool *ok, const uint8_t *blobs, const uint8_t *commitments,
                                        const uint8_t *proofs, size_t n, const KzgSettings *s);
 /* Same, with all three arrays already resident in DEVICE memory (HBM) - the form the throughput
@@ -303,9 +306,18 @@ KzgRet kzg_g1_decompress(uint8_t *status_out, uint8_t *xy_out, const uint8_t *po
 /* G1Projective::msm_variable_base (call sites src/kzg_proof.rs:419,429,430): out = sum scalars[i] * points[i];
  * points: n * 48 bytes compressed, must lie in G1 (checked: the MSM uses the GLV endomorphism); scalars: n * 32 bytes
  * big-endian (reduced mod r),
- * out: 48 bytes compressed.  Host pointers.  n <= 2^26 (KZG_BADARGS above).  BASELINE config 4: 2^20 terms in 7.8 ms + 24.5 ms of
- * decompression, subgroup tests and table rows for the 2^20 points. */
+ * out: 48 bytes compressed.  Host pointers.  n <= 2^26 (KZG_BADARGS above).  2^20 terms: 7.8 ms + 24.5 ms of decompression,
+ * subgroup tests and table rows for the 2^20 points (for sums over the setup's own points see kzg_g1_msm_setup). */
 KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t *points48, const uint8_t *scalars, size_t n, const KzgSettings *s);
+/* The same sum over the HANDLE'S OWN G1 Lagrange points (KzgSettings::g1_points, src/trusted_setup.rs:20-26, bit-reversal
+ * permuted as build.rs:79,89-105 leaves them): out = sum_i scalars[i] * g1_points[i mod 4096] - what msm_variable_base computes
+ * at the reference's call sites (src/kzg_proof.rs:419,429,430) when the points are trusted-setup points, and the shape of
+ * BASELINE.json configs[3] ("2^20 trusted-setup points x random Fr scalars").  scalars: n * 32 bytes big-endian (reduced mod r);
+ * host pointers; n <= 2^26.  Needs a handle made from a trusted-setup file (KZG_BADARGS otherwise; KZG_BAD_SETUP when a point is
+ * outside G1).  Nothing is decoded per call - the tables were made when the setup was loaded; from 32 768 terms on the sum takes the
+ * fixed-base form (csrc/msm_fixed.hpp: 16-bit signed windows over rows 2^(16 v) P_j, half the bucket additions of the
+ * variable-base form).  KZG_OPTIONS g1_msm_setup_form = window | fixed forces a form (same result bit for bit). */
+KzgRet kzg_g1_msm_setup(uint8_t out[48], const uint8_t *scalars, size_t n, const KzgSettings *s);
 /* out48[i] = compress(scalars[i] * G1::generator()); scalars n * 32 bytes big-endian (reduced mod r).
  * Prover-side helper used to build synthetic (commitment, proof) pairs under a
  * known-tau test setup (the `G1Affine::generator() * scalar` of src/kzg_proof.rs:388,423). */

@@ -133,6 +133,7 @@ def lib():
         L.kzg_evaluate_polynomials_device.argtypes = [vp, vp, vp, sz, vp]
         L.kzg_g1_decompress.argtypes = [u8, u8, u8, sz, vp]
         L.kzg_g1_msm.argtypes = [u8, u8, u8, sz, vp]
+        L.kzg_g1_msm_setup.argtypes = [u8, u8, sz, vp]
         L.kzg_pairing_check.argtypes = [bp, u8, u8, vp]
         L.kzg_pairings_verify.argtypes = [bp, u8, u8, u8, u8, vp]
         L.kzg_g1_mul_generator.argtypes = [u8, u8, sz, vp]
@@ -576,6 +577,15 @@ def g1_msm(points, scalars, kzg_settings):
     n = len(points)
     out = C.create_string_buffer(48)
     _chk(lib().kzg_g1_msm(out, b"".join(points), b"".join(scalars), n, kzg_settings._h))
+    return out.raw
+
+
+def g1_msm_setup(scalars, kzg_settings):
+    """sum_i scalars[i] * g1_points[i mod 4096] over the handle's own Lagrange points (kzg_g1_msm_setup): scalars = a list of
+    32-byte big-endian values, or one bytes object of n x 32."""
+    raw = scalars if isinstance(scalars, (bytes, bytearray)) else b"".join(scalars)
+    out = C.create_string_buffer(48)
+    _chk(lib().kzg_g1_msm_setup(out, bytes(raw), len(raw) // 32, kzg_settings._h))
     return out.raw
 
 

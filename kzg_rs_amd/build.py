@@ -88,6 +88,13 @@ def _device_key(csrc, flags):
     return h.hexdigest()[:24]
 
 
+def kernel_key(variant=0):
+    """What identifies the KERNELS of a build, wherever the tree lies: the device-side sources in full plus what the device pass sees
+    of the host-only files (_device_key), without the absolute paths of the compile flags.  PMC profiles under profiles/ are stamped
+    with it (tools/prof/pmc_to_json.py) and bench.py flags a profile whose stamp differs from the tree it runs in."""
+    return _device_key(os.path.join(HERE, "csrc"), ["kernel-key", "-DKZG_AB_VARIANTS=%d" % variant])
+
+
 def _kernel_names(obj, stubs):
     """demangled kernel names an object defines (device code object) or launches (host object: its __device_stub__ symbols)"""
     out = subprocess.run([os.path.join(LLVM_BIN, "llvm-readelf"), "-sW", "--demangle", obj], capture_output=True, text=True, check=True).stdout

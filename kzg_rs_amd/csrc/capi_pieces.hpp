@@ -117,16 +117,154 @@ extern "C" KzgRet kzg_g1_decompress(uint8_t* status_out, uint8_t* xy_out, const 
     return fail(KZG_MALLOC, "host buffers of the call");  // (nothing is thrown across the C ABI)
 }
 
-// G1Projective::msm_variable_base for n (point, scalar) pairs in host memory, on the SAME kernels as the verification path's
-// MSM (rounds 1-4 built this entry's tables with the round-1 kernels - k_g1_decode, k_g1_multiples, a format conversion - and
-// accumulated full Jacobian additions from a global sorted list: 20 ns per term at n = 2^20 against the hot path's 7):
-//   decode + subgroup test + table rows in one pass (k_g1_decode_multiples29 -> affine rows through k_mult_to_affine29),
+// ---------------------------------------------------------------- G1Projective::msm_variable_base (call sites src/kzg_proof.rs:419,429,430)
+// Two entry points over one core:
+//   kzg_g1_msm        n (point, scalar) pairs in host memory: decode + subgroup test + table rows of the call's points, then the sum
+//   kzg_g1_msm_setup  n scalars over the HANDLE'S OWN Lagrange points (term i -> g1_points[i mod 4096]; capi_prover.hpp): the tables
+//                     were made when the setup was loaded - no per-call decode - and large sums take the fixed-base form of
+//                     msm_fixed.hpp (16-bit windows, half the bucket additions)
+// The core runs on the SAME kernels as the verification path's MSM (rounds 1-4 built this entry's tables with the round-1
+// kernels and accumulated full Jacobian additions from a global sorted list: 20 ns per term at n = 2^20 against the hot path's 7):
 //   GLV split, then the window kernel in the hot path's SHAPE: the terms are cut into slices of at most 3 072 (a 1 024-blob
 //   batch's output B holds 2 049) - so that every (window, slice) workgroup sorts its 4 x 3 072 list entries in LDS and
 //   adds mixed (affine) entries, 8 windows x 2 S workgroups (the terms are dealt to the kernel's two outputs, halves of one
 //   sum); the S window sums per window are folded by trees of 64 and the 8 windows combined as usual.
-// timings: [2] the MSM (split, windows, reduce, folds, combine), [6] decode + tables.
+// timings: [2] the MSM (split, windows, reduce, folds, combine), [6] decode + tables (0 for the setup form).
 constexpr size_t G1_MSM_SLICE_TERMS = 3072;
+// nothing of a call may stay in flight on the stream when an error path releases the host buffers its copies read or write
+struct StreamDrain {
+    hipStream_t st;
+    ~StreamDrain() {
+        if (st) (void)hipStreamSynchronize(st);
+    }
+};
+// the family's device scratch lives on the handle, grow-only (three or four hipMalloc + hipFree per call stalled every small-call
+// lane of the device: hipFree waits for the whole device)
+static KzgRet g1msm_scratch(const KzgSettings* s, size_t bytes, uint8_t** out) {
+    Workspace& w = s->ws;
+    if (bytes > w.cap_g1msm) {
+        if (w.d_g1msm) (void)hipFree(w.d_g1msm);
+        w.d_g1msm = nullptr;
+        w.cap_g1msm = 0;
+        HIPCHK(hipMalloc(&w.d_g1msm, bytes));
+        w.cap_g1msm = bytes;
+    }
+    *out = w.d_g1msm;
+    return KZG_OK;
+}
+struct G1MsmTables {
+    const void* mult;       // table rows [MSM_CHUNKS][stride]
+    const uint32_t* pflag;  // [stride]: non-zero -> the point adds nothing
+    int stride;
+    bool affine;            // G1Aff29Mem rows (Curve29Aff) | Jacobian rows of the handle's field form
+    bool periodic;          // term i uses point i mod stride (the setup form) | point i
+};
+// the sum of n terms: canonical scalars at ws.d_scalars (destroyed: GLV split in place), compressed result -> out.  The caller holds
+// the handle's lock, has reserved the workspace for (n + 1) / 2 + 1 "blobs" and recorded nothing on ev[2] / ev[3]; returns after the
+// stream has drained.
+static KzgRet g1_msm_core(const KzgSettings* s, size_t n, const G1MsmTables& tb, uint8_t out[48]) {
+    Workspace& w = s->ws;
+    // the terms dealt to the kernel's two outputs: [0, h) and [h, n); slices of at most slice_terms terms (option
+    // g1_msm_slice_terms, default 3 072: 4 x 3 072 list entries = 48 KB of LDS, three workgroups per CU - measured at 2^20 terms
+    // against 2 048: fewer (window, slice) workgroups to reduce and fold), their number a multiple of 4 (the XCD placement of
+    // msm.hpp wants 2 S workgroup layers in eights)
+    static const size_t slice_terms = (size_t)std::max(256L, std::min(3072L, ab_int("g1_msm_slice_terms", (long)G1_MSM_SLICE_TERMS)));
+    const size_t h = (n + 1) / 2;
+    unsigned S = (unsigned)((h + slice_terms - 1) / slice_terms);
+    S = S <= 1 ? 1 : (S + 3) & ~3u;
+    const unsigned W = MSM_WINDOWS / MSM_CHUNKS, gz = 2 * S, gz_pad = gz <= 64 ? gz : (gz + 63) & ~63u;
+    KzgRet rc;
+    if ((rc = msm_save_reserve(s, W, 1, gz)) != KZG_OK) return rc;
+    // From 16 layers on (and while the save area holds them all: ~4 M terms) the tail of a LARGE sum: the slices folded bucket
+    // by bucket, then W slots reduced with four lanes per addition (msm.hpp msm_large_tail) - 0.8 ms instead of 1.55 at 2^20
+    // terms.  fold_per = the layers one thread adds in a row (more: fewer partial sums for the quads, a longer chain; measured at
+    // 344 layers: 6 -> 0.166 + 0.160 ms, 11 -> 0.188 + 0.111, 16 -> 0.264 + 0.115, 22 -> 0.358 + 0.077 for fold + sum).
+    static const int fold_per_opt = (int)std::max(2L, std::min(64L, ab_int("g1_msm_fold_per", 11)));
+    const int fold_per = std::max(fold_per_opt, (int)((gz + MSM_FOLD_MAX_GROUPS - 1) / MSM_FOLD_MAX_GROUPS));
+    int fold_gp = 0;
+    (void)msm_large_tail_groups(gz, fold_per, &fold_gp);
+    const bool large_tail = fp29_enabled() && gz >= 16 && ab_flag("g1_msm_large_tail", true) &&
+                            w.cap_msm_save >= msm_save_layer_bytes(W, 1, MSM_SAVE2_WORDS) * gz;
+    // scratch: window sums [gz_pad][W] | fold level A [gz_pad / 2][W] | fold level B [gz_pad / 4][W] | the large tail's
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t b_ws = up(sizeof(G1Jac) * (size_t)gz_pad * W), b_f0 = up(sizeof(G1Jac) * (size_t)std::max(1u, gz_pad / 2) * W),
+                 b_f1 = up(sizeof(G1Jac) * (size_t)std::max(1u, gz_pad / 4) * W), b_tail = large_tail ? up(msm_large_tail_bytes(W, fold_gp)) : 0;
+    uint8_t* scratch = nullptr;
+    if ((rc = g1msm_scratch(s, b_ws + b_f0 + b_f1 + b_tail, &scratch)) != KZG_OK) return rc;
+    G1Jac* const t_ws = reinterpret_cast<G1Jac*>(scratch);
+    G1Jac* const t_f0 = reinterpret_cast<G1Jac*>(scratch + b_ws);
+    G1Jac* const t_f1 = reinterpret_cast<G1Jac*>(scratch + b_ws + b_f0);
+    uint32_t* const t_tail = reinterpret_cast<uint32_t*>(scratch + b_ws + b_f0 + b_f1);
+    if (gz_pad != gz)  // (Z = 0: the identity) the padding of the window sums up to whole groups of 64
+        HIPCHK(hipMemsetAsync(t_ws + (size_t)gz * W, 0, sizeof(G1Jac) * (size_t)(gz_pad - gz) * W, s->s1));
+    HIPCHK(hipEventRecord(s->ev[2], s->s1));
+    if (n) {
+        hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, (int)n);
+        if (tb.periodic && (size_t)tb.stride == (size_t)FE_PER_BLOB)
+            hipLaunchKernelGGL(k_commit_terms, dim3((unsigned)((2 * h + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar, (int)(2 * h));
+        else
+            hipLaunchKernelGGL(k_plain_terms, dim3((unsigned)((2 * h + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar, (int)(2 * h));
+    }
+    MsmDesc d{};
+    d.mult = const_cast<void*>(tb.mult);
+    d.pflag = const_cast<uint32_t*>(tb.pflag);
+    d.scalars = w.d_scalars;
+    d.term_point = w.d_term_point;  // output 1's list starts at entry max_terms = h: term_point[i] = i (or i mod 4096) serves both
+    d.term_scalar = w.d_term_scalar;
+    d.sorted = w.d_sorted;
+    d.window_sums = t_ws;
+    d.nterms[0] = (int)h;
+    d.nterms[1] = (int)(n - h);
+    d.max_terms = (int)(h ? h : 1);
+    d.stride = tb.stride;
+    d.slices = (int)S;
+    d.chunks = MSM_CHUNKS;
+    d.chunks_per_block = MSM_CHUNKS;  // one workgroup per (window, slice): the four chunks' entries in one sorted list
+    d.flags = (gz & 7) == 0 ? MSM_FLAG_XCD : 0;
+    if (tb.affine) msm_window_launch<Curve29Aff, true>(d, W, 1, gz, w.d_msm_save, w.cap_msm_save, s->s1, !large_tail);
+    else if (fp29_enabled()) msm_window_launch<Curve29, true>(d, W, 1, gz, w.d_msm_save, w.cap_msm_save, s->s1, !large_tail);
+#if KZG_AB_VARIANTS
+    else msm_window_launch<Curve32, true>(d, W, 1, gz, w.d_msm_save, w.cap_msm_save, s->s1);
+#endif
+    if (large_tail) HIPCHK(msm_large_tail(w.d_msm_save, W, gz, fold_per, t_tail, t_ws, s->s1));
+    // window sums [2 S (padded to whole groups of 64 with identities)][W] -> [1][W]: trees over up to 64 slices at a time.  A level
+    // with more than 64 inputs reads them in whole groups of 64: the tail of the last group is zeroed here when the level below
+    // wrote a count that is not a multiple of 64 (gz = 4 160 -> 65 partial sums: round 5 read 63 uninitialised points there)
+    const G1Jac* cur = t_ws;
+    G1Jac* bufs[2] = {t_f0, t_f1};
+    int which = 0;
+    for (unsigned left = large_tail ? 1 : gz_pad; left > 1;) {
+        const unsigned f = std::min(left, 64u), groups = (left + f - 1) / f;
+        if (groups > 64 && (groups & 63)) {
+            const unsigned pad = ((groups + 63) & ~63u) - groups;
+            HIPCHK(hipMemsetAsync(bufs[which] + (size_t)groups * W, 0, sizeof(G1Jac) * (size_t)pad * W, s->s1));
+        }
+        hipLaunchKernelGGL(k_msm_fold_slices, dim3(groups * W), dim3(64), 0, s->s1, cur, bufs[which], (int)f, (int)W);
+        cur = bufs[which];
+        which ^= 1;
+        left = groups;
+    }
+    // 8 windows of one output: the Horner chain with four lanes per doubling / addition (0.8 -> ~0.2 ms of a 2^20-term call)
+    if (fp29_enabled()) hipLaunchKernelGGL(k_msm_combine_quad, dim3(1), dim3(64), 0, s->s1, cur, w.d_ab, (int)W);
+    else hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, cur, w.d_ab, 1, (int)W);
+    HIPCHK(hipEventRecord(s->ev[3], s->s1));
+    hipLaunchKernelGGL(k_jac_compress, dim3(1), dim3(64), 0, s->s1, w.d_ab, w.d_bytes, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, w.d_bytes, 48, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    elapsed(&s->timings[2], s->ev[2], s->ev[3]);
+    return KZG_OK;
+}
+// scalars: big-endian, any value below 2^256 -> canonical limbs at ws.d_scalars, reduced on the device (round 5 reduced and
+// reversed them on the host: 10 ms of a 2^20-term call); staged behind `skip` bytes of ws.d_bytes
+static KzgRet g1_msm_scalars_in(const KzgSettings* s, const uint8_t* scalars, size_t n, size_t skip) {
+    Workspace& w = s->ws;
+    uint8_t* const stage = w.d_bytes + ((skip + 15) & ~(size_t)15);
+    HIPCHK(hipMemcpyAsync(stage, scalars, 32 * n, hipMemcpyHostToDevice, s->s1));
+    hipLaunchKernelGGL(k_scalars_reduce_be, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, stage, w.d_scalars, (int)n);
+    HIPCHK(hipGetLastError());
+    return KZG_OK;
+}
 extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uint8_t* scalars, size_t n, const KzgSettings* s) try {
     if (!s || !out || (n && (!points48 || !scalars))) return fail(KZG_BADARGS, "null argument");
     if (n > ((size_t)1 << 26)) return fail(KZG_BADARGS, "kzg_g1_msm: more than 2^26 terms");  // (a list entry holds a 27-bit point index)
@@ -137,20 +275,13 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
     if (rc != KZG_OK) return rc;
     Workspace& w = s->ws;
     const int np = (int)(n ? n : 1);  // table stride
-    // scalars: big-endian, reduced mod r on the host (at most two subtractions), little-endian limbs on the device
-    std::vector<uint8_t> le(32 * (n ? n : 1));
-    for (size_t i = 0; i < n; i++) {
-        uint8_t t[32];
-        memcpy(t, scalars + 32 * i, 32);
-        while (be_geq_r(t)) be_sub_r(t);
-        reverse32(le.data() + 32 * i, t);
-    }
     const bool aff = msm_affine_enabled();
     std::vector<uint32_t> st(n);
+    StreamDrain drain{s->s1};  // (declared after `st`: destroyed - and the stream drained - before it)
     HIPCHK(hipEventRecord(s->ev[5], s->s1));
     if (n) {
         HIPCHK(hipMemcpyAsync(w.d_bytes, points48, 48 * n, hipMemcpyHostToDevice, s->s1));
-        HIPCHK(hipMemcpyAsync(w.d_scalars, le.data(), 32 * n, hipMemcpyHostToDevice, s->s1));
+        if ((rc = g1_msm_scalars_in(s, scalars, n, 48 * n)) != KZG_OK) return rc;
         HIPCHK(hipEventRecord(s->ev[5], s->s1));
         const unsigned blocks256 = (unsigned)((n + 255) / 256);
         if (aff) {
@@ -173,83 +304,8 @@ extern "C" KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t* points48, const uin
         HIPCHK(hipMemcpyAsync(st.data(), w.d_pflag, 4 * n, hipMemcpyDeviceToHost, s->s1));
     }
     HIPCHK(hipEventRecord(s->ev[6], s->s1));
-    // the terms dealt to the kernel's two outputs: [0, h) and [h, n); slices of at most slice_terms terms (option
-    // g1_msm_slice_terms, default 3 072: 4 x 3 072 list entries = 48 KB of LDS, three workgroups per CU - measured at 2^20 terms
-    // against 2 048: fewer (window, slice) workgroups to reduce and fold), their number a multiple of 4 (the XCD placement of
-    // msm.hpp wants 2 S workgroup layers in eights)
-    static const size_t slice_terms = (size_t)std::max(256L, std::min(3072L, ab_int("g1_msm_slice_terms", (long)G1_MSM_SLICE_TERMS)));
-    const size_t h = (n + 1) / 2;
-    unsigned S = (unsigned)((h + slice_terms - 1) / slice_terms);
-    S = S <= 1 ? 1 : (S + 3) & ~3u;
-    const unsigned W = MSM_WINDOWS / MSM_CHUNKS, gz = 2 * S, gz_pad = gz <= 64 ? gz : (gz + 63) & ~63u;
-    DevTmp t_ws, t_f0, t_f1;
-    HIPCHK(hipMalloc(&t_ws.p, sizeof(G1Jac) * (size_t)gz_pad * W));
-    HIPCHK(hipMalloc(&t_f0.p, sizeof(G1Jac) * (size_t)std::max(1u, gz_pad / 2) * W));
-    HIPCHK(hipMalloc(&t_f1.p, sizeof(G1Jac) * (size_t)std::max(1u, gz_pad / 4) * W));
-    if ((rc = msm_save_reserve(s, W, 1, gz)) != KZG_OK) return rc;
-    // From 16 layers on (and while the save area holds them all: ~4 M terms) the tail of a LARGE sum: the slices folded bucket
-    // by bucket, then W slots reduced with four lanes per addition (msm.hpp msm_large_tail) - 0.8 ms instead of 1.55 at 2^20
-    // terms.  fold_per = the layers one thread adds in a row (more: fewer partial sums for the quads, a longer chain; measured at
-    // 344 layers: 6 -> 0.166 + 0.160 ms, 11 -> 0.188 + 0.111, 16 -> 0.264 + 0.115, 22 -> 0.358 + 0.077 for fold + sum).
-    static const int fold_per_opt = (int)std::max(2L, std::min(64L, ab_int("g1_msm_fold_per", 11)));
-    const int fold_per = std::max(fold_per_opt, (int)((gz + MSM_FOLD_MAX_GROUPS - 1) / MSM_FOLD_MAX_GROUPS));
-    int fold_gp = 0;
-    (void)msm_large_tail_groups(gz, fold_per, &fold_gp);
-    const bool large_tail = fp29_enabled() && gz >= 16 && ab_flag("g1_msm_large_tail", true) &&
-                            w.cap_msm_save >= msm_save_layer_bytes(W, 1, MSM_SAVE2_WORDS) * gz;
-    DevTmp t_tail;
-    if (large_tail) HIPCHK(hipMalloc(&t_tail.p, msm_large_tail_bytes(W, fold_gp)));
-    if (gz_pad != gz) {  // (Z = 0: the identity) the padding of the window sums, and of the first fold's output where a second full level reads it
-        HIPCHK(hipMemsetAsync(t_ws.as<G1Jac>() + (size_t)gz * W, 0, sizeof(G1Jac) * (size_t)(gz_pad - gz) * W, s->s1));
-        HIPCHK(hipMemsetAsync(t_f0.p, 0, sizeof(G1Jac) * (size_t)(gz_pad / 2) * W, s->s1));
-    }
-    HIPCHK(hipEventRecord(s->ev[2], s->s1));
-    if (n) {
-        hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s->s1, w.d_scalars, (int)n);
-        hipLaunchKernelGGL(k_plain_terms, dim3((unsigned)((2 * h + 255) / 256)), dim3(256), 0, s->s1, w.d_term_point, w.d_term_scalar, (int)(2 * h));
-    }
-    MsmDesc d{};
-    d.mult = w.d_mult;
-    d.pflag = w.d_pflag;
-    d.scalars = w.d_scalars;
-    d.term_point = w.d_term_point;  // output 1's list starts at entry max_terms = h: term_point[i] = i serves both
-    d.term_scalar = w.d_term_scalar;
-    d.sorted = w.d_sorted;
-    d.window_sums = t_ws.as<G1Jac>();
-    d.nterms[0] = (int)h;
-    d.nterms[1] = (int)(n - h);
-    d.max_terms = (int)(h ? h : 1);
-    d.stride = np;
-    d.slices = (int)S;
-    d.chunks = MSM_CHUNKS;
-    d.chunks_per_block = MSM_CHUNKS;  // one workgroup per (window, slice): the four chunks' entries in one sorted list
-    d.flags = (gz & 7) == 0 ? MSM_FLAG_XCD : 0;
-    if (aff) msm_window_launch<Curve29Aff, true>(d, W, 1, gz, w.d_msm_save, w.cap_msm_save, s->s1, !large_tail);
-    else if (fp29_enabled()) msm_window_launch<Curve29, true>(d, W, 1, gz, w.d_msm_save, w.cap_msm_save, s->s1, !large_tail);
-#if KZG_AB_VARIANTS
-    else msm_window_launch<Curve32, true>(d, W, 1, gz, w.d_msm_save, w.cap_msm_save, s->s1);
-#endif
-    if (large_tail) HIPCHK(msm_large_tail(w.d_msm_save, W, gz, fold_per, t_tail.as<uint32_t>(), t_ws.as<G1Jac>(), s->s1));
-    // window sums [2 S (padded to whole groups of 64 with identities)][W] -> [1][W]: trees over up to 64 slices at a time
-    const G1Jac* cur = t_ws.as<G1Jac>();
-    G1Jac* bufs[2] = {t_f0.as<G1Jac>(), t_f1.as<G1Jac>()};
-    int which = 0;
-    for (unsigned left = large_tail ? 1 : gz_pad; left > 1;) {
-        const unsigned f = std::min(left, 64u), groups = (left + f - 1) / f;  // (left > 64: a multiple of 64; the last level takes any count)
-        hipLaunchKernelGGL(k_msm_fold_slices, dim3(groups * W), dim3(64), 0, s->s1, cur, bufs[which], (int)f, (int)W);
-        cur = bufs[which];
-        which ^= 1;
-        left = groups;
-    }
-    // 8 windows of one output: the Horner chain with four lanes per doubling / addition (0.8 -> ~0.2 ms of a 2^20-term call)
-    if (fp29_enabled()) hipLaunchKernelGGL(k_msm_combine_quad, dim3(1), dim3(64), 0, s->s1, cur, w.d_ab, (int)W);
-    else hipLaunchKernelGGL(k_msm_combine, dim3(1), dim3(64), 0, s->s1, cur, w.d_ab, 1, (int)W);
-    HIPCHK(hipEventRecord(s->ev[3], s->s1));
-    hipLaunchKernelGGL(k_jac_compress, dim3(1), dim3(64), 0, s->s1, w.d_ab, w.d_bytes, 1);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, w.d_bytes, 48, hipMemcpyDeviceToHost, s->s1));
-    HIPCHK(hipStreamSynchronize(s->s1));
-    elapsed(&s->timings[2], s->ev[2], s->ev[3]);
+    const G1MsmTables tb{w.d_mult, w.d_pflag, np, aff, false};
+    if ((rc = g1_msm_core(s, n, tb, out)) != KZG_OK) return rc;
     elapsed(&s->timings[6], s->ev[5], s->ev[6]);
     for (size_t i = 0; i < n; i++)
         if (st[i] == G1_INVALID) return fail(KZG_BADARGS, "invalid G1 point");

@@ -202,3 +202,85 @@ extern "C" KzgRet kzg_compute_blob_kzg_proof(uint8_t* proofs48, const uint8_t* b
     if (!s || (n && (!proofs48 || !blobs || !commitments))) return fail(KZG_BADARGS, "null argument");
     return compute_proofs(proofs48, nullptr, blobs, nullptr, commitments, n, s);
 }
+
+// ---------------------------------------------------------------- G1 msm_variable_base over the handle's own points
+// out = sum_i scalars[i] * g1_points[i mod N] (N = 4 096 Lagrange points, bit-reversal permuted as the handle keeps them:
+// src/trusted_setup.rs:20-26; the shape of BASELINE.json configs[3], "2^20 trusted-setup points x random Fr scalars", and of the
+// reference's own call sites src/kzg_proof.rs:419,429,430 when their points are setup points).  scalars: n x 32 big-endian bytes,
+// any value below 2^256 (reduced mod r like Scalar::from_raw).  Nothing is decoded per call: the tables were made when the setup
+// was loaded.  Two forms, same result bit for bit:
+//   n <  FBM_MIN_TERMS   the verification path's window kernel (GLV, 8-bit windows) over the setup's affine table rows
+//   n >= FBM_MIN_TERMS   the fixed-base form of msm_fixed.hpp: 16-bit signed windows over rows 2^(16 v) P_j (16 MB with the doubled rows, made by the
+//                       first such call), 16 bucket additions per term instead of 32, one shared bucket set
+// option g1_msm_setup_form = window | fixed forces one (tests, A/B).  timings: [2] the MSM, [6] = 0 (no decode, no tables).
+constexpr size_t FBM_MIN_TERMS = 32768;
+static KzgRet fb_rows_ready(const KzgSettings* s) {
+    if (s->d_g1_fb_rows) return KZG_OK;
+    const int N = s->n_g1;
+    DevTmp t_jac;
+    G1Aff29Mem* rows = nullptr;
+    HIPCHK(hipMalloc(&t_jac.p, sizeof(G1Jac29Mem) * (size_t)(2 * FBM_WINDOWS - 1) * N));
+    HIPCHK(hipMalloc(&rows, sizeof(G1Aff29Mem) * (size_t)2 * FBM_WINDOWS * N));
+    DevTmp own;
+    own.p = rows;  // (released on an error path)
+    if (!s->d_fb_plan) HIPCHK(hipMalloc(&s->d_fb_plan, 4 * FBM_PLAN_WORDS));
+    HIPCHK(hipMemcpyAsync(rows, s->d_g1_mult_aff, sizeof(G1Aff29Mem) * (size_t)N, hipMemcpyDeviceToDevice, s->s1));  // row 0 = P_j
+    hipLaunchKernelGGL(k_fb_build_rows, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, s->s1, (const G1Aff29Mem*)s->d_g1_mult_aff, (const uint32_t*)s->d_g1_flag,
+                       t_jac.as<G1Jac29Mem>(), N);
+    const int m = (2 * FBM_WINDOWS - 1) * N;
+    hipLaunchKernelGGL(k_jac29_to_aff29, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s->s1, (const G1Jac29Mem*)t_jac.as<G1Jac29Mem>(), rows + N, m);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->s1));
+    own.p = nullptr;
+    s->d_g1_fb_rows = rows;
+    return KZG_OK;
+}
+extern "C" KzgRet kzg_g1_msm_setup(uint8_t out[48], const uint8_t* scalars, size_t n, const KzgSettings* s) try {
+    if (!s || !out || (n && !scalars)) return fail(KZG_BADARGS, "null argument");
+    if (n > ((size_t)1 << 26)) return fail(KZG_BADARGS, "kzg_g1_msm_setup: more than 2^26 terms");
+    KzgRet rc = prover_ready(s);
+    if (rc != KZG_OK) return rc;
+    std::lock_guard<std::mutex> lk(s->mu);
+    HIPCHK(hipSetDevice(s->device));
+    select_streams(s, (size_t)-1);  // stand-alone pieces run on the plain stream pair
+    if ((rc = ws_reserve(s, (n + 1) / 2 + 1, 1, STAGE_NONE)) != KZG_OK) return rc;
+    Workspace& w = s->ws;
+    StreamDrain drain{s->s1};
+    const bool aff = msm_affine_enabled() && s->d_g1_mult_aff;
+    static const int forced = opt_is("g1_msm_setup_form", "window") ? 1 : opt_is("g1_msm_setup_form", "fixed") ? 2 : 0;
+    static const int L = (int)std::max(1024L, std::min((long)FBM_SLICE_ENTRIES, ab_int("g1_msm_fb_slice", (long)FBM_SLICE_ENTRIES)));
+    const unsigned Z = fb_max_blocks((size_t)FBM_WINDOWS * n, L);
+    const size_t save_bytes = (size_t)Z * 256 * MSM_SAVE2_WORDS * 4;
+    const bool fixed = aff && n > 0 && (size_t)s->n_g1 * 2 * FBM_WINDOWS <= 131072 && save_bytes <= ((size_t)2 << 30) && (forced == 2 || (forced == 0 && n >= FBM_MIN_TERMS));
+    if (n && (rc = g1_msm_scalars_in(s, scalars, n, 0)) != KZG_OK) return rc;
+    s->timings[6] = 0.0f;
+    if (!fixed) {
+        const G1MsmTables tb{aff ? (const void*)s->d_g1_mult_aff : (const void*)s->d_g1_mult, s->d_g1_flag, s->n_g1, aff, true};
+        return g1_msm_core(s, n, tb, out);
+    }
+    if ((rc = fb_rows_ready(s)) != KZG_OK) return rc;
+    if (save_bytes > w.cap_msm_save) {  // (grow-only, like msm_save_reserve; this form's layers are 48 KB each)
+        if (w.d_msm_save) (void)hipFree(w.d_msm_save);
+        w.d_msm_save = nullptr;
+        w.cap_msm_save = 0;
+        HIPCHK(hipMalloc(&w.d_msm_save, save_bytes));
+        w.cap_msm_save = save_bytes;
+    }
+    static const int fold_per_opt = (int)std::max(2L, std::min(64L, ab_int("g1_msm_fold_per", 11)));
+    int gp = 0;
+    (void)msm_large_tail_groups(Z, std::max(fold_per_opt, (int)((Z + MSM_FOLD_MAX_GROUPS - 1) / MSM_FOLD_MAX_GROUPS)), &gp);
+    uint8_t* tmp = nullptr;
+    if ((rc = g1msm_scratch(s, fb_tail_bytes(gp), &tmp)) != KZG_OK) return rc;
+    HIPCHK(hipEventRecord(s->ev[2], s->s1));
+    HIPCHK(fb_msm_launch(w.d_scalars, s->d_g1_flag, (int)n, s->n_g1, s->d_g1_fb_rows, s->d_fb_plan, w.d_sorted, w.d_msm_save, tmp, w.d_ab, L, fold_per_opt,
+                         w.d_ktime ? w.d_ktime + 8 : nullptr, s->s1, s->s2, s->ev[7], s->ev[8]));
+    HIPCHK(hipEventRecord(s->ev[3], s->s1));
+    hipLaunchKernelGGL(k_jac_compress, dim3(1), dim3(64), 0, s->s1, w.d_ab, w.d_bytes, 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, w.d_bytes, 48, hipMemcpyDeviceToHost, s->s1));
+    HIPCHK(hipStreamSynchronize(s->s1));
+    elapsed(&s->timings[2], s->ev[2], s->ev[3]);
+    return KZG_OK;
+} catch (const std::bad_alloc&) {
+    return fail(KZG_MALLOC, "host buffers of the call");  // (nothing is thrown across the C ABI)
+}

@@ -46,6 +46,8 @@ struct Workspace {
     G1Jac29Mem* d_jtmp = nullptr;  // 2^64 P of every decoded point on its way to the affine table (k_mult_to_affine29)
     bool mult_affine = false;      // format of d_mult as the last decode left it
     Fp *d_slp_in = nullptr, *d_slp_out = nullptr;
+    uint8_t* d_g1msm = nullptr;  // kzg_g1_msm / kzg_g1_msm_setup: window sums, fold trees, the large-sum tail (grow-only; a per-call hipFree stalls every lane of the device)
+    size_t cap_g1msm = 0;
     uint8_t *d_stage_blobs = nullptr, *d_stage_cp = nullptr, *d_bytes = nullptr, *d_records = nullptr;
     uint32_t* d_sha_mid = nullptr;  // SHA-256 midstates between the segments of a sliced challenge chain, 32 B per blob
     // host-fed stream of batches (kzg_verify_blob_kzg_proof_batches): two staging sets, each [blobs | commitments | proofs]
@@ -73,6 +75,10 @@ struct KzgSettings {
     G1Aff* d_g1 = nullptr;            // g1_points, bit-reversal permuted (build.rs:79,89-105), 4096 entries
     uint32_t* d_g1_flag = nullptr;    // 0 finite / 1 identity (unchecked decode, build.rs:68)
     void* d_g1_mult = nullptr;        // their MSM multiples (msm.hpp), valid iff g1_in_subgroup
+    G1Aff29Mem* d_g1_mult_aff = nullptr;  // the same as AFFINE rows (the throughput layout of the verification path's MSM): kzg_g1_msm_setup's 8-bit form
+    int n_g1 = 0;                     // number of G1 Lagrange points (4096)
+    mutable G1Aff29Mem* d_g1_fb_rows = nullptr;  // fixed-base rows 2^(16 v) P_j (msm_fixed.hpp), made by the first large kzg_g1_msm_setup call
+    mutable uint32_t* d_fb_plan = nullptr;       // ... and that form's device-side plan words
     bool g1_in_subgroup = false;      // every G1 point lies in the r-torsion (what the GLV multiples need)
     Fp* d_g2 = nullptr;               // g2_points (monomial), n_g2 x 4 Fp
     size_t n_g2 = 0;
@@ -410,6 +416,20 @@ static KzgRet settings_load_points(KzgSettings* s, const std::vector<uint8_t>& g
         hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, false>), dim3((unsigned)((N + 63) / 64)), dim3(64), 64 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s1, d_bytes, d_bytes, N, d_tmp,
                            d_flag2, s->d_g1_mult, (G1Jac29Mem*)nullptr, N, N);
     HIPCHK(hipGetLastError());
+    s->n_g1 = N;
+    DevTmp t_jtmp, t_aff_pts;
+    if (msm_affine_enabled()) {
+        // the same points as affine table rows (P, 2^64 P, -phi(P), -phi(2^64 P)): sums over the setup's own points
+        // (kzg_g1_msm_setup) then run on the verification path's mixed-addition window kernel without a per-call decode
+        HIPCHK(hipMalloc(&s->d_g1_mult_aff, sizeof(G1Aff29Mem) * MSM_CHUNKS * (size_t)N));
+        HIPCHK(hipMalloc(&t_jtmp.p, sizeof(G1Jac29Mem) * (size_t)N));
+        HIPCHK(hipMalloc(&t_aff_pts.p, sizeof(G1Aff) * (size_t)N));
+        hipLaunchKernelGGL((k_g1_decode_multiples29<MSM_CHUNKS, true>), dim3((unsigned)((N + 255) / 256)), dim3(256), 256 * PARK_UINT4_PER_THREAD * sizeof(uint4), s->s1, d_bytes,
+                           d_bytes, N, t_aff_pts.as<G1Aff>(), d_flag2, (void*)s->d_g1_mult_aff, t_jtmp.as<G1Jac29Mem>(), N, N);
+        const unsigned conv_blocks = (unsigned)((N + 64 * AFFINE_BATCH - 1) / (64 * AFFINE_BATCH));
+        hipLaunchKernelGGL(k_mult_to_affine29, dim3(conv_blocks), dim3(64), 0, s->s1, t_jtmp.as<G1Jac29Mem>(), d_flag2, s->d_g1_mult_aff, N, N);
+        HIPCHK(hipGetLastError());
+    }
     std::vector<uint32_t> f1((size_t)N), f2((size_t)N);
     HIPCHK(hipMemcpyAsync(f1.data(), s->d_g1_flag, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
     HIPCHK(hipMemcpyAsync(f2.data(), d_flag2, 4 * (size_t)N, hipMemcpyDeviceToHost, s->s1));
@@ -556,7 +576,7 @@ extern "C" KzgRet kzg_settings_from_tau_g2_devices(KzgSettings** out, const uint
 static void ws_free(Workspace& w) {
     void* ptrs[] = {w.d_z, w.d_y, w.d_scalars, w.d_partial, w.d_r, w.d_status, w.d_pflag, w.d_term_point, w.d_term_scalar,
                     w.d_sorted, w.d_points, w.d_window, w.d_window_sl, w.d_ab, w.d_send, w.d_mult, w.d_jtmp, w.d_ktime, w.d_parts, w.d_slp_in, w.d_slp_out, w.d_stage_blobs, w.d_stage_cp, w.d_bytes,
-                    w.d_records, w.d_hstage[0], w.d_hstage[1], w.d_msm_save, w.d_sha_mid};
+                    w.d_records, w.d_hstage[0], w.d_hstage[1], w.d_msm_save, w.d_sha_mid, w.d_g1msm};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (w.h_buf) (void)hipHostFree(w.h_buf);
@@ -581,7 +601,7 @@ extern "C" void kzg_settings_free(KzgSettings* s) {
     if (s->h_proofs) (void)hipHostFree(s->h_proofs);
     prover_release(s);
     if (!s->borrowed) {  // (a lane reads its parent's tables)
-        void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob, s->verify2.blob, s->d_prep29, s->scalars.blob, s->verify3.blob, s->d_fixed_base};
+        void* ptrs[] = {s->d_g1, s->d_g1_flag, s->d_g1_mult, s->d_g1_mult_aff, s->d_g1_fb_rows, s->d_fb_plan, s->d_g2, s->d_M, s->d_DM, s->d_M29, s->d_DM29, s->d_eval_a, s->d_eval_b, s->d_eval_c, s->d_tau4, s->d_prep, s->d_gen_mult, s->d_gen_mult_aff, s->prep.blob, s->verify.blob, s->verify2.blob, s->d_prep29, s->scalars.blob, s->verify3.blob, s->d_fixed_base};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }

@@ -915,10 +915,12 @@ extern "C" KzgRet kzg_verify_blob_kzg_proof_batch(bool* ok, const uint8_t* blobs
     HostBatch host{blobs, commitments, proofs};  // phase 1 brings the batch over, in slices across the blobs (host_slices)
     std::vector<uint8_t> z_host;
     hostpool::JobRef z_job;
+    hostpool::JoinOnExit joined;  // (declared after z_host: on an exception out of the batch the workers are joined before the buffer they write dies)
     if (n <= host_max) {  // a few blobs: their challenges from the host's SHA-NI cores, beside the point decode on the GPU
         z_host.resize(32 * n);
         host.z_le = z_host.data();
         z_job = hostpool::make(z_host.data(), blobs, commitments, n);
+        joined.add(z_job);
         hostpool::post(z_job, (size_t)std::max(1L, std::min(16L, opt_int("host_threads", 16))));
         host.z_job = z_job.get();
     }
@@ -1378,6 +1380,7 @@ static KzgRet blobs_parts_locked(BlobsPart* parts, size_t n_parts, size_t m, con
     uint8_t* const h_z = reinterpret_cast<uint8_t*>(pl.h_zy);  // (the mirror's z | y area: 32 m bytes of challenges)
     uint32_t* const h_status = pl.h_zy + 8 * m;
     std::vector<hostpool::JobRef> own(n_parts);
+    hostpool::JoinOnExit joined;  // (every HIPCHK / rc return below leaves with the posted jobs finished: they read the callers' blobs)
     size_t off = 0;
     for (size_t k = 0; k < n_parts; k++) {
         BlobsPart& pt = parts[k];
@@ -1386,6 +1389,7 @@ static KzgRet blobs_parts_locked(BlobsPart* parts, size_t n_parts, size_t m, con
         if (!pt.job) {  // hashed from here: the pool's workers start at once, this thread joins them after the copies below
             own[k] = hostpool::make(h_z + 32 * off, pt.blobs, pt.commitments, pt.n);
             static const size_t threads = (size_t)std::max(1L, std::min(16L, opt_int("host_threads", 16)));
+            joined.add(own[k]);
             hostpool::post(own[k], threads);
         }
         off += pt.n;

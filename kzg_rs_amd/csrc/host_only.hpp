@@ -360,7 +360,9 @@ static void post(const JobRef& j, size_t max_threads = (size_t)-1) {
     std::lock_guard<std::mutex> lk(P.mu);
     P.jobs.push_back(j);
     size_t want = std::min(std::min(j->n, max_threads), P.max_workers);
-    while (P.workers < P.max_workers && P.workers < P.workers - P.idle + want) {  // started < busy + wanted
+    // new workers only for what the idle ones do not cover: idle + started < wanted (round 5's condition compared against a count
+    // that did not move while spawning, so the first job of two blobs started all max_workers threads)
+    for (size_t started = 0; P.workers < P.max_workers && P.idle + started < want; started++) {
         try {
             std::thread(&Pool::worker, &P).detach();
             P.workers++;
@@ -372,6 +374,20 @@ static void post(const JobRef& j, size_t max_threads = (size_t)-1) {
     else
         for (size_t k = 0; k < want; k++) P.cv.notify_one();
 }
+// Whoever posts a job over memory it does not own (the caller's blobs, a buffer of its own frame) joins it on EVERY way out -
+// an error return, an exception - before that memory goes away: the pool's workers read the blobs and write z_le.
+struct JoinOnExit {
+    std::vector<JobRef> jobs;
+    JoinOnExit() = default;
+    JoinOnExit(const JoinOnExit&) = delete;
+    JoinOnExit& operator=(const JoinOnExit&) = delete;
+    void add(const JobRef& j) {
+        if (j) jobs.push_back(j);
+    }
+    ~JoinOnExit() {
+        for (const JobRef& j : jobs) finish(*j);
+    }
+};
 static JobRef make(uint8_t* z_le, const uint8_t* blobs, const uint8_t* commitments, size_t n) {
     JobRef j = std::make_shared<Job>();
     j->blobs = blobs;

@@ -20,6 +20,7 @@
 #include "fr_kernels.hpp"
 #include "g1.hpp"
 #include "msm.hpp"
+#include "msm_fixed.hpp"
 #include "slp.hpp"
 #include "slp2.hpp"
 #include "proof_kernels.hpp"

@@ -32,6 +32,8 @@ extern "C" {
     pub fn kzg_verify_blob_kzg_proof(ok: *mut bool, blob: *const u8, commitment: *const u8, proof: *const u8, s: *const RawSettings) -> c_int;
     pub fn kzg_verify_blob_kzg_proof_batch(ok: *mut bool, blobs: *const u8, commitments: *const u8, proofs: *const u8, n: usize, s: *const RawSettings) -> c_int;
     pub fn kzg_pairings_verify(ok: *mut bool, a1: *const u8, a2: *const u8, b1: *const u8, b2: *const u8, s: *const RawSettings) -> c_int;
+    pub fn kzg_g1_msm(out: *mut u8, points48: *const u8, scalars: *const u8, n: usize, s: *const RawSettings) -> c_int;
+    pub fn kzg_g1_msm_setup(out: *mut u8, scalars: *const u8, n: usize, s: *const RawSettings) -> c_int;
     pub fn kzg_last_error() -> *const c_char;
 }
 
@@ -46,8 +48,6 @@ pub fn last_error() -> String {
     }
 }
 
-/// `KzgRet` -> `Result`: KZG_OK is "the boolean is valid" (`Ok(true)` / `Ok(false)`), everything else one of the
-/// reference's `Err(KzgError::...)` (include/kzg_rs_amd.h, "Conventions").
 /// What a successful constructor wants its caller to know about the handle ("" = nothing): fewer than 8 HIP hardware queues,
 /// how a multi-device handle exchanges its partial sums and what its self-test found.
 pub fn settings_note(h: &Handle) -> String {
@@ -60,6 +60,8 @@ pub fn settings_note(h: &Handle) -> String {
     }
 }
 
+/// `KzgRet` -> `Result`: KZG_OK is "the boolean is valid" (`Ok(true)` / `Ok(false)`), everything else one of the
+/// reference's `Err(KzgError::...)` (include/kzg_rs_amd.h, "Conventions").
 pub fn check(rc: c_int) -> Result<(), KzgError> {
     KzgError::from_ret(rc, last_error)
 }

@@ -158,6 +158,34 @@ def test_bench_script_two_ranks_shared_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and d["config"]["batch"] == 2048
     assert d["config"]["batches_per_step"] == 16 and d["multi_gpu"]["ranks"] == 2
+    mg = d["multi_gpu"]
+    # the run describes itself: which exchange ran over which transport, every rank's stage split, the negative control through the pipeline
+    assert "all_to_all_single" in mg["exchange_ran"]["exchange1"] and "288 B" in mg["exchange_ran"]["exchange2"] and "gloo" in mg["exchange_ran"]["transport"]
+    assert [r["rank"] for r in mg["per_rank_stage_ms_per_step"]] == [0, 1] and all(r["groups"] >= 4 and r["r_hash_ms"] > 0 for r in mg["per_rank_stage_ms_per_step"])
+    assert mg["pipe_check"]["passed"] is True and mg["pipe_check"]["results"].count(False) == 1 and mg["pipe_check"]["results"][8] is False
+    assert d["preflight"]["shrunk"] is False and d["preflight"]["batches_per_step"] == 16
+    assert d["roofline"]["frac_path"] > 0 and "inputs" in d["roofline"]
+
+
+def test_bench_shard_leg_world_of_one():
+    """`bench.py --workload config5 --force-collectives` on ONE GPU (what the default run's configs.config5_shard leg starts as a child):
+    BASELINE configs[4]'s shard shape through PipelinedVerifier with the exchanges of a world of one rank over RCCL - here at a reduced
+    size (2 048-blob shards, 4 batches per step) - prints the standard line with the stage split, the exchange that ran and the
+    poisoned batch's false."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "config5", "--force-collectives", "--steps", "3", "--warmup", "1",
+           "--blobs", "2048", "--group", "4", "--no-latency", "--no-self-check", "--no-cpu-baseline", "--no-configs", "--no-concurrent"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["blobs_per_step"] == 4 * 2048
+    assert "PipelinedVerifier" in d["config"]["entry_point"] and "world of ONE rank" in d["config"]["entry_point"]
+    mg = d["multi_gpu"]
+    assert mg["backend"] == "nccl" and mg["exchange_ran"]["world_of_one"] is True and "RCCL" in mg["exchange_ran"]["transport"]
+    assert mg["pipe_check"]["passed"] is True and mg["pipe_check"]["results"] == [True, True, False, True]
+    assert mg["per_rank_stage_ms_per_step"][0]["r_hash_ms"] > 0
 
 
 def test_bench_script_bare_command_starts_its_own_ranks():

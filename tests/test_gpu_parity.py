@@ -1546,3 +1546,79 @@ def test_small_host_batches_hash_on_the_host_or_on_the_gpu_with_the_same_results
     for opts in ("", "small_batch_pairings_max=0", "host_challenge_max_blobs=0"):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_OPTIONS=opts), capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "SMALL-HOST mismatches 0" in out.stdout, (opts, out.stdout[-500:], out.stderr[-2000:])
+
+
+def test_small_batch_forms_agree_on_2000_seeded_mixed_batches():
+    """include/kzg_rs_amd.h documents the DEFAULT for batches of 2 .. 256 items as a different algorithm from the reference's - the
+    conjunction of per-item pairings instead of the random linear combination src/kzg_proof.rs:399-444 - with the same answer.  Here
+    2 000 seeded batches of 2 .. 24 proof tuples (valid ones; a wrong y; two proofs swapped; a repeated tuple; a commitment replaced
+    by the identity or by another tuple's; a non-canonical z; a proof outside G1) and 120 host-blob batches of 2 .. 6 blobs (valid;
+    a swapped proof; a field element equal to r) go through kzg_verify_kzg_proof_batch / kzg_verify_blob_kzg_proof_batch in two
+    child processes - the default and KZG_OPTIONS=small_batch_pairings_max=0 (the reference's combination at every size): the 2 120
+    results (true / false / Err) must be identical, and the first 150 + 30 of them equal the CPU oracle's."""
+    import subprocess
+    import sys
+    code = ("import sys, random, hashlib\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import ctypes as C\n"
+            "import numpy as np\n"
+            "import golden_data as G, oracle_lib as O\n"
+            "from kzg_rs_amd import api, synth\n"
+            "R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001\n"
+            "INF = bytes([0xC0]) + bytes(47)\n"
+            "pc, pz, py, pp, st = synth.make_valid_proofs(256, seed=2000)\n"
+            "ost = O.Settings.from_tau_g2(synth.synthetic_setup()[1])\n"
+            "L = api.lib(); ok = C.c_bool(False)\n"
+            "rng = random.Random(20260)\n"
+            "res, checked = [], 0\n"
+            "for t in range(2000):\n"
+            "    n = rng.randrange(2, 25)\n"
+            "    idx = [rng.randrange(256) for _ in range(n)]\n"
+            "    c, z, y, p = [pc[i] for i in idx], [pz[i] for i in idx], [py[i] for i in idx], [pp[i] for i in idx]\n"
+            "    kind = rng.randrange(10)\n"
+            "    k = rng.randrange(n)\n"
+            "    if kind == 0: y[k] = py[(idx[k] + 1) %% 256]\n"
+            "    elif kind == 1 and n > 1: p[k], p[(k + 1) %% n] = p[(k + 1) %% n], p[k]\n"
+            "    elif kind == 2: c[k], z[k], y[k], p[k] = c[0], z[0], y[0], p[0]\n"
+            "    elif kind == 3: c[k] = INF\n"
+            "    elif kind == 4: c[k] = pc[(idx[k] + 7) %% 256]\n"
+            "    elif kind == 5: z[k] = R.to_bytes(32, 'big')\n"
+            "    elif kind == 6: p[k] = G.off_subgroup_g1()\n"
+            "    rc = L.kzg_verify_kzg_proof_batch(C.byref(ok), b''.join(c), b''.join(z), b''.join(y), b''.join(p), n, st._h)\n"
+            "    got = None if rc else bool(ok.value)\n"
+            "    res.append(got)\n"
+            "    if t < 150:\n"
+            "        try:\n"
+            "            want = O.verify_kzg_proof_batch(c, z, y, p, ost)\n"
+            "        except O.OracleError:\n"
+            "            want = None\n"
+            "        assert got == want, (t, kind, n, got, want)\n"
+            "        checked += 1\n"
+            "blobs, cs, ps, _ = synth.make_valid_batch(16, seed=2001, settings=st)\n"
+            "for t in range(120):\n"
+            "    n = rng.randrange(2, 7)\n"
+            "    idx = [rng.randrange(16) for _ in range(n)]\n"
+            "    b = np.ascontiguousarray(blobs[idx]); c = [cs[i] for i in idx]; p = [ps[i] for i in idx]\n"
+            "    kind = rng.randrange(4)\n"
+            "    k = rng.randrange(n)\n"
+            "    if kind == 0: p[k] = ps[(idx[k] + 1) %% 16]\n"
+            "    elif kind == 1: b[k, 32 * 77: 32 * 78] = list(R.to_bytes(32, 'big'))\n"
+            "    rc = L.kzg_verify_blob_kzg_proof_batch(C.byref(ok), b.ctypes.data_as(C.c_char_p), b''.join(c), b''.join(p), n, st._h)\n"
+            "    got = None if rc else bool(ok.value)\n"
+            "    res.append(got)\n"
+            "    if t < 30:\n"
+            "        try:\n"
+            "            want = O.verify_blob_kzg_proof_batch([b[i].tobytes() for i in range(n)], c, p, ost)\n"
+            "        except O.OracleError:\n"
+            "            want = None\n"
+            "        assert got == want, ('blobs', t, kind, n, got, want)\n"
+            "        checked += 1\n"
+            "print('FORMS', len(res), checked, res.count(True), res.count(False), res.count(None), hashlib.sha256(repr(res).encode()).hexdigest())\n"
+            % (O.ROOT, os.path.join(O.ROOT, "tests")))
+    lines = []
+    for opts in ("", "small_batch_pairings_max=0"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_OPTIONS=opts), capture_output=True, text=True, timeout=1500)
+        assert out.returncode == 0, (opts, out.stdout[-800:], out.stderr[-2500:])
+        lines.append([ln for ln in out.stdout.splitlines() if ln.startswith("FORMS")][-1].split())
+    assert lines[0] == lines[1], lines
+    assert lines[0][1] == "2120" and lines[0][2] == "180" and int(lines[0][3]) > 400 and int(lines[0][4]) > 400 and int(lines[0][5]) > 100, lines[0]

@@ -4,8 +4,13 @@ are tallied at 64 bytes; WRITE_SIZE exact), with the correction checked in the s
 bench.py under KZG_PMC_CALIBRATE=1 runs ONE elementwise kernel that reads 128 MiB and writes 128 MiB (the only
 vectorized_elementwise_kernel of that grid in the process; a hipMemcpy would be ambiguous - device-to-host copies of the
 records use the same blit kernel and grid).  Expected: FETCH_SIZE ~ 65 536 KB (x2 = 131 072), WRITE_SIZE = 131 072 KB."""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from kzg_rs_amd import build as kbuild  # noqa: E402
+
+# the kernels these counters describe: bench.py (kzg_rs_amd/benchline.py) uses a profile only when its stamp equals the running tree's
+KERNEL_KEY = kbuild.kernel_key()
 prefix, group = sys.argv[1], int(sys.argv[2])
 kern = {}
 calib = {}
@@ -51,13 +56,13 @@ if group == 0:  # the config legs (tools/prof/config_legs.py): no launch group, 
     print(json.dumps({
         "method": "rocprofv3 --pmc, one counter set per run, KZG_OPTIONS=single_stream=1, python3 tools/prof/config_legs.py: values are "
                   "per launch of the kernel (its largest dispatch in the process: k_blob_evaluate over 16 384 blobs = BASELINE configs[2]; k_msm_window, "
-                  "k_msm_bucket_fold, k_msm_bucket_sum_quads, k_msm_reduce_quads, k_g1_decode_multiples29, k_mult_to_affine29 over 2^20 terms = BASELINE configs[3]). FETCH_SIZE / WRITE_SIZE in KB as "
+                  "k_fb_window and the partition, fold and reduction kernels of kzg_g1_msm_setup, k_msm_window, k_g1_decode_multiples29, k_mult_to_affine29 of kzg_g1_msm over 2^20 terms = BASELINE configs[3]). FETCH_SIZE / WRITE_SIZE in KB as "
                   "reported; hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, MI355X_MICROARCH.md HBM section).",
-        "config3_blobs": 16384, "config4_pairs": 1 << 20, "kernels": kern}, indent=1))
+        "kernel_key": KERNEL_KEY, "config3_blobs": 16384, "config4_pairs": 1 << 20, "kernels": kern}, indent=1))
     sys.exit(0)
 print(json.dumps({
     "method": "rocprofv3 --pmc, one counter set per run, KZG_OPTIONS=single_stream=1, bench.py --group %d --inflight 1 --steps 1 --warmup 0: one "
               "launch group of %d batches x 1024 blobs; values are per launch of the kernel (its largest dispatch). FETCH_SIZE / "
               "WRITE_SIZE in KB as reported; hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
               "MI355X_MICROARCH.md HBM section); calibration = the same counters on a dispatch that reads 128 MiB and writes 128 MiB." % (group, group),
-    "blobs_per_launch": 1024 * group, "calibration": calib, "kernels": kern}, indent=1))
+    "kernel_key": KERNEL_KEY, "blobs_per_launch": 1024 * group, "calibration": calib, "kernels": kern}, indent=1))
