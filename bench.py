@@ -239,21 +239,22 @@ def config_legs(settings, torch, dev, no_cpu=False):
     d_z = torch.from_numpy(z_le).to(dev)
     d_y = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    # The leg's input was just written by memory-bound fill kernels (2 GiB).  For some tens of milliseconds after such a burst the
-    # chip runs this VALU-bound kernel 15-30 % slower (0.93 -> 1.20 ms, decaying over ~20 calls), and after 20 ms of idleness not at
-    # all (0.911-0.924 ms, 12 calls, spread 1.4 %): profiles/r6_config3_regimes.json.  It is the state of the chip, not the launch:
-    # the time per blob is the same at 4.0, 5.0 and 5.33 rounds of resident wavefronts (12 288 / 15 360 / 16 384 blobs: 54.7 / 54.6 /
-    # 54.0 ns), so there is no quantisation tail for a persistent grid to remove.  Both regimes are reported: `ms` after a settle,
-    # `ms_after_memory_burst` right behind the fills.
-    burst = []
-    for _ in range(4):
-        api.evaluate_polynomials_device(d_y.data_ptr(), d_blobs.data_ptr(), d_z.data_ptr(), n, settings)
-        burst.append(settings.last_timings()[4])
-    time.sleep(0.05)
+    # What this 1 ms VALU-bound launch costs depends on what the chip did in the milliseconds before it (profiles/r6_config3_regimes.json):
+    #   alone - 20 ms of idleness before the call:           0.911-0.924 ms, 12 calls, spread 1.4 %   -> `ms` (what one such call costs a caller)
+    #   back to back: 0.93, 0.98, then 1.1-1.25 ms for ~5 calls, decaying to 0.92 over ~20 calls       -> `ms_back_to_back_*` (a power / clock transient:
+    #   the same happens behind a memory-bound torch kernel, and not at all behind a pause)
+    # It is the state of the chip, not the launch: the time per blob is the same at 4.0, 5.0 and 5.33 rounds of resident wavefronts
+    # (12 288 / 15 360 / 16 384 blobs: 54.7 / 54.6 / 54.0 ns per blob), so there is no quantisation tail for a persistent grid to remove.
+    api.evaluate_polynomials_device(d_y.data_ptr(), d_blobs.data_ptr(), d_z.data_ptr(), n, settings)   # warm-up (scratch allocation)
     ms3 = []
-    for _ in range(8):
+    for _ in range(11):
+        time.sleep(0.02)
         api.evaluate_polynomials_device(d_y.data_ptr(), d_blobs.data_ptr(), d_z.data_ptr(), n, settings)
         ms3.append(settings.last_timings()[4])
+    b2b = []
+    for _ in range(32):
+        api.evaluate_polynomials_device(d_y.data_ptr(), d_blobs.data_ptr(), d_z.data_ptr(), n, settings)
+        b2b.append(settings.last_timings()[4])
     y = d_y.cpu().numpy().reshape(n, 32)
     ok3 = bool((y[:half] == y[half:]).all())
     for i, k in roots.items():
@@ -263,14 +264,16 @@ def config_legs(settings, torch, dev, no_cpu=False):
     out["config3"] = {"workload": "evaluate_polynomial_in_evaluation_form only, %d device-resident blobs (BASELINE.json configs[2])" % n,
                       "entry_point": "kzg_evaluate_polynomials_device", "blobs": n, "ms": round(t3, 4), "ms_all_runs": [round(x, 4) for x in ms3],
                       "spread": round((max(ms3[1:]) - min(ms3[1:])) / t3, 4),
-                      "ms_after_memory_burst": [round(x, 4) for x in burst],
+                      "ms_back_to_back_all_runs": [round(x, 4) for x in b2b], "ms_back_to_back_steady": round(sorted(b2b[-8:])[4], 4),
+                      "ms_back_to_back_worst": round(max(b2b), 4),
                       "blobs_per_s": round(n / t3 * 1e3, 1),
                       "roofline": {"bound": "valu-issue", "algorithmic_bytes_per_blob": alg3, "achieved": round(alg3 * n / t3 / 1e6, 2), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(alg3 * n / t3 / 1e6 / HBM_PEAK_GBS, 6)},
                       "checked": {"passed": ok3, "what": "%d blobs evaluated at a root of unity return their own element; the two identical halves agree bit for bit"
                                                          % len(roots)},
-                      "timing": "HIP events on the library's stream around k_eval_powers + k_blob_evaluate + k_eval_finish; ms = median of 7 back-to-back calls after one "
-                                "warm-up, started 50 ms after the input fills; ms_after_memory_burst = the 4 calls right behind the fills (see profiles/r6_config3_regimes.json)"}
+                      "timing": "HIP events on the library's stream around k_eval_powers + k_blob_evaluate + k_eval_finish; ms = median of 10 calls, each after 20 ms of "
+                                "idleness (one warm-up before); ms_back_to_back_*: 32 calls one behind the other - the first calls of such a burst run into a power / clock "
+                                "transient (worst), the last 8 are the steady state (see profiles/r6_config3_regimes.json: regimes and a size sweep)"}
     del d_blobs, d_z, d_y
     torch.cuda.empty_cache()
     # ---- config 4
@@ -1094,10 +1097,13 @@ def main():
         sp = os.environ.get("KZG_BENCH_SINGLE_PROCESS", "1")
         if world > 1 and sp != "0" and (not share or sp == "force"):  # (ranks sharing one GPU: only when a test asks for it - the list then names device 0 `world` times)
             out["multi_gpu"]["single_process"] = run_single_process_child(",".join("0" if share else str(i) for i in range(world)), n)
-    if world == 1 and not use_pipe and not args.no_configs and not args.no_shard_leg:
+    if world == 1 and not use_pipe and not args.no_configs and not args.no_self_check and not args.no_shard_leg:
         # BASELINE configs[4]'s SHARD SHAPE on this one GPU, through the code path --gpus N runs (a child process: this one gives
         # its memory back first; a failure or a hang there costs the leg, not the line)
-        del variants, d_blobs
+        variants.clear()   # (and every other name that still points into them)
+        v = vv = v0 = saved = res = t = solo_res = d_blobs = d_c = d_p = None
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
         out.setdefault("configs", {})
         if out["configs"] is None:
@@ -1118,6 +1124,9 @@ def run_shard_leg_child(steps, warmup, timeout=420):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
+    for k in list(env):   # a profiler around this process (rocprofv3 preloads its tool library) does not follow the child: it runs plain
+        if k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES") or k.startswith(("ROCPROF", "ROCPROFILER", "ROCTX")):
+            env.pop(k)
     try:
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)

@@ -216,7 +216,7 @@ __global__ void k_jac_compress(const G1Jac* __restrict__ p, uint8_t* __restrict_
     int i = threadIdx.x;
     if (i >= count || blockIdx.x) return;
     G1Aff a;
-    bool finite = g1_to_affine(a, p[i]);
+    bool finite = g1_to_affine<true>(a, p[i]);  // (one or two lanes: the Euclidean inversion, 0.1 ms instead of 1.0)
     g1_compress(out + 48 * i, a, !finite);
 }
 

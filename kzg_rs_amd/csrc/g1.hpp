@@ -72,6 +72,74 @@ __device__ inline Fp fp_const(const uint32_t (&c)[12]) {
 // a^-1 by Fermat (a != 0).  Used only in set-up / per-call tails, never per blob element.
 __device__ inline Fp fp_inv(const Fp& a) { return fp_pow(a, consts::FP_P_MINUS_2); }
 
+// a^-1 for a LONE LANE (a != 0): the binary extended Euclidean algorithm on the plain integers - ~760 halvings and ~380 subtractions of
+// 12-limb numbers (~55 k instructions) against the 381 squarings + 190 products of the Fermat chain (~260 k): 0.1 ms instead of 1.0 ms
+// when one lane converts one point (k_jac_compress: the tail of every kzg_g1_msm / kzg_g1_msm_setup call).  Variable time and full of
+// data-dependent branches: right for a single lane, wasteful for a wavefront of independent inversions (those keep fp_inv).
+// Input and output in Montgomery form: the algorithm inverts x = a R as an integer, t = a^-1 R^-1; two products by R^2 give a^-1 R.
+__device__ inline Fp fp_inv_lone_lane(const Fp& a) {
+    auto is_one = [](const Fp& x) {
+        uint32_t o = x.l[0] ^ 1u;
+#pragma unroll
+        for (int i = 1; i < 12; i++) o |= x.l[i];
+        return o == 0;
+    };
+    auto shr1 = [](Fp& x, uint32_t top) {
+#pragma unroll
+        for (int i = 0; i < 11; i++) x.l[i] = (x.l[i] >> 1) | (x.l[i + 1] << 31);
+        x.l[11] = (x.l[11] >> 1) | (top << 31);
+    };
+    auto half_mod = [&](Fp& x) {  // x / 2 mod p for 0 <= x < p  (x + p < 2^382 stays inside 12 limbs, the carry is always 0)
+        uint32_t c = 0;
+        if (x.l[0] & 1u) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) x.l[i] = addc(x.l[i], consts::FP_MOD[i], c);
+        }
+        shr1(x, c);
+    };
+    auto sub_mod = [](Fp& x, const Fp& y) {  // x - y mod p for 0 <= x, y < p
+        uint32_t b = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) x.l[i] = subb(x.l[i], y.l[i], b);
+        if (b) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < 12; i++) x.l[i] = addc(x.l[i], consts::FP_MOD[i], c);
+        }
+    };
+    Fp u = a, v = fp_const(consts::FP_MOD), x1 = FpF::zero(), x2 = FpF::zero();
+    x1.l[0] = 1u;
+#pragma unroll 1
+    while (!is_one(u) && !is_one(v)) {
+#pragma unroll 1
+        while ((u.l[0] & 1u) == 0) {
+            shr1(u, 0u);
+            half_mod(x1);
+        }
+#pragma unroll 1
+        while ((v.l[0] & 1u) == 0) {
+            shr1(v, 0u);
+            half_mod(x2);
+        }
+        Fp d;
+        uint32_t b = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) d.l[i] = subb(u.l[i], v.l[i], b);
+        if (!b) {  // u >= v
+            u = d;
+            sub_mod(x1, x2);
+        } else {
+            uint32_t b2 = 0;
+#pragma unroll
+            for (int i = 0; i < 12; i++) v.l[i] = subb(v.l[i], u.l[i], b2);
+            sub_mod(x2, x1);
+        }
+    }
+    const Fp t = is_one(u) ? x1 : x2;  // (a R)^-1 as a plain integer
+    const Fp r2 = fp_const(consts::FP_R2);
+    return fp_mul(fp_mul(t, r2), r2);
+}
+
 // a^e with a 3-bit sliding window over the CONSTANT exponent e (the same in every lane, so the window walk is
 // wave-uniform and the table of odd powers a, a^3, a^5, a^7 lives in registers, picked by selects).  For the
 // square-root exponent: 379 squarings + 107 multiplications + 4 for the table, against 379 + 229 bit by bit.
@@ -304,13 +372,14 @@ __device__ inline void g1_compress(uint8_t* b, const G1Aff& a, bool inf) {
 }
 
 // Jacobian -> affine (one Fermat inversion); returns false for the identity
+template <bool LONE_LANE = false>
 __device__ inline bool g1_to_affine(G1Aff& out, const G1Jac& p) {
     if (g1_is_identity(p)) {
         out.x = FpF::zero();
         out.y = FpF::zero();
         return false;
     }
-    Fp zi = fp_inv(p.z), zi2 = fp_sqr(zi);
+    Fp zi = LONE_LANE ? fp_inv_lone_lane(p.z) : fp_inv(p.z), zi2 = fp_sqr(zi);
     out.x = fp_mul(p.x, zi2);
     out.y = fp_mul(p.y, fp_mul(zi2, zi));
     return true;

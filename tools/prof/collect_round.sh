@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the profile set of a round on the GPU box (run through gpurun from the repo root):
-#   tools/prof/collect_round.sh <tag> [group]
+#   tools/prof/collect_round.sh <tag> [group]   (round 6: r6)
 # 1. rocprofv3 --kernel-trace --stats of THE DRIVER'S COMMAND (python3 bench.py --gpus 1 --steps 20 --warmup 5)
 #                                                                          -> gpurun_out/<tag>_stats/
 # 2. PMC passes (each in its own run; single stream so dispatches do not overlap; ONE launch group of the bench's size):
@@ -43,3 +43,5 @@ done
 [ "${SKIP_PMC:-0}" = "1" ] || python3 tools/prof/pmc_to_json.py gpurun_out/${tag}_config_pmc 0 > gpurun_out/${tag}_config_pmc.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 tail -1 gpurun_out/${tag}_bench.json | cut -c1-400
+# 5. the kernel resource table of the library these profiles describe (code-object metadata: VGPRs, LDS, scratch, waves per SIMD)
+python3 tools/prof/kernel_resources.py > gpurun_out/${tag}_kernel_resources.txt 2>/dev/null
