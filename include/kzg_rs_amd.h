@@ -316,7 +316,10 @@ KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t *points48, const uint8_t *scala
  * host pointers; n <= 2^26.  Needs a handle made from a trusted-setup file (KZG_BADARGS otherwise; KZG_BAD_SETUP when a point is
  * outside G1).  Nothing is decoded per call - the tables were made when the setup was loaded; from 32 768 terms on the sum takes the
  * fixed-base form (csrc/msm_fixed.hpp: 16-bit signed windows over rows 2^(16 v) P_j, half the bucket additions of the
- * variable-base form).  KZG_OPTIONS g1_msm_setup_form = window | fixed forces a form (same result bit for bit). */
+ * variable-base form).  KZG_OPTIONS g1_msm_setup_form = window | fixed forces a form (same result bit for bit).
+ * 2^20 terms: 5.1-5.4 ms, 6.0 ms for the call.  Like kzg_g1_msm, the timing assumes scalars whose digits spread over the buckets
+ * (random, or hash-derived as in the verifier): a million EQUAL scalars put every entry of a window into one bucket, which one
+ * lane then adds one after the other - the sum is still exact, the call takes on the order of a second. */
 KzgRet kzg_g1_msm_setup(uint8_t out[48], const uint8_t *scalars, size_t n, const KzgSettings *s);
 /* out48[i] = compress(scalars[i] * G1::generator()); scalars n * 32 bytes big-endian (reduced mod r).
  * Prover-side helper used to build synthetic (commitment, proof) pairs under a
