@@ -176,3 +176,34 @@ def test_window_form_fold_tree_with_a_ragged_second_level(base):
     sums = [sum(int(c) * v for c, v in zip(row, vals) if c) % R for row in cnt]
     want = O.g1_msm(b"".join(base), b"".join(v.to_bytes(32, "big") for v in sums), N)
     assert got == [want.hex(), want.hex()]
+
+
+def test_g1_msm_setup_two_million_terms(settings, base):
+    """beyond BASELINE configs[3]'s size: 2^21 + 5 terms (5 590 workgroups of the fixed-base form, a fold over as many layers)"""
+    n = (1 << 21) + 5
+    sc = _random_scalars(n, 21)
+    words = np.ascontiguousarray(sc).view(">u4")          # (n, 8): the scalars' 32-bit words, most significant first
+    idx = np.arange(n) % N
+    tot = [0] * N
+    for k in range(8):                                       # per point, the sum of word k over its ~513 terms: below 2^42, exact in a double
+        part = np.bincount(idx, weights=words[:, k].astype(np.float64), minlength=N)
+        for j in range(N):
+            tot[j] += int(part[j]) << (32 * (7 - k))
+    want = O.g1_msm(b"".join(base), b"".join((v % R).to_bytes(32, "big") for v in tot), N)
+    assert _call(settings, sc) == want
+
+
+def test_g1_msm_setup_with_an_identity_among_the_setup_points():
+    """A trusted setup whose G1 section holds the point at infinity (the loader decodes unchecked, build.rs:66-70; the identity is a
+    member of G1): its terms add nothing, in both forms."""
+    ts = open(os.path.join(O.ROOT, "kzg_rs_amd", "data", "trusted_setup.txt")).read().split("\n")
+    brp = lambda i: int(format(i, "012b")[::-1], 2)
+    lines = list(ts)
+    lines[2 + brp(5)] = G1_INF.hex()       # g1_points[5] of the handle
+    lines[2 + brp(4095)] = G1_INF.hex()
+    st = KzgSettings.load_trusted_setup_text("\n".join(lines).encode())
+    pts = [bytes.fromhex(lines[2 + brp(i)]) for i in range(N)]
+    assert st.g1_point(5) == G1_INF and st.g1_point(6) == pts[6]
+    for n in (4096 + 17, 40_000):       # the window form, the fixed-base form
+        sc = _random_scalars(n, 300 + n)
+        assert _call(st, sc) == _expected(pts, sc)
