@@ -180,6 +180,27 @@ int main(int argc, char** argv) {
     host_batch_challenges(rb.data(), big.data(), 40, 1024, 1024, 0);
     for (size_t b = 0; b < 40; b++) host_batch_challenges(rs.data() + 32 * b, big.data() + 160 * 1024 * b, 1, 1024, 1024, 0);
     CHECK(rb == rs);
+    {   // the pool's FIRST job (round-5 advisor finding (a), below): at most the workers it asked for
+        hostpool::Pool& P = hostpool::pool();
+        size_t before;
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            before = P.workers;
+        }
+        const size_t BLOB = (size_t)32 * KZG_HOST_FE_PER_BLOB;
+        std::vector<uint8_t> blobs(BLOB * 2), cs(48 * 2), z(64), want(64);
+        for (auto& x : blobs) x = (uint8_t)rng();
+        for (size_t i = 0; i < 2; i++) host_blob_challenge(want.data() + 32 * i, blobs.data() + BLOB * i, cs.data() + 48 * i);
+        hostpool::JobRef j = hostpool::make(z.data(), blobs.data(), cs.data(), 2);
+        hostpool::post(j, 2);
+        hostpool::finish(*j);
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            CHECK(before == 0 && P.workers <= 2);   // the pool's first job: two blobs, two threads wanted
+            CHECK(P.workers <= P.max_workers);
+        }
+        CHECK(z == want);
+    }
     {   // the per-blob challenges on the persistent pool (hostpool): 8 caller threads at once, each with jobs of 1..5 blobs, some of
         // them posted and finished by different threads (the small-call queue's leader finishes jobs its followers posted)
         const size_t BLOB = (size_t)32 * KZG_HOST_FE_PER_BLOB, NB = 5;
@@ -207,6 +228,34 @@ int main(int argc, char** argv) {
             });
         for (auto& th : callers) th.join();
         CHECK(wrong.load() == 0);
+    }
+    {   // round-5 advisor findings on the pool.  (a) post() started all max_workers threads for the first job of two blobs, whatever it
+        // wanted (the spawn loop compared against a count that did not move): a job that wants k workers starts at most k beyond the
+        // idle ones.  (b) JoinOnExit: a scope that posted jobs over its own buffers leaves - by return or by exception - only after
+        // the workers are done with them.
+        const size_t BLOB = (size_t)32 * KZG_HOST_FE_PER_BLOB;
+        for (int thrown = 0; thrown < 2; thrown++) {
+            std::vector<uint8_t> zz(32 * 4, 0xee), bl(BLOB * 4), cc(48 * 4), w4(32 * 4);
+            for (auto& x : bl) x = (uint8_t)rng();
+            for (size_t i = 0; i < 4; i++) host_blob_challenge(w4.data() + 32 * i, bl.data() + BLOB * i, cc.data() + 48 * i);
+            bool done_at_exit = false;
+            try {
+                hostpool::JobRef jj;
+                struct Probe {  // destroyed AFTER the guard below (declared before it): sees the state the guard leaves
+                    hostpool::JobRef* j;
+                    bool* out;
+                    ~Probe() { *out = *j && (*j)->done.load() == (*j)->n; }
+                } probe{&jj, &done_at_exit};
+                hostpool::JoinOnExit joined;
+                jj = hostpool::make(zz.data(), bl.data(), cc.data(), 4);
+                joined.add(jj);
+                hostpool::post(jj, 3);
+                if (thrown) throw std::bad_alloc();   // an error path that never reaches a finish() of its own
+            } catch (const std::bad_alloc&) {
+            }
+            CHECK(done_at_exit);
+            CHECK(zz == w4);
+        }
     }
     printf("failures %d\n", failures);
     return failures ? 1 : 0;
