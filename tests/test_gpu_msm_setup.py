@@ -207,3 +207,11 @@ def test_g1_msm_setup_with_an_identity_among_the_setup_points():
     for n in (4096 + 17, 40_000):       # the window form, the fixed-base form
         sc = _random_scalars(n, 300 + n)
         assert _call(st, sc) == _expected(pts, sc)
+
+
+def test_g1_msm_setup_randomised_check():
+    """12 s of tools/fuzz_g1_msm_setup.py: random sizes on both sides of the switch to the fixed-base form, scalar patterns that collide in its
+    buckets and partitions (one bucket for the whole call, the recoding's edge digits, one window per term ...), every sum against the
+    oracle.  (Longer runs: `python tools/fuzz_g1_msm_setup.py 600 <seed>`.)"""
+    out = subprocess.run([sys.executable, os.path.join(O.ROOT, "tools", "fuzz_g1_msm_setup.py"), "12", "20261004"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "no mismatch" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
