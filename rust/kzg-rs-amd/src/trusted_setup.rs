@@ -109,6 +109,18 @@ impl KzgSettings {
         Ok(KzgSettings { roots_of_unity, g1_points, g2_points, handle: Arc::new(ffi::Handle(raw)) })
     }
 
+    /// `sum_i scalars[i] * g1_points[i mod 4096]` - `G1Projective::msm_variable_base` (kzg-rs `src/kzg_proof.rs:419,429,430`) when its
+    /// points are this setup's own Lagrange points: computed from the tables the library made when the setup was loaded, nothing
+    /// decoded per call (`kzg_g1_msm_setup`; not a function of kzg-rs).  Scalars as big-endian bytes, any value below 2^256
+    /// (reduced mod r like `Scalar::from_raw`); the sum comes back compressed.  Needs settings loaded from a trusted-setup file
+    /// (`from_parts` handles carry no G1 section: `KzgError::BadArgs`).
+    pub fn g1_msm_over_setup_points(&self, scalars: &[crate::dtypes::Bytes32]) -> Result<crate::dtypes::Bytes48, KzgError> {
+        let mut out = [0u8; 48];
+        // (`Bytes32` is #[repr(transparent)] over [u8; 32]: a slice of them is n * 32 contiguous bytes)
+        ffi::check(unsafe { ffi::kzg_g1_msm_setup(out.as_mut_ptr(), scalars.as_ptr() as *const u8, scalars.len(), self.handle.0) })?;
+        Ok(crate::dtypes::Bytes48(out))
+    }
+
     /// The devices this handle runs on and how its partial sums travel: 0 one device, 1 host staging, 2 in-process RCCL.
     pub fn devices(&self) -> Result<(Vec<i32>, i32), KzgError> {
         let (mut n, mut ex, mut devs) = (0usize, 0 as c_int, [0 as c_int; 64]);
