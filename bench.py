@@ -333,7 +333,12 @@ def config_legs(settings, torch, dev, no_cpu=False):
                       "ms_call_wall": round(w4, 3), "ms_call_wall_all_runs": [round(x, 3) for x in wall4], "pairs_per_s": round(n4 / t4 * 1e3, 1), "ns_per_term": round(t4 * 1e6 / n4, 3),
                       "roofline": {"bound": "valu-issue", "algorithmic_bytes_per_pair": 32, "achieved": round(32 * n4 / t4 / 1e6, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(32 * n4 / t4 / 1e6 / HBM_PEAK_GBS, 6),
-                                   "note": "algorithmic bytes = the scalars (32 B per term): the points are the handle's, resident as table rows (16 MB)"},
+                                   "note": "algorithmic bytes = the scalars (32 B per term): the points are the handle's, resident as table rows (16 MB).  What the bucket "
+                                           "kernel moves beyond them (hbm_traffic_bytes below: ~1.4 GB at 2^20 terms) is 16 row reads of 128 B per term = 2.1 GB of requests against "
+                                           "a 16 MB table, of which the ~60 % that miss the 4 MB L2 of their XCD are counted (they are served by the 256 MB MALL, not by HBM: the "
+                                           "counter is L2-to-fabric traffic), plus the partitioned entry list written and read once (2 x 67 MB) and the workgroups' bucket sums "
+                                           "(70 MB).  The same launch over a 128 KB table (rows of 64 points) takes the same time (profiles/r6_fb_window_timeline.txt): the kernel is "
+                                           "issue-bound, the row traffic is not what limits it"},
                       "form": "fixed base (csrc/msm_fixed.hpp): 16 signed 16-bit windows, 16 bucket additions per term into ONE set of 2^15 buckets; entries partitioned in HBM by "
                               "the bucket's high 7 bits (counting sort, 4 B per entry), each workgroup sorts <= 12 288 entries of one partition by the low 8 bits in LDS (48 KB) and "
                               "accumulates one bucket per lane in registers (mixed additions of 128-B affine rows 2^(16 v) P_j)",
