@@ -70,7 +70,10 @@ __global__ void k_jac_compress_n(const G1Jac* __restrict__ p, uint8_t* __restric
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     G1Aff a;
-    bool finite = g1_to_affine(a, p[i]);
+    // up to one wavefront of points (a prover chunk's commitments or proofs): the binary Euclidean inversion - 0.1 ms for a lone lane, and
+    // still ahead of the Fermat chain's 1.0 ms when 64 lanes run it side by side (every lane waits for the longest run of halvings among
+    // them: measured 5.54 against 5.68 ms for a 64-blob commitment call, 2.5 against 3.65 ms for one blob)
+    bool finite = count <= 64 ? g1_to_affine<true>(a, p[i]) : g1_to_affine<false>(a, p[i]);
     g1_compress(out + 48 * (size_t)i, a, !finite);
 }
 

@@ -65,8 +65,12 @@ static KzgRet setup_msm(const KzgSettings* s, ProverBufs& b, size_t m) {
     const int total = (int)(m * NT);
     hipLaunchKernelGGL(k_commit_terms, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->s1, b.d_tp, b.d_ts, total);
     hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->s1, b.d_sc, total);
+    // the setup's AFFINE table rows when the handle has them (mixed additions: 8M + 3S instead of 12M + 4S per bucket entry), and the
+    // (window, chunk group) workgroups sized so that their sorted lists stay in LDS: one chunk (4 096 entries) per workgroup for a few
+    // blobs, two (8 192) from 16 blobs on - rounds 2-5 ran Jacobian rows with four chunks per workgroup and the list in global memory
+    const bool aff = msm_affine_enabled() && s->d_g1_mult_aff != nullptr;
     MsmDesc d{};
-    d.mult = s->d_g1_mult;
+    d.mult = aff ? (void*)s->d_g1_mult_aff : s->d_g1_mult;
     d.pflag = s->d_g1_flag;
     d.scalars = b.d_sc;
     d.term_point = b.d_tp;
@@ -78,7 +82,7 @@ static KzgRet setup_msm(const KzgSettings* s, ProverBufs& b, size_t m) {
     d.stride = (int)NT;
     d.slices = 1;
     d.chunks = MSM_CHUNKS;
-    d.chunks_per_block = m >= 16 ? 4 : 1;
+    d.chunks_per_block = aff ? (m >= 16 ? 2 : 1) : (m >= 16 ? 4 : 1);
     const unsigned slots = MSM_CHUNKS / d.chunks_per_block;
     KzgRet rc_save = msm_save_reserve(s, 8, slots, (unsigned)m);
     if (rc_save != KZG_OK) return rc_save;
@@ -86,7 +90,8 @@ static KzgRet setup_msm(const KzgSettings* s, ProverBufs& b, size_t m) {
     if (!fp29_enabled()) msm_window_launch<Curve32, false>(d, 8, slots, (unsigned)m, s->ws.d_msm_save, s->ws.cap_msm_save, s->s1);
     else
 #endif
-        msm_window_launch<Curve29, false>(d, 8, slots, (unsigned)m, s->ws.d_msm_save, s->ws.cap_msm_save, s->s1);
+        if (aff) msm_window_launch<Curve29Aff, true>(d, 8, slots, (unsigned)m, s->ws.d_msm_save, s->ws.cap_msm_save, s->s1);
+    else msm_window_launch<Curve29, false>(d, 8, slots, (unsigned)m, s->ws.d_msm_save, s->ws.cap_msm_save, s->s1);
     hipLaunchKernelGGL(k_msm_combine, dim3((unsigned)m), dim3(64), 0, s->s1, b.d_win, b.d_res, (int)slots, 8);
     hipLaunchKernelGGL(k_jac_compress_n, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, s->s1, b.d_res, b.d_out, (int)m);
     HIPCHK(hipGetLastError());
