@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the north-star path: verify_blob_kzg_proof_batch on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|configs1|config5] [--blobs n] [--group G] [--inflight 3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|configs1|config5] [--blobs n] [--group G] [--inflight 4]
+                    [--force-collectives] [--no-shard-leg] [--no-configs] [--no-concurrent] [--no-latency] [--no-self-check] [--no-cpu-baseline]
 
 One "step" = one LAUNCH GROUP: `--group` (256) independent verify_blob_kzg_proof_batch calls
 (src/kzg_proof.rs:472-525) of `--blobs` (1 024, BASELINE.json configs[1]) synthetic blobs each, all already resident
@@ -22,6 +23,14 @@ Rank 0 prints ONE JSON line.
 
 `python3 bench.py --gpus N` from a bare command (no WORLD_SIZE in the environment) starts the N ranks itself, as child
 processes, BEFORE anything in this process has touched the GPU, and exits with their worst return code.
+
+The default one-GPU run also measures BASELINE configs[4]'s SHARD SHAPE on that one GPU (`configs.config5_shard`: 8 batches x 32 768 blobs
+per step through the very code path `--gpus N` runs - `--workload config5 --force-collectives` in a child process, a world of one rank over
+RCCL - with its stage split and a poisoned batch), so that a later `--gpus N` curve has a like-for-like N = 1 point
+(`multi_gpu.efficiency_vs`); a pre-flight sizes the variants against free HBM and shrinks the launch group instead of dying.  `configs.config3`
+/ `configs.config4`: BASELINE configs[2] (evaluation only) and configs[3] (2^20-term MSM over the setup's points, kzg_g1_msm_setup);
+`end_to_end.large_calls`: ONE call with a Vec<Blob> of 8 192 / 32 768 blobs.  The `roofline` / `path` / `valu` blocks are assembled by
+kzg_rs_amd/benchline.py (its docstring states the rules; `roofline.inputs` carries the measurement they follow from).
 
 Also in the line: `self_check` (the negative control THROUGH THE BENCHMARKED ENTRY POINT: five launch groups of the full
 shape through kzg_verify_blob_kzg_proof_batch_groups_device with the benchmark's groups in flight, a wrong proof, a field
