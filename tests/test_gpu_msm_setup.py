@@ -215,3 +215,13 @@ def test_g1_msm_setup_randomised_check():
     oracle.  (Longer runs: `python tools/fuzz_g1_msm_setup.py 600 <seed>`.)"""
     out = subprocess.run([sys.executable, os.path.join(O.ROOT, "tools", "fuzz_g1_msm_setup.py"), "12", "20261004"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "no mismatch" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
+def test_g1_msm_setup_argument_checks(settings):
+    L = api.lib()
+    out = C.create_string_buffer(48)
+    assert L.kzg_g1_msm_setup(out, None, 5, settings._h) != 0                       # null scalars with n > 0
+    assert L.kzg_g1_msm_setup(None, bytes(32), 1, settings._h) != 0                 # null output
+    assert L.kzg_g1_msm_setup(out, bytes(32), (1 << 26) + 1, settings._h) != 0      # beyond the documented limit (checked before anything is read)
+    assert b"2^26" in L.kzg_last_error()
+    assert L.kzg_g1_msm_setup(out, None, 0, settings._h) == 0 and out.raw == G1_INF  # the empty sum needs no scalars
