@@ -315,7 +315,7 @@ KzgRet kzg_g1_msm(uint8_t out[48], const uint8_t *points48, const uint8_t *scala
  * at the reference's call sites (src/kzg_proof.rs:419,429,430) when the points are trusted-setup points, and the shape of
  * BASELINE.json configs[3] ("2^20 trusted-setup points x random Fr scalars").  scalars: n * 32 bytes big-endian (reduced mod r);
  * host pointers; n <= 2^26.  Needs a handle made from a trusted-setup file (KZG_BADARGS otherwise; KZG_BAD_SETUP when a point is
- * outside G1).  Nothing is decoded per call - the tables were made when the setup was loaded; from 32 768 terms on the sum takes the
+ * outside G1).  Nothing is decoded per call - the tables were made when the setup was loaded; the sum takes the
  * fixed-base form (csrc/msm_fixed.hpp: 16-bit signed windows over rows 2^(16 v) P_j, half the bucket additions of the
  * variable-base form).  KZG_OPTIONS g1_msm_setup_form = window | fixed forces a form (same result bit for bit).
  * 2^20 terms: 5.1-5.4 ms, 6.0 ms for the call.  Like kzg_g1_msm, the timing assumes scalars whose digits spread over the buckets

@@ -214,11 +214,14 @@ extern "C" KzgRet kzg_compute_blob_kzg_proof(uint8_t* proofs48, const uint8_t* b
 // reference's own call sites src/kzg_proof.rs:419,429,430 when their points are setup points).  scalars: n x 32 big-endian bytes,
 // any value below 2^256 (reduced mod r like Scalar::from_raw).  Nothing is decoded per call: the tables were made when the setup
 // was loaded.  Two forms, same result bit for bit:
-//   n <  FBM_MIN_TERMS   the verification path's window kernel (GLV, 8-bit windows) over the setup's affine table rows
-//   n >= FBM_MIN_TERMS   the fixed-base form of msm_fixed.hpp: 16-bit signed windows over rows 2^(16 v) P_j (16 MB with the doubled rows, made by the
-//                       first such call), 16 bucket additions per term instead of 32, one shared bucket set
+//   fixed   the fixed-base form of msm_fixed.hpp, the default at EVERY size: 16-bit signed windows over rows 2^(16 v) P_j (16 MB with the
+//           doubled rows, made by the first call), 16 bucket additions per term instead of 32, one shared bucket set.  Measured against
+//           the window form at 1 / 1 024 / 4 096 / 32 768 / 65 536 / 2^20 terms: 0.39 / 0.69 / 0.77 / 1.04 / 1.30 / 5.2 ms against
+//           1.14 / 1.19 / 1.63 / 1.50 / 1.83 / 8.1 ms
+//   window  the verification path's window kernel (GLV, 8-bit windows) over the setup's affine table rows: the fallback when the
+//           fixed-base form's bucket sums would pass 2 GiB (above ~2^24.6 terms) or the handle has no affine rows (A/B build, fp29=0)
 // option g1_msm_setup_form = window | fixed forces one (tests, A/B).  timings: [2] the MSM, [6] = 0 (no decode, no tables).
-constexpr size_t FBM_MIN_TERMS = 32768;
+constexpr size_t FBM_MIN_TERMS = 1;
 static KzgRet fb_rows_ready(const KzgSettings* s) {
     if (s->d_g1_fb_rows) return KZG_OK;
     const int N = s->n_g1;

@@ -1,7 +1,7 @@
 """kzg_g1_msm_setup: G1Projective::msm_variable_base (call sites src/kzg_proof.rs:419,429,430) over the handle's own Lagrange
 points (src/trusted_setup.rs:20-26) - term i = scalars[i] x g1_points[i mod 4096] - against the CPU oracle's MSM.  Both forms
-(csrc/capi_prover.hpp): the verification path's window kernel over the setup's affine table rows (n < 32 768) and the fixed-base
-form of csrc/msm_fixed.hpp (16-bit signed windows, partitioned bucket lists).  By linearity the expected value is the oracle's
+(csrc/capi_prover.hpp): the fixed-base form of csrc/msm_fixed.hpp (16-bit signed windows, partitioned bucket lists; the default at every
+size) and the verification path's window kernel over the setup's affine table rows (the fallback, forced through KZG_OPTIONS here).  By linearity the expected value is the oracle's
 4 096-term MSM over each point's scalars summed mod r; bit-exact."""
 import ctypes as C
 import os
@@ -72,10 +72,10 @@ def test_setup_point_matches_the_handle(settings, base):
     assert _call(settings, np.zeros((0, 32), dtype=np.uint8)) == G1_INF  # the empty sum
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 4095, 4096, 4097, 12289, 32767, 32768, 32769, 100_003, 1 << 18])
+@pytest.mark.parametrize("n", [1, 2, 5, 767, 768, 769, 1023, 1025, 4095, 4096, 4097, 12289, 32767, 32768, 32769, 100_003, 1 << 18])
 def test_g1_msm_setup_vs_oracle(settings, base, n):
-    """sizes on either side of the point count, of the window form's slice boundaries and of the switch to the fixed-base form
-    (32 768 terms); random scalars over the whole 256-bit range with 0, r - 1, r and 2^256 - 1 among them"""
+    """sizes on either side of the point count, of the fixed-base form's first full slice (768 terms x 16 windows = 12 288 entries), of a
+    workgroup's term block (1 024) and around 32 768; random scalars over the whole 256-bit range with 0, r - 1, r and 2^256 - 1 among them"""
     sc = _random_scalars(n, 100 + n)
     assert _call(settings, sc) == _expected(base, sc)
 
@@ -195,18 +195,40 @@ def test_g1_msm_setup_two_million_terms(settings, base):
 
 def test_g1_msm_setup_with_an_identity_among_the_setup_points():
     """A trusted setup whose G1 section holds the point at infinity (the loader decodes unchecked, build.rs:66-70; the identity is a
-    member of G1): its terms add nothing, in both forms."""
+    member of G1): its terms add nothing - in the default (fixed-base) form here, and in the window form through a child process."""
     ts = open(os.path.join(O.ROOT, "kzg_rs_amd", "data", "trusted_setup.txt")).read().split("\n")
     brp = lambda i: int(format(i, "012b")[::-1], 2)
     lines = list(ts)
     lines[2 + brp(5)] = G1_INF.hex()       # g1_points[5] of the handle
     lines[2 + brp(4095)] = G1_INF.hex()
-    st = KzgSettings.load_trusted_setup_text("\n".join(lines).encode())
+    txt = "\n".join(lines).encode()
+    st = KzgSettings.load_trusted_setup_text(txt)
     pts = [bytes.fromhex(lines[2 + brp(i)]) for i in range(N)]
     assert st.g1_point(5) == G1_INF and st.g1_point(6) == pts[6]
-    for n in (4096 + 17, 40_000):       # the window form, the fixed-base form
+    want = {}
+    for n in (4096 + 17, 40_000):
         sc = _random_scalars(n, 300 + n)
-        assert _call(st, sc) == _expected(pts, sc)
+        want[n] = _expected(pts, sc)
+        assert _call(st, sc) == want[n]
+    code = (
+        "import sys, ctypes as C, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from kzg_rs_amd import api\n"
+        "st = api.KzgSettings.load_trusted_setup_text(open(sys.argv[1], 'rb').read())\n"
+        "for n in (4096 + 17, 40000):\n"
+        "    sc = np.random.Generator(np.random.PCG64(300 + n)).integers(0, 256, size=(n, 32), dtype=np.uint8)\n"
+        "    sc[n // 2] = 0; sc[n - 1] = np.frombuffer((%d - 1).to_bytes(32, 'big'), dtype=np.uint8); sc[1] = 0xFF; sc[2] = np.frombuffer((%d).to_bytes(32, 'big'), dtype=np.uint8)\n"
+        "    out = C.create_string_buffer(48)\n"
+        "    api._chk(api.lib().kzg_g1_msm_setup(out, sc.ctypes.data_as(C.c_char_p), n, st._h))\n"
+        "    print('SUM', n, out.raw.hex())\n" % (O.ROOT, R, R))
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".txt") as f:
+        f.write(txt)
+        f.flush()
+        r = subprocess.run([sys.executable, "-c", code, f.name], env=dict(os.environ, KZG_OPTIONS="g1_msm_setup_form=window"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    got = {int(ln.split()[1]): ln.split()[2] for ln in r.stdout.splitlines() if ln.startswith("SUM")}
+    assert got == {n: w.hex() for n, w in want.items()}
 
 
 def test_g1_msm_setup_randomised_check():
