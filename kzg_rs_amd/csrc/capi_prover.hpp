@@ -59,10 +59,39 @@ static void prover_release(const KzgSettings* s) {
     delete s->prover;
     s->prover = nullptr;
 }
+static KzgRet fb_rows_ready(const KzgSettings* s);
 // m MSMs: out[b] = compress(sum_i sc[b][i] * g1_points[i]); sc = plain canonical scalars (destroyed: GLV split in place)
 static KzgRet setup_msm(const KzgSettings* s, ProverBufs& b, size_t m) {
     const size_t NT = (size_t)FE_PER_BLOB;
     const int total = (int)(m * NT);
+    // One or two blobs: every sum through the FIXED-BASE form of kzg_g1_msm_setup (msm_fixed.hpp: a 4 096-term sum in ~0.8-1.1 ms;
+    // the window kernels below need ~1.6 ms for one blob and pay off from a handful of blobs per launch on).  The row sums stay on the
+    // main stream here: the proof path's second stream is busy with the commitments' decode.
+    static const size_t fb_max_blobs = (size_t)std::max(0L, std::min(8L, opt_int("prover_fixed_base_max_blobs", 2)));
+    if (m <= fb_max_blobs && msm_affine_enabled() && s->d_g1_mult_aff && (size_t)s->n_g1 == NT && NT * 2 * FBM_WINDOWS <= 131072) {
+        KzgRet rc = fb_rows_ready(s);
+        if (rc != KZG_OK) return rc;
+        const int L = FBM_SLICE_ENTRIES;
+        const unsigned Z = fb_max_blocks((size_t)FBM_WINDOWS * NT, L);
+        Workspace& w = s->ws;
+        const size_t save_bytes = (size_t)Z * 256 * MSM_SAVE2_WORDS * 4;
+        if (save_bytes > w.cap_msm_save) {
+            if (w.d_msm_save) (void)hipFree(w.d_msm_save);
+            w.d_msm_save = nullptr;
+            w.cap_msm_save = 0;
+            HIPCHK(hipMalloc(&w.d_msm_save, save_bytes));
+            w.cap_msm_save = save_bytes;
+        }
+        int gp = 0;
+        (void)msm_large_tail_groups(Z, std::max(11, (int)((Z + MSM_FOLD_MAX_GROUPS - 1) / MSM_FOLD_MAX_GROUPS)), &gp);
+        uint8_t* tmp = nullptr;
+        if ((rc = g1msm_scratch(s, fb_tail_bytes(gp), &tmp)) != KZG_OK) return rc;
+        for (size_t k = 0; k < m; k++)
+            HIPCHK(fb_msm_launch(b.d_sc + k * NT, s->d_g1_flag, (int)NT, s->n_g1, s->d_g1_fb_rows, s->d_fb_plan, b.d_sorted, w.d_msm_save, tmp, b.d_res + k, L, 11, nullptr, s->s1));
+        hipLaunchKernelGGL(k_jac_compress_n, dim3(1), dim3(64), 0, s->s1, b.d_res, b.d_out, (int)m);
+        HIPCHK(hipGetLastError());
+        return KZG_OK;
+    }
     hipLaunchKernelGGL(k_commit_terms, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->s1, b.d_tp, b.d_ts, total);
     hipLaunchKernelGGL(k_glv_split, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s->s1, b.d_sc, total);
     // the setup's AFFINE table rows when the handle has them (mixed additions: 8M + 3S instead of 12M + 4S per bucket entry), and the
