@@ -273,7 +273,7 @@ KzgRet kzg_verify_blob_kzg_proof_batches(bool *ok_out, uint8_t *err_out, const u
  * g1_points[i], one 4096-term MSM per blob over the settings' Lagrange points.  blobs: n * 131072 bytes (host), out:
  * n * 48 bytes.  KZG_BADARGS for a non-canonical field element, or settings without G1 points.  1.1 ms for one blob (the fixed-base
  * form of kzg_g1_msm_setup per blob, for one or two blobs), 5.5 ms for 64 (mixed additions over the setup's affine table rows);
- * kzg_compute_blob_kzg_proof: 2.7 / 6.1 ms. */
+ * kzg_compute_blob_kzg_proof: 1.9 / 6.2 ms. */
 KzgRet kzg_blob_to_kzg_commitment(uint8_t *out48, const uint8_t *blobs, size_t n, const KzgSettings *s);
 /* c-kzg-4844's compute_kzg_proof for n (blob, z) pairs: ys_out[i] = p_i(z_i) (32 bytes big-endian), proofs_out[i] =
  * commitment to the quotient (p_i(X) - y_i) / (X - z_i) (48 bytes), z = a root of unity included.  zs: n * 32 bytes

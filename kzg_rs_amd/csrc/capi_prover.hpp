@@ -11,8 +11,9 @@ struct ProverBufs {
     uint32_t *d_tp = nullptr, *d_ts = nullptr, *d_sorted = nullptr, *d_status = nullptr, *d_cflag = nullptr;
     G1Jac *d_win = nullptr, *d_res = nullptr;
     G1Aff* d_cpts = nullptr;
+    G1Jac29Mem* d_cmult = nullptr;  // the commitments' multiples, a by-product of their eight-lane decode (never read)
     ~ProverBufs() {
-        void* ptrs[] = {d_blobs, d_out, d_cm, d_sc, d_z, d_y, d_tp, d_ts, d_sorted, d_status, d_cflag, d_win, d_res, d_cpts};
+        void* ptrs[] = {d_blobs, d_out, d_cm, d_sc, d_z, d_y, d_tp, d_ts, d_sorted, d_status, d_cflag, d_win, d_res, d_cpts, d_cmult};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
     }
@@ -32,6 +33,7 @@ struct ProverBufs {
         HIPCHK(hipMalloc(&d_cm, 48 * CH));
         HIPCHK(hipMalloc(&d_cflag, 4 * CH));
         HIPCHK(hipMalloc(&d_cpts, sizeof(G1Aff) * CH));
+        HIPCHK(hipMalloc(&d_cmult, sizeof(G1Jac29Mem) * MSM_CHUNKS_LATENCY * CH));
         return KZG_OK;
     }
 };
@@ -197,7 +199,16 @@ static KzgRet compute_proofs(uint8_t* proofs48, uint8_t* ys32, const uint8_t* bl
                 HIPCHK(hipStreamWaitEvent(side, s->ev[5], 0));
                 dec = side;
             }
-            hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, dec, b.d_cm, b.d_cm, (int)m, b.d_cpts, b.d_cflag, (int)m, 1);
+            // the commitments' validity (decompression + subgroup test): EIGHT lanes per point where every workgroup of eight points can
+            // have a CU to itself (msm.hpp k_g1_decode_multiples29_quads: 1.2 ms instead of the one-lane kernel's 2.5 - the longest chain of
+            // a one-blob proof call); its table multiples are a by-product nobody reads
+            static const bool dec_quads = fp29_enabled() && ab_flag("decode_quads", true);
+            const unsigned qblocks = (unsigned)((m + DECQ_POINTS_PER_BLOCK - 1) / DECQ_POINTS_PER_BLOCK);
+            if (dec_quads && (int)qblocks <= s->n_cus && DYN_LDS(k_g1_decode_multiples29_quads<MSM_CHUNKS_LATENCY>, DECQ_LDS_BYTES) == hipSuccess)
+                hipLaunchKernelGGL(k_g1_decode_multiples29_quads<MSM_CHUNKS_LATENCY>, dim3(qblocks), dim3(64), DECQ_LDS_BYTES, dec, (const uint8_t*)b.d_cm, (const uint8_t*)b.d_cm, (int)m,
+                                   b.d_cpts, b.d_cflag, b.d_cmult, (int)m, (int)PROVER_CHUNK);
+            else
+                hipLaunchKernelGGL(k_g1_decode, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, dec, b.d_cm, b.d_cm, (int)m, b.d_cpts, b.d_cflag, (int)m, 1);
             if (m <= host_hash_max) {
                 const size_t threads = (size_t)std::max(1L, std::min(16L, opt_int("host_threads", 16)));
                 host_blob_challenges(le.data(), blobs + (size_t)BLOB_BYTES * lo, commitments + 48 * lo, m, threads);

@@ -126,6 +126,10 @@ def test_compute_proofs(settings, osettings):
         api.compute_kzg_proof([blobs[0]], [R.to_bytes(32, "big")], settings)
     with pytest.raises(KzgError):
         api.compute_blob_kzg_proof([blobs[0]], [bytes([0x81]) + bytes(range(1, 48))], settings)
+    with pytest.raises(KzgError):   # one blob, a commitment on the curve but outside G1 (the eight-lane decode beside the fixed-base sum)
+        api.compute_blob_kzg_proof([blobs[0]], [G.off_subgroup_g1()], settings)
+    assert api.compute_blob_kzg_proof(blobs[:2], cs[:2], settings) == ps[:2] and api.compute_blob_kzg_proof(blobs[:3], cs[:3], settings) == ps[:3]
+    assert api.blob_to_kzg_commitment(blobs[:1], settings) == cs[:1] and api.blob_to_kzg_commitment(blobs[:2], settings) == cs[:2]
     # 70 blobs: two launch chunks; an invalid commitment in the second chunk is found by the check that runs beside the chain
     many = [i % 7 for i in range(70)]
     assert api.compute_blob_kzg_proof([blobs[i] for i in many], [cs[i] for i in many], settings) == [ps[i] for i in many]
